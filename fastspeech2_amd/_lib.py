@@ -1,0 +1,144 @@
+"""ctypes binding of libfs2_hip.so (C ABI in include/fs2.h).
+
+There is no CPU or eager-PyTorch fallback: if the shared library is missing or cannot be
+loaded, importing the product path raises immediately (``Fs2LibraryError``).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfs2_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+FS2_PREC_FP32, FS2_PREC_BF16X3, FS2_PREC_BF16 = 0, 1, 2
+PRECISIONS = {"fp32": FS2_PREC_FP32, "bf16x3": FS2_PREC_BF16X3, "bf16": FS2_PREC_BF16}
+
+
+class Fs2LibraryError(RuntimeError):
+    pass
+
+
+class Fs2Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libfs2_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "idim", "odim", "adim", "aheads", "elayers", "eunits", "ddim", "dlayers", "dunits", "ffn_kernel",
+        "dur_layers", "dur_chans", "dur_kernel", "var_layers", "var_chans", "var_kernel", "n_bins",
+        "postnet_layers", "postnet_chans", "postnet_filts", "use_batch_norm", "use_scaled_pos_enc",
+        "reduction_factor", "device")]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Tmax", C.c_int32), ("ilens", C.POINTER(C.c_int64)),
+                ("compat_padded", C.c_int32), ("precision", C.c_int32)]
+
+
+class EncodeIO(C.Structure):
+    _fields_ = [("batch", Batch), ("xs", C.c_void_p), ("ds", C.c_void_p), ("d_log", C.c_void_p),
+                ("d_int", C.c_void_p), ("olens", C.c_void_p), ("enc_out", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class DecodeIO(C.Structure):
+    _fields_ = [("batch", Batch), ("olens", C.POINTER(C.c_int64)), ("Lmax", C.c_int32), ("masked", C.c_int32),
+                ("es", C.c_void_p), ("ps", C.c_void_p), ("es_stride", C.c_int32), ("ps_stride", C.c_int32),
+                ("before", C.c_void_p), ("after", C.c_void_p), ("e_out", C.c_void_p), ("p_out", C.c_void_p),
+                ("qe", C.c_void_p), ("qp", C.c_void_p), ("lr_index", C.c_void_p), ("dec_out", C.c_void_p),
+                ("token_workspace", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class OpGemmArgs(C.Structure):
+    _fields_ = [("R", C.c_int32), ("C", C.c_int32), ("N", C.c_int32), ("ktaps", C.c_int32), ("precision", C.c_int32),
+                ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("resid", C.c_void_p),
+                ("relu_pre", C.c_int32), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
+                ("act_post", C.c_int32), ("dot_w", C.c_void_p), ("dot_b", C.c_void_p), ("dot_out", C.c_void_p),
+                ("y", C.c_void_p), ("row_valid", C.c_void_p)]
+
+
+# every symbol include/fs2.h declares (tests check the library exports all of them)
+EXPORTS = ["fs2_create", "fs2_destroy", "fs2_last_error", "fs2_load_weights", "fs2_token_workspace_bytes",
+           "fs2_encode", "fs2_frame_workspace_bytes", "fs2_decode", "fs2_set_profiling", "fs2_get_profile",
+           "fs2_op_conv_gemm", "fs2_op_attention", "fs2_op_length_regulate", "fs2_op_bucketize"]
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/fs2_runtime.hip for gfx950 into fastspeech2_amd/libfs2_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    hdr = os.path.join(_HERE, "..", "include", "fs2.h")
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(p) for p in srcs + [hdr])
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "fs2_runtime.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises Fs2LibraryError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Fs2LibraryError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise Fs2LibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    vp, i32, i64p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
+    L.fs2_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.fs2_create.restype = C.c_int
+    L.fs2_destroy.argtypes = [vp]
+    L.fs2_destroy.restype = None
+    L.fs2_last_error.argtypes = [vp]
+    L.fs2_last_error.restype = C.c_char_p
+    L.fs2_load_weights.argtypes = [vp, C.POINTER(TensorDesc), i32, vp]
+    L.fs2_load_weights.restype = C.c_int
+    L.fs2_token_workspace_bytes.argtypes = [vp, C.POINTER(Batch)]
+    L.fs2_token_workspace_bytes.restype = C.c_size_t
+    L.fs2_encode.argtypes = [vp, vp, C.POINTER(EncodeIO)]
+    L.fs2_encode.restype = C.c_int
+    L.fs2_frame_workspace_bytes.argtypes = [vp, C.POINTER(Batch), i64p]
+    L.fs2_frame_workspace_bytes.restype = C.c_size_t
+    L.fs2_decode.argtypes = [vp, vp, C.POINTER(DecodeIO)]
+    L.fs2_decode.restype = C.c_int
+    L.fs2_set_profiling.argtypes = [vp, i32]
+    L.fs2_set_profiling.restype = C.c_int
+    L.fs2_get_profile.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double), i32]
+    L.fs2_get_profile.restype = C.c_int
+    L.fs2_op_conv_gemm.argtypes = [vp, C.POINTER(OpGemmArgs)]
+    L.fs2_op_conv_gemm.restype = C.c_int
+    L.fs2_op_attention.argtypes = [vp, vp, vp, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, i32]
+    L.fs2_op_attention.restype = C.c_int
+    L.fs2_op_length_regulate.argtypes = [vp, vp, vp, i64p, i32, i32, i32, i32, vp, vp, vp]
+    L.fs2_op_length_regulate.restype = C.c_int
+    L.fs2_op_bucketize.argtypes = [vp, vp, C.c_int64, vp, i32, vp]
+    L.fs2_op_bucketize.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(code, handle=None):
+    if code != 0:
+        msg = lib().fs2_last_error(handle)
+        raise Fs2Error(code, msg.decode() if msg else "?")

@@ -1,0 +1,61 @@
+// Shared definitions for the gfx950 kernels of libfs2_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fs2 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kGap = 8;        // zero rows between packed sequences (>= largest conv halo, 4)
+constexpr int kMaxHalo = 16;   // LDS rows reserved for conv halos (ktaps <= 17)
+constexpr int kBK = 32;        // K-chunk (channels per LDS stage) of the fp32 GEMMs
+constexpr int kLd = kBK + 4;   // LDS row stride in floats (16-B aligned, breaks the 128-B bank period)
+
+// Activation layout ("gapped packed rows"): utterance b owns rows [start[b], start[b]+len[b]) of every
+// [R, width] activation buffer; at least kGap zero rows separate utterances and precede the first one,
+// so a k-tap convolution along the row axis needs no boundary logic: it simply reads the zero rows.
+// Every kernel that produces an activation buffer writes zeros into the gap rows (row_pos < 0).
+struct SeqMeta {
+    const int* start;     // [B] first row
+    const int* len;       // [B] rows stored / seen by convolutions
+    const int* klen;      // [B] attention keys (<= len)
+    const int* vlen;      // [B] true (unpadded) length
+    const int* row_pos;   // [Rpad] position inside the utterance, -1 for gap rows
+    const int* row_seq;   // [Rpad] utterance index, -1 for gap rows
+    int B, R;
+};
+
+// Arguments of the conv-as-GEMM kernels (gemm_f32.h).  Y = epilogue(sum_taps X[row+tap-P] . W[tap]).
+struct GemmArgs {
+    const float* X; int ldx; int C;        // input [R, ldx], C channels contracted per tap (C % 4 == 0)
+    const float* W; int Cpad; int ktaps;   // repacked weights [Npad][ktaps][Cpad], zero padded
+    int N; int R;
+    const int* row_pos;                    // [>= R] or nullptr (all rows valid)
+    const float* bias;                     // [N] or nullptr
+    const float* resid; int ldr;           // [R, ldr] or nullptr
+    int relu_pre;                          // ReLU before the LayerNorm
+    const float* ln_g; const float* ln_b; float ln_eps;   // LayerNorm over the N outputs if ln_g
+    int act_post;                          // 0 none, 1 relu, 2 tanh
+    const float* pe; int pe_ld; const float* pe_alpha; float x_scale;  // v = v*x_scale + alpha*pe[pos] if pe
+    const float* dot_w; const float* dot_b; float* dot_out;            // dot_out[row] = v . dot_w + dot_b
+    float* Y; int ldy;                     // output [R, ldy] or nullptr
+};
+
+__device__ __forceinline__ float wave16_sum(float v) {
+    // sum over the 16 lanes that share lane>>4 (one MFMA row group)
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return tanhf(v);
+    return v;
+}
+
+}  // namespace fs2

@@ -1,0 +1,250 @@
+// HBM-bound kernels of the path: row metadata, embedding + positional encoding, duration post-op,
+// length regulator (prefix sum + expand), bucketize + embedding add, packed -> padded output copies.
+// All of them move whole rows with 16-byte accesses, one wavefront per row.
+#pragma once
+#include "common.h"
+
+namespace fs2 {
+
+// row_pos / row_seq for a gapped packed layout (start[] ascending).
+__global__ void build_row_meta(const int* start, const int* len, int B, int rpad, int* row_pos, int* row_seq) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rpad) return;
+    int lo = 0, hi = B;   // first b with start[b] > row
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (start[mid] <= row) lo = mid + 1; else hi = mid;
+    }
+    const int b = lo - 1;
+    int pos = -1, seq = -1;
+    if (b >= 0 && row - start[b] < len[b]) { pos = row - start[b]; seq = b; }
+    row_pos[row] = pos;
+    row_seq[row] = seq;
+}
+
+// h[row] = E[xs[b, t]] * xscale + alpha * pe[t]      (reference encoder.py:196, embedding.py:77-80,105-120)
+__global__ __launch_bounds__(256) void embed_pe(const int64_t* xs, int Tmax, const float* E, int idim, int D,
+                                                const float* pe, const float* alpha_p, float xscale,
+                                                const int* row_pos, const int* row_seq, int R, float* h) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const int t = row_pos[row];
+    float* dst = h + (size_t)row * D;
+    if (t < 0) {
+        for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<float4*>(dst + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const int b = row_seq[row];
+    int64_t id = (t < Tmax) ? xs[(size_t)b * Tmax + t] : 0;
+    if (id < 0 || id >= idim) id = 0;
+    const float alpha = alpha_p ? alpha_p[0] : 1.f;
+    const float* e = E + (size_t)id * D;
+    const float* p = pe + (size_t)t * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 ev = *reinterpret_cast<const float4*>(e + c);
+        const float4 pv = *reinterpret_cast<const float4*>(p + c);
+        float4 o;
+        o.x = ev.x * xscale + alpha * pv.x;
+        o.y = ev.y * xscale + alpha * pv.y;
+        o.z = ev.z * xscale + alpha * pv.z;
+        o.w = ev.w * xscale + alpha * pv.w;
+        *reinterpret_cast<float4*>(dst + c) = o;
+    }
+}
+
+// Duration post-op (reference duration_predictor.py:77-84): packed per-row log-durations ->
+// padded [B,Tmax] outputs; d = clamp(round_half_even(exp(y) - 1), 0), pads -> 0.
+__global__ void dur_finalize(const float* dlog_rows, const int* start, const int* vlen, int B, int Tmax,
+                             float* d_log, int64_t* d_int) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Tmax) return;
+    const int b = i / Tmax, t = i - b * Tmax;
+    float y = 0.f;
+    int64_t d = 0;
+    if (t < vlen[b]) {
+        y = dlog_rows[start[b] + t];
+        const float f = fmaxf(rintf(expf(y) - 1.0f), 0.f);     // rintf = round half to even
+        d = (f >= 9.0e18f) ? INT64_MAX : (int64_t)f;
+    }
+    if (d_log) d_log[i] = y;
+    if (d_int) d_int[i] = d;
+}
+
+// Per-utterance inclusive prefix sum of the durations actually used (reference length_regulator.py:60,
+// 85-88: slice to ilen, an all-zero row becomes all ones).  One workgroup per utterance.
+__global__ __launch_bounds__(256) void dur_scan(const int64_t* ds, int Tmax, const int* ilen, int* cum,
+                                                int64_t* olens, int* olens32) {
+    __shared__ int wsum[4];
+    __shared__ int carry_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = ilen[b];
+    const int64_t* d = ds + (size_t)b * Tmax;
+    // pass 1: total
+    int tot = 0;
+    for (int t = tid; t < T; t += 256) tot += (int)(d[t] > 0 ? d[t] : 0);
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    if (lane == 0) wsum[wave] = tot;
+    __syncthreads();
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const bool ones = (total == 0);
+    __syncthreads();
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < T; base += 256) {
+        const int t = base + tid;
+        int v = (t < T) ? (ones ? 1 : (int)(d[t] > 0 ? d[t] : 0)) : 0;
+        int x = v;   // inclusive scan inside the wave
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int off = carry_s;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (t < T) cum[(size_t)b * Tmax + t] = off + x;
+        __syncthreads();
+        if (tid == 255) carry_s = off + x;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int tt = ones ? T : total;
+        if (olens) olens[b] = tt;
+        if (olens32) olens32[b] = tt;
+    }
+}
+
+// Length-regulator expand (reference length_regulator.py:90-95 + utils/util.py:91-104):
+// out[row] = hs[tok_start[b] + idx], idx = #{i : cum[b,i] <= j}; rows beyond the utterance -> 0.
+// One wavefront per output row.  If row_seq == nullptr the output is a dense [B, uniform_len] layout.
+__global__ __launch_bounds__(256) void lr_expand(const float* hs, int D, const int* tok_start, const int* ilen,
+                                                 const int* cum, int Tmax, const int* row_pos, const int* row_seq,
+                                                 int uniform_len, const int* vlen, int R, float* out,
+                                                 int* index_rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= R) return;
+    int b, j;
+    if (row_seq) { b = row_seq[row]; j = row_pos[row]; } else { b = row / uniform_len; j = row - b * uniform_len; }
+    float* dst = out + (size_t)row * D;
+    int idx = -1;
+    if (b >= 0 && j < vlen[b]) {
+        const int* c = cum + (size_t)b * Tmax;
+        int lo = 0, hi = ilen[b];   // first i with c[i] > j
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (c[mid] <= j) lo = mid + 1; else hi = mid;
+        }
+        idx = lo;
+    }
+    if (index_rows && lane == 0) index_rows[row] = idx;
+    if (idx < 0) {
+        for (int c4 = lane * 4; c4 < D; c4 += 256) *reinterpret_cast<float4*>(dst + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float* src = hs + (size_t)(tok_start[b] + idx) * D;
+    for (int c4 = lane * 4; c4 < D; c4 += 256)
+        *reinterpret_cast<float4*>(dst + c4) = *reinterpret_cast<const float4*>(src + c4);
+}
+
+// torch.bucketize(x, bins, right=False): first i with x <= bins[i]; NaN -> nb (the `!(b >= x)` form keeps
+// torch's NaN behaviour).  reference variance_predictor.py:158,231
+__device__ __forceinline__ int bucket_index(float x, const float* bins, int nb) {
+    int lo = 0, hi = nb;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (!(bins[mid] >= x)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void bucketize_kernel(const float* x, int64_t n, const float* bins, int nb, int* idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = bucket_index(x[i], bins, nb);
+}
+
+// Variance adaptor tail (reference fastspeech.py:218-219 with the one-hot GEMMs collapsed to gathers):
+// h[row] = (h[row] + Tp[qp]) + Te[qe], Tx[q][c] = fl(W[c][q] + b[c]) precomputed at weight load, which is
+// bit-identical to one_hot(q) @ W^T + b.  e/p come from the caller ([B, stride], teacher forcing) or from
+// the predictors (per packed row).  One wavefront per row.
+__global__ __launch_bounds__(256) void bucket_embed(float* h, int D, const int* row_pos, const int* row_seq, int R,
+                                                    const float* es, int es_stride, const float* ps, int ps_stride,
+                                                    const float* e_rows, const float* p_rows,
+                                                    const float* ebins, const float* pbins, int nb,
+                                                    const float* Te, const float* Tp, int* qe_rows, int* qp_rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const int j = row_pos[row];
+    if (j < 0) {
+        if (lane == 0) { if (qe_rows) qe_rows[row] = -1; if (qp_rows) qp_rows[row] = -1; }
+        return;
+    }
+    const int b = row_seq[row];
+    const float e = es ? (j < es_stride ? es[(size_t)b * es_stride + j] : 0.f) : e_rows[row];
+    const float p = ps ? (j < ps_stride ? ps[(size_t)b * ps_stride + j] : 0.f) : p_rows[row];
+    const int qe = bucket_index(e, ebins, nb);
+    const int qp = bucket_index(p, pbins, nb);
+    if (lane == 0) { if (qe_rows) qe_rows[row] = qe; if (qp_rows) qp_rows[row] = qp; }
+    float* dst = h + (size_t)row * D;
+    const float* te = Te + (size_t)qe * D;
+    const float* tp = Tp + (size_t)qp * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(dst + c);
+        const float4 a = *reinterpret_cast<const float4*>(tp + c);
+        const float4 g = *reinterpret_cast<const float4*>(te + c);
+        v.x = (v.x + a.x) + g.x;
+        v.y = (v.y + a.y) + g.y;
+        v.z = (v.z + a.z) + g.z;
+        v.w = (v.w + a.w) + g.w;
+        *reinterpret_cast<float4*>(dst + c) = v;
+    }
+}
+
+// packed rows [R, W] -> padded [B, Lout, W]; positions >= limit[b] are filled with `fill`.
+template <typename T>
+__global__ void unpack_rows(const T* src, int W, const int* start, const int* limit, int B, int Lout, T* dst, T fill) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)B * Lout * W;
+    if (i >= total) return;
+    const int w = (int)(i % W);
+    const int64_t bj = i / W;
+    const int j = (int)(bj % Lout), b = (int)(bj / Lout);
+    dst[i] = (j < limit[b]) ? src[(size_t)(start[b] + j) * W + w] : fill;
+}
+
+// ---- weight repacking (run once per load_state_dict) ----
+// conv / linear weight [N][C][k] -> [Npad][k][Cpad], zero padded, optionally scaled per output channel by
+// gamma / sqrt(var + eps) (eval-mode BatchNorm folded into the Postnet convs, reference modules.py:285-348).
+__global__ void repack_weight(const float* w, int N, int C, int k, int Npad, int Cpad, const float* bn_g,
+                              const float* bn_v, float bn_eps, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)Npad * k * Cpad;
+    if (i >= total) return;
+    const int c = (int)(i % Cpad);
+    const int tap = (int)((i / Cpad) % k);
+    const int n = (int)(i / ((int64_t)Cpad * k));
+    float v = 0.f;
+    if (n < N && c < C) {
+        v = w[((size_t)n * C + c) * k + tap];
+        if (bn_g) v *= bn_g[n] / sqrtf(bn_v[n] + bn_eps);
+    }
+    out[i] = v;
+}
+
+// folded BatchNorm bias: beta - mean * gamma / sqrt(var + eps)
+__global__ void bn_fold_bias(const float* g, const float* b, const float* m, const float* v, float eps, int N, float* out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) out[n] = b[n] - m[n] * (g[n] / sqrtf(v[n] + eps));
+}
+
+// embedding table of a Linear applied to one-hot rows: T[q][c] = W[c][q] + b[c]
+__global__ void onehot_table(const float* W, const float* bias, int D, int nbins, float* T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D * nbins) return;
+    const int c = i % D, q = i / D;
+    T[i] = W[(size_t)c * nbins + q] + bias[c];
+}
+
+}  // namespace fs2

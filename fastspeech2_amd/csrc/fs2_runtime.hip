@@ -1,0 +1,868 @@
+// libfs2_hip.so -- runtime + C ABI (include/fs2.h) of the MI355X FastSpeech2 mel-generation path.
+// Orchestrates the kernels in gemm_f32.h / attn_f32.h / elementwise.h over the gapped packed row layout.
+// Replaces the tensor work of reference fastspeech.py:169-243 (`FeedForwardTransformer._forward`).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/fs2.h"
+#include "attn_f32.h"
+#include "common.h"
+#include "elementwise.h"
+#include "gemm_f32.h"
+
+using namespace fs2;
+
+namespace {
+
+std::string g_create_error;
+
+struct Gemm {          // one repacked Linear / Conv1d
+    float* w = nullptr;      // [Npad][ktaps][Cpad]
+    float* bias = nullptr;   // [N] or null
+    int N = 0, C = 0, Cpad = 0, ktaps = 1;
+};
+struct Layer {
+    Gemm qkv, out, w1, w2;
+    float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+};
+struct Predictor {
+    std::vector<Gemm> conv;
+    std::vector<float*> lng, lnb;
+    float *lin_w = nullptr, *lin_b = nullptr;
+};
+struct Stack {
+    std::vector<Layer> layers;
+    float* pe = nullptr; int pe_rows = 0;
+    float* alpha = nullptr;
+};
+
+struct HostLayout {
+    int B = 0, R = 0, Rpad = 0;
+    std::vector<int> start, len, klen, vlen;
+    std::vector<int2> work;
+};
+struct DevLayout {
+    int *start = nullptr, *len = nullptr, *klen = nullptr, *vlen = nullptr, *row_pos = nullptr, *row_seq = nullptr;
+    int2* work = nullptr;
+};
+
+struct ProfRec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
+
+}  // namespace
+
+struct fs2_handle {
+    fs2_config cfg;
+    std::string err;
+    bool loaded = false;
+    std::vector<void*> allocs;
+    // weights
+    float* enc_embed = nullptr;
+    Stack enc, dec;
+    Predictor dur, energy, pitch;
+    float *ebins = nullptr, *pbins = nullptr, *Te = nullptr, *Tp = nullptr;
+    Gemm dec_in; float *dec_in_lng = nullptr, *dec_in_lnb = nullptr;
+    Gemm feat;
+    std::vector<Gemm> post;
+    // state carried from encode to decode
+    bool encoded = false;
+    HostLayout tok;
+    DevLayout dtok;
+    float* enc_final = nullptr;
+    int* cum = nullptr;
+    int enc_B = 0, enc_Tmax = 0, enc_compat = 0;
+    void* enc_ws = nullptr;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+};
+
+namespace {
+
+int fail(fs2_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                        \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(h, FS2_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+struct Bump {   // carve a caller-provided workspace
+    char* base; size_t off = 0, cap;
+    Bump(void* p, size_t c) : base((char*)p), cap(c) {}
+    template <typename T> T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = reinterpret_cast<T*>(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+// ------------------------------------------------------------------ profiling wrappers
+struct Scope {
+    fs2_handle* h; hipStream_t s; size_t idx = (size_t)-1;
+    Scope(fs2_handle* h_, hipStream_t s_, const char* name, double flops, double bytes) : h(h_), s(s_) {
+        if (h && h->prof) {
+            ProfRec r; r.name = name; r.flops = flops; r.bytes = bytes;
+            hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+            hipEventRecord(r.e0, s);
+            h->recs.push_back(r); idx = h->recs.size() - 1;
+        }
+    }
+    ~Scope() { if (idx != (size_t)-1) hipEventRecord(h->recs[idx].e1, s); }
+};
+
+// ------------------------------------------------------------------ kernel launchers
+template <int NT>
+hipError_t launch_rows(hipStream_t s, const GemmArgs& a) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_f32<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)rows_lds_bytes<NT>());
+        attr = true;
+    }
+    dim3 grid((a.R + kRowsBM - 1) / kRowsBM);
+    hipLaunchKernelGGL(gemm_rows_f32<NT>, grid, dim3(256), rows_lds_bytes<NT>(), s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile(hipStream_t s, const GemmArgs& a) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds);
+        attr = true;
+    }
+    dim3 grid((a.R + kTileBM - 1) / kTileBM, (a.N + kTileBN - 1) / kTileBN);
+    hipLaunchKernelGGL(gemm_tile_f32, grid, dim3(256), kTileLds, s, a);
+    return hipGetLastError();
+}
+
+bool rows_supported(int N) { return N == 80 || N == 256 || N == 384; }
+
+// Picks the kernel shape: row-complete tiles when the epilogue needs whole rows, 128x128 tiles otherwise.
+int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a) {
+    if (a.ktaps - 1 > kMaxHalo) return fail(h, FS2_ERR_UNSUPPORTED, "%s: kernel size %d > %d", name, a.ktaps, kMaxHalo + 1);
+    if (a.C % 4 != 0 || a.ldx % 4 != 0) return fail(h, FS2_ERR_UNSUPPORTED, "%s: channels %d / ld %d must be multiples of 4", name, a.C, a.ldx);
+    const bool need_rows = a.ln_g || a.dot_w || a.pe || a.relu_pre;
+    const double flops = 2.0 * a.R * (double)a.N * a.C * a.ktaps;
+    const double bytes = 4.0 * ((double)a.R * a.C + (double)a.N * a.C * a.ktaps + (double)a.R * a.N);
+    Scope sc(h, s, name, flops, bytes);
+    hipError_t e;
+    if (need_rows || (a.N < 128 && rows_supported(a.N))) {
+        if (!rows_supported(a.N)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: row-epilogue GEMM needs N in {80,256,384}, got %d", name, a.N);
+        if (a.N == 80) e = launch_rows<5>(s, a);
+        else if (a.N == 256) e = launch_rows<16>(s, a);
+        else e = launch_rows<24>(s, a);
+    } else {
+        e = launch_tile(s, a);
+    }
+    if (e != hipSuccess) return fail(h, FS2_ERR_HIP, "%s launch: %s", name, hipGetErrorString(e));
+    return FS2_OK;
+}
+
+GemmArgs gemm_args(const Gemm& g, const float* X, int ldx, int R, const int* row_pos, float* Y, int ldy) {
+    GemmArgs a;
+    memset(&a, 0, sizeof a);
+    a.X = X; a.ldx = ldx; a.C = g.C; a.W = g.w; a.Cpad = g.Cpad; a.ktaps = g.ktaps; a.N = g.N; a.R = R;
+    a.row_pos = row_pos; a.bias = g.bias; a.Y = Y; a.ldy = ldy; a.x_scale = 1.f; a.ln_eps = 1e-5f;
+    return a;
+}
+
+int launch_attention(fs2_handle* h, hipStream_t s, const char* name, const float* qkv, float* ctx, int D, int heads,
+                     const DevLayout& dl, int nwork, int mask_q, double flops) {
+    const int dk = D / heads;
+    AttnArgs a;
+    a.qkv = qkv; a.ld = 3 * D; a.ctx = ctx; a.ldc = D; a.start = dl.start; a.len = dl.len; a.klen = dl.klen;
+    a.work = dl.work; a.D = D; a.mask_q = mask_q; a.scale = 1.0f / sqrtf((float)dk);
+    if (nwork == 0) return FS2_OK;
+    Scope sc(h, s, name, flops, 0.0);
+    dim3 grid(nwork, heads);
+    if (dk == 128) {
+        static bool attr = false;
+        if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds_bytes<128>()); attr = true; }
+        hipLaunchKernelGGL(attn_f32<128>, grid, dim3(256), attn_lds_bytes<128>(), s, a);
+    } else if (dk == 192) {
+        static bool attr = false;
+        if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32<192>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds_bytes<192>()); attr = true; }
+        hipLaunchKernelGGL(attn_f32<192>, grid, dim3(256), attn_lds_bytes<192>(), s, a);
+    } else if (dk == 64) {
+        static bool attr = false;
+        if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds_bytes<64>()); attr = true; }
+        hipLaunchKernelGGL(attn_f32<64>, grid, dim3(256), attn_lds_bytes<64>(), s, a);
+    } else {
+        return fail(h, FS2_ERR_UNSUPPORTED, "attention head dim %d not in {64,128,192}", dk);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, FS2_ERR_HIP, "%s launch: %s", name, hipGetErrorString(e));
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------ layouts
+void build_layout(HostLayout& L, int B, const std::vector<int>& len, const std::vector<int>& klen, const std::vector<int>& vlen) {
+    L.B = B; L.len = len; L.klen = klen; L.vlen = vlen;
+    L.start.resize(B); L.work.clear();
+    int row = kGap;
+    for (int b = 0; b < B; ++b) {
+        L.start[b] = row;
+        for (int q = 0; q * kAttBQ < len[b]; ++q) L.work.push_back(make_int2(b, q));
+        row += len[b] + kGap;
+    }
+    L.R = row;
+    L.Rpad = round_up(row, 128);
+}
+
+size_t layout_dev_ints(const HostLayout& L) { return (size_t)4 * L.B + 2 * (size_t)L.Rpad + 2 * L.work.size() + 64; }
+
+// uploads start/len/klen/vlen/work, then derives row_pos/row_seq on the device
+int upload_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, DevLayout& D) {
+    std::vector<int> host;
+    host.reserve(4 * L.B + 2 * L.work.size());
+    host.insert(host.end(), L.start.begin(), L.start.end());
+    host.insert(host.end(), L.len.begin(), L.len.end());
+    host.insert(host.end(), L.klen.begin(), L.klen.end());
+    host.insert(host.end(), L.vlen.begin(), L.vlen.end());
+    for (auto& w : L.work) { host.push_back(w.x); host.push_back(w.y); }
+    HIP_TRY(h, hipMemcpyAsync(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    D.start = dev; D.len = dev + L.B; D.klen = dev + 2 * L.B; D.vlen = dev + 3 * L.B;
+    D.work = reinterpret_cast<int2*>(dev + 4 * L.B);
+    int* rest = dev + 4 * L.B + 2 * L.work.size();
+    rest = reinterpret_cast<int*>(align_up(reinterpret_cast<size_t>(rest), 16));
+    D.row_pos = rest; D.row_seq = rest + L.Rpad;
+    hipLaunchKernelGGL(build_row_meta, dim3((L.Rpad + 255) / 256), dim3(256), 0, s, D.start, D.len, L.B, L.Rpad, D.row_pos, D.row_seq);
+    HIP_TRY(h, hipGetLastError());
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------ FFT block stack
+struct StackBufs { float *x0, *x1, *qkv, *ctx, *hid; };
+
+// x0 holds the input; returns the buffer holding the output (x0 again).
+int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, int D, int heads, int R,
+              const HostLayout& L, const DevLayout& dl, int mask_q, const StackBufs& b) {
+    char nm[96];
+    double att_flops = 0;
+    for (int i = 0; i < L.B; ++i) att_flops += 4.0 * D * (double)L.klen[i] * std::min(L.len[i], mask_q ? L.klen[i] : L.len[i]);
+    for (size_t li = 0; li < st.layers.size(); ++li) {
+        const Layer& ly = st.layers[li];
+        int rc;
+        snprintf(nm, sizeof nm, "%s.qkv", tag);
+        GemmArgs a = gemm_args(ly.qkv, b.x0, D, R, dl.row_pos, b.qkv, 3 * D);
+        if ((rc = launch_gemm(h, s, nm, a))) return rc;
+        snprintf(nm, sizeof nm, "%s.attn", tag);
+        if ((rc = launch_attention(h, s, nm, b.qkv, b.ctx, D, heads, dl, (int)L.work.size(), mask_q, att_flops))) return rc;
+        snprintf(nm, sizeof nm, "%s.out_ln", tag);
+        a = gemm_args(ly.out, b.ctx, D, R, dl.row_pos, b.x1, D);
+        a.resid = b.x0; a.ldr = D; a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
+        if ((rc = launch_gemm(h, s, nm, a))) return rc;
+        snprintf(nm, sizeof nm, "%s.ffn1", tag);
+        a = gemm_args(ly.w1, b.x1, D, R, dl.row_pos, b.hid, ly.w1.N);
+        a.act_post = 1;
+        if ((rc = launch_gemm(h, s, nm, a))) return rc;
+        snprintf(nm, sizeof nm, "%s.ffn2_ln", tag);
+        a = gemm_args(ly.w2, b.hid, ly.w1.N, R, dl.row_pos, b.x0, D);
+        a.resid = b.x1; a.ldr = D; a.ln_g = ly.ln2g; a.ln_b = ly.ln2b; a.ln_eps = 1e-5f;
+        if ((rc = launch_gemm(h, s, nm, a))) return rc;
+    }
+    return FS2_OK;
+}
+
+// conv stack + scalar head (reference variance_predictor.py:46-51 / duration_predictor.py:70-75);
+// tmp0/tmp1: [R, chans] scratch; out_rows: [R]
+int run_predictor(fs2_handle* h, hipStream_t s, const char* tag, const Predictor& p, const float* X, int ldx, int R,
+                  const int* row_pos, float* tmp0, float* tmp1, float* out_rows) {
+    char nm[96];
+    const float* in = X; int ld = ldx;
+    float* bufs[2] = {tmp0, tmp1};
+    for (size_t l = 0; l < p.conv.size(); ++l) {
+        const bool last = (l + 1 == p.conv.size());
+        float* out = bufs[l & 1];
+        GemmArgs a = gemm_args(p.conv[l], in, ld, R, row_pos, last ? nullptr : out, p.conv[l].N);
+        a.relu_pre = 1; a.ln_g = p.lng[l]; a.ln_b = p.lnb[l]; a.ln_eps = 1e-12f;
+        if (last) { a.dot_w = p.lin_w; a.dot_b = p.lin_b; a.dot_out = out_rows; }
+        snprintf(nm, sizeof nm, "%s.conv%d", tag, (int)l);
+        int rc = launch_gemm(h, s, nm, a);
+        if (rc) return rc;
+        in = out; ld = p.conv[l].N;
+    }
+    return FS2_OK;
+}
+
+// ------------------------------------------------------------------ weight loading
+struct Loader {
+    fs2_handle* h; hipStream_t s;
+    std::map<std::string, const fs2_tensor_desc*> m;
+    int rc = FS2_OK;
+    const fs2_tensor_desc* get(const std::string& name, std::initializer_list<int64_t> shape) {
+        auto it = m.find(name);
+        if (it == m.end()) { if (!rc) rc = fail(h, FS2_ERR_WEIGHT, "missing tensor %s", name.c_str()); return nullptr; }
+        const fs2_tensor_desc* d = it->second;
+        bool ok = d->ndim == (int)shape.size();
+        int i = 0;
+        for (int64_t v : shape) { if (ok && d->shape[i] != v) ok = false; ++i; }
+        if (!ok) { if (!rc) rc = fail(h, FS2_ERR_WEIGHT, "tensor %s has the wrong shape", name.c_str()); return nullptr; }
+        return d;
+    }
+    float* dalloc(size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)) != hipSuccess) { if (!rc) rc = fail(h, FS2_ERR_HIP, "hipMalloc of %zu floats failed", n); return nullptr; }
+        h->allocs.push_back(p);
+        return (float*)p;
+    }
+    float* copy(const std::string& name, std::initializer_list<int64_t> shape) {
+        const fs2_tensor_desc* d = get(name, shape);
+        if (!d) return nullptr;
+        size_t n = 1;
+        for (int64_t v : shape) n *= (size_t)v;
+        float* p = dalloc(n);
+        if (p && hipMemcpyAsync(p, d->data, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess && !rc) rc = fail(h, FS2_ERR_HIP, "copy of %s failed", name.c_str());
+        return p;
+    }
+    // parts: weights stacked along N (q|k|v); each [n_i, C, k] (k omitted for Linear)
+    Gemm gemm(std::vector<std::string> wnames, std::vector<std::string> bnames, int Neach, int C, int k, bool linear,
+              const std::string& bn_prefix = "") {
+        Gemm g;
+        const int parts = (int)wnames.size();
+        g.N = Neach * parts; g.C = C; g.ktaps = k; g.Cpad = round_up(C, kBK);
+        const int Npad = round_up(g.N, 128);
+        g.w = dalloc((size_t)Npad * k * g.Cpad);
+        if (!g.w) return g;
+        hipMemsetAsync(g.w, 0, (size_t)Npad * k * g.Cpad * sizeof(float), s);
+        const float *bg = nullptr, *bb = nullptr, *bm = nullptr, *bv = nullptr;
+        if (!bn_prefix.empty()) {
+            const fs2_tensor_desc *dg = get(bn_prefix + ".weight", {Neach}), *db = get(bn_prefix + ".bias", {Neach}),
+                                  *dm = get(bn_prefix + ".running_mean", {Neach}), *dv = get(bn_prefix + ".running_var", {Neach});
+            if (!dg || !db || !dm || !dv) return g;
+            bg = (const float*)dg->data; bb = (const float*)db->data; bm = (const float*)dm->data; bv = (const float*)dv->data;
+        }
+        for (int p = 0; p < parts; ++p) {
+            const fs2_tensor_desc* d = linear ? get(wnames[p], {Neach, C}) : get(wnames[p], {Neach, C, k});
+            if (!d) return g;
+            const int64_t total = (int64_t)Neach * k * g.Cpad;
+            hipLaunchKernelGGL(repack_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)d->data, Neach, C, k,
+                               Neach, g.Cpad, bg, bv, 1e-5f, g.w + (size_t)p * Neach * k * g.Cpad);
+        }
+        if (!bnames.empty()) {
+            g.bias = dalloc(g.N);
+            if (!g.bias) return g;
+            for (int p = 0; p < parts; ++p) {
+                const fs2_tensor_desc* d = get(bnames[p], {Neach});
+                if (!d) return g;
+                hipMemcpyAsync(g.bias + (size_t)p * Neach, d->data, Neach * sizeof(float), hipMemcpyDeviceToDevice, s);
+            }
+        } else if (bg) {
+            g.bias = dalloc(g.N);
+            if (!g.bias) return g;
+            hipLaunchKernelGGL(bn_fold_bias, dim3((Neach + 255) / 256), dim3(256), 0, s, bg, bb, bm, bv, 1e-5f, Neach, g.bias);
+        }
+        return g;
+    }
+};
+
+void load_stack(Loader& L, Stack& st, const std::string& pre, int nlayers, int D, int units, int k, const std::string& pe_pre,
+                bool scaled) {
+    st.layers.resize(nlayers);
+    for (int i = 0; i < nlayers; ++i) {
+        const std::string p = pre + ".encoders_." + std::to_string(i);
+        Layer& ly = st.layers[i];
+        ly.qkv = L.gemm({p + ".self_attn.linear_q.weight", p + ".self_attn.linear_k.weight", p + ".self_attn.linear_v.weight"},
+                        {p + ".self_attn.linear_q.bias", p + ".self_attn.linear_k.bias", p + ".self_attn.linear_v.bias"}, D, D, 1, true);
+        ly.out = L.gemm({p + ".self_attn.linear_out.weight"}, {p + ".self_attn.linear_out.bias"}, D, D, 1, true);
+        ly.w1 = L.gemm({p + ".feed_forward.w_1.weight"}, {p + ".feed_forward.w_1.bias"}, units, D, k, L.h->cfg.ffn_kernel == 1 && L.m.count(p + ".feed_forward.w_1.weight") && L.m[p + ".feed_forward.w_1.weight"]->ndim == 2);
+        {
+            const bool lin2 = L.m.count(p + ".feed_forward.w_2.weight") && L.m[p + ".feed_forward.w_2.weight"]->ndim == 2;
+            ly.w2 = L.gemm({p + ".feed_forward.w_2.weight"}, {p + ".feed_forward.w_2.bias"}, D, units, 1, lin2);
+        }
+        ly.ln1g = L.copy(p + ".norm1.weight", {D}); ly.ln1b = L.copy(p + ".norm1.bias", {D});
+        ly.ln2g = L.copy(p + ".norm2.weight", {D}); ly.ln2b = L.copy(p + ".norm2.bias", {D});
+    }
+    auto it = L.m.find(pe_pre + ".pe");
+    if (it == L.m.end() || it->second->ndim != 3 || it->second->shape[2] != D) {
+        if (!L.rc) L.rc = fail(L.h, FS2_ERR_WEIGHT, "missing/odd positional table %s.pe", pe_pre.c_str());
+        return;
+    }
+    st.pe_rows = (int)it->second->shape[1];
+    st.pe = L.copy(pe_pre + ".pe", {1, st.pe_rows, D});
+    st.alpha = scaled ? L.copy(pe_pre + ".alpha", {}) : nullptr;
+}
+
+void load_predictor(Loader& L, Predictor& p, const std::string& pre, int nlayers, int idim, int chans, int k) {
+    p.conv.clear(); p.lng.clear(); p.lnb.clear();
+    for (int l = 0; l < nlayers; ++l) {
+        const std::string c = pre + ".conv." + std::to_string(l);
+        p.conv.push_back(L.gemm({c + ".0.weight"}, {c + ".0.bias"}, chans, l == 0 ? idim : chans, k, false));
+        p.lng.push_back(L.copy(c + ".2.layer_norm.weight", {chans}));
+        p.lnb.push_back(L.copy(c + ".2.layer_norm.bias", {chans}));
+    }
+    p.lin_w = L.copy(pre + ".linear.weight", {1, chans});
+    p.lin_b = L.copy(pre + ".linear.bias", {1});
+}
+
+void free_weights(fs2_handle* h) {
+    for (void* p : h->allocs) hipFree(p);
+    h->allocs.clear();
+    h->loaded = false;
+}
+
+int check_batch(fs2_handle* h, const fs2_batch& b) {
+    if (b.B <= 0 || b.Tmax <= 0 || !b.ilens) return fail(h, FS2_ERR_ARG, "batch: B=%d Tmax=%d ilens=%p", b.B, b.Tmax, (const void*)b.ilens);
+    for (int i = 0; i < b.B; ++i)
+        if (b.ilens[i] <= 0 || b.ilens[i] > b.Tmax) return fail(h, FS2_ERR_ARG, "ilens[%d]=%lld outside [1,%d]", i, (long long)b.ilens[i], b.Tmax);
+    if (b.precision != FS2_PREC_FP32) return fail(h, FS2_ERR_UNSUPPORTED, "precision mode %d is not built into this library yet", b.precision);
+    return FS2_OK;
+}
+
+void token_layout(const fs2_batch& b, HostLayout& L) {
+    std::vector<int> len(b.B), klen(b.B), vlen(b.B);
+    for (int i = 0; i < b.B; ++i) {
+        vlen[i] = klen[i] = (int)b.ilens[i];
+        len[i] = b.compat_padded ? b.Tmax : (int)b.ilens[i];
+    }
+    build_layout(L, b.B, len, klen, vlen);
+}
+
+struct TokenPlan {   // offsets inside the token workspace
+    size_t total;
+};
+
+// carve the token workspace; if ws == nullptr only sizes it
+size_t carve_tokens(const fs2_config& c, const fs2_batch& b, const HostLayout& L, void* ws, size_t cap, int** meta, StackBufs* sb,
+                    float** p0, float** p1, float** dlog_rows, int64_t** dint, int** cum, int** olens32, bool* ok) {
+    Bump bp(ws, cap);
+    const size_t R = L.Rpad;
+    int* m = bp.take<int>(layout_dev_ints(L));
+    float* x0 = bp.take<float>(R * c.adim);
+    float* x1 = bp.take<float>(R * c.adim);
+    float* qkv = bp.take<float>(R * 3 * c.adim);
+    float* ctx = bp.take<float>(R * c.adim);
+    float* hid = bp.take<float>(R * c.eunits);
+    float* q0 = bp.take<float>(R * c.dur_chans);
+    float* q1 = bp.take<float>(R * c.dur_chans);
+    float* dl = bp.take<float>(R);
+    int64_t* di = bp.take<int64_t>((size_t)b.B * b.Tmax);
+    int* cu = bp.take<int>((size_t)b.B * b.Tmax);
+    int* o32 = bp.take<int>(b.B);
+    if (meta) *meta = m;
+    if (sb) { sb->x0 = x0; sb->x1 = x1; sb->qkv = qkv; sb->ctx = ctx; sb->hid = hid; }
+    if (p0) *p0 = q0;
+    if (p1) *p1 = q1;
+    if (dlog_rows) *dlog_rows = dl;
+    if (dint) *dint = di;
+    if (cum) *cum = cu;
+    if (olens32) *olens32 = o32;
+    if (ok) *ok = bp.ok();
+    return align_up(bp.off, 256);
+}
+
+struct FrameBufs {
+    int* meta; float* hfr; float *t0, *t1, *e_rows, *p_rows; StackBufs sb; float *before, *after; int *qe, *qp, *lri;
+};
+
+size_t carve_frames(const fs2_config& c, const HostLayout& L, void* ws, size_t cap, FrameBufs* fb, bool* ok) {
+    Bump bp(ws, cap);
+    const size_t R = L.Rpad;
+    FrameBufs f;
+    f.meta = bp.take<int>(layout_dev_ints(L));
+    f.hfr = bp.take<float>(R * c.adim);
+    f.t0 = bp.take<float>(R * c.var_chans);
+    f.t1 = bp.take<float>(R * c.var_chans);
+    f.e_rows = bp.take<float>(R);
+    f.p_rows = bp.take<float>(R);
+    f.sb.x0 = bp.take<float>(R * c.ddim);
+    f.sb.x1 = bp.take<float>(R * c.ddim);
+    f.sb.qkv = bp.take<float>(R * 3 * c.ddim);
+    f.sb.ctx = bp.take<float>(R * c.ddim);
+    f.sb.hid = bp.take<float>(R * (size_t)std::max(c.dunits, 2 * c.postnet_chans));
+    f.before = bp.take<float>(R * c.odim);
+    f.after = bp.take<float>(R * c.odim);
+    f.qe = bp.take<int>(R);
+    f.qp = bp.take<int>(R);
+    f.lri = bp.take<int>(R);
+    if (fb) *fb = f;
+    if (ok) *ok = bp.ok();
+    return align_up(bp.off, 256);
+}
+
+void frame_layout(const fs2_batch& b, const int64_t* olens, int masked, HostLayout& L) {
+    std::vector<int> len(b.B), klen(b.B), vlen(b.B);
+    int mx = 0;
+    for (int i = 0; i < b.B; ++i) mx = std::max(mx, (int)olens[i]);
+    for (int i = 0; i < b.B; ++i) {
+        vlen[i] = (int)olens[i];
+        len[i] = b.compat_padded ? mx : vlen[i];
+        klen[i] = b.compat_padded ? (masked ? vlen[i] : mx) : vlen[i];
+    }
+    build_layout(L, b.B, len, klen, vlen);
+}
+
+template <typename T>
+int unpack(fs2_handle* h, hipStream_t s, const T* src, int W, const int* start, const int* limit, int B, int Lout, T* dst, T fill) {
+    const int64_t total = (int64_t)B * Lout * W;
+    if (total == 0) return FS2_OK;
+    hipLaunchKernelGGL(unpack_rows<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, W, start, limit, B, Lout, dst, fill);
+    HIP_TRY(h, hipGetLastError());
+    return FS2_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int fs2_create(const fs2_config* cfg, fs2_handle** out) {
+    if (!cfg || !out) return fail(nullptr, FS2_ERR_ARG, "fs2_create: null argument");
+    *out = nullptr;
+    if (cfg->reduction_factor != 1) return fail(nullptr, FS2_ERR_UNSUPPORTED, "reduction_factor %d (only 1 is implemented)", cfg->reduction_factor);
+    if (cfg->adim % cfg->aheads || cfg->ddim % cfg->aheads) return fail(nullptr, FS2_ERR_ARG, "adim/ddim not divisible by aheads");
+    if (cfg->n_bins != cfg->adim) return fail(nullptr, FS2_ERR_ARG, "n_bins (%d) must equal adim (%d): the reference feeds one_hot(256) into Linear(adim, adim)", cfg->n_bins, cfg->adim);
+    if (cfg->ffn_kernel % 2 == 0 || cfg->dur_kernel % 2 == 0 || cfg->var_kernel % 2 == 0 || (cfg->postnet_layers > 0 && cfg->postnet_filts % 2 == 0))
+        return fail(nullptr, FS2_ERR_UNSUPPORTED, "even convolution kernel sizes are not supported");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, FS2_ERR_HIP, "no HIP device is visible: libfs2_hip has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, FS2_ERR_ARG, "device %d out of range (%d visible)", cfg->device, ndev);
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    fs2_handle* h = new fs2_handle();
+    h->cfg = *cfg;
+    *out = h;
+    return FS2_OK;
+}
+
+void fs2_destroy(fs2_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    free_weights(h);
+    for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    delete h;
+}
+
+const char* fs2_last_error(const fs2_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int fs2_load_weights(fs2_handle* h, const fs2_tensor_desc* t, int32_t n, void* stream) {
+    if (!h || !t || n <= 0) return fail(h, FS2_ERR_ARG, "fs2_load_weights: bad arguments");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(h, hipStreamSynchronize(s));   // nothing may still be reading the old weights
+    free_weights(h);
+    h->encoded = false;
+    const fs2_config& c = h->cfg;
+    Loader L{h, s, {}, FS2_OK};
+    for (int i = 0; i < n; ++i) if (t[i].name) L.m[t[i].name] = &t[i];
+
+    h->enc_embed = L.copy("encoder.embed.0.weight", {c.idim, c.adim});
+    load_stack(L, h->enc, "encoder", c.elayers, c.adim, c.eunits, c.ffn_kernel, "encoder.embed.1", c.use_scaled_pos_enc);
+    load_stack(L, h->dec, "decoder", c.dlayers, c.ddim, c.dunits, c.ffn_kernel, "decoder.embed.4", c.use_scaled_pos_enc);
+    load_predictor(L, h->dur, "duration_predictor", c.dur_layers, c.adim, c.dur_chans, c.dur_kernel);
+    load_predictor(L, h->energy, "energy_predictor.predictor", c.var_layers, c.adim, c.var_chans, c.var_kernel);
+    load_predictor(L, h->pitch, "pitch_predictor.predictor", c.var_layers, c.adim, c.var_chans, c.var_kernel);
+    h->ebins = L.copy("energy_predictor.energy_bins", {c.n_bins - 1});
+    h->pbins = L.copy("pitch_predictor.pitch_bins", {c.n_bins - 1});
+    h->Te = L.dalloc((size_t)c.n_bins * c.adim);
+    h->Tp = L.dalloc((size_t)c.n_bins * c.adim);
+    {
+        const fs2_tensor_desc *we = L.get("energy_embed.weight", {c.adim, c.n_bins}), *be = L.get("energy_embed.bias", {c.adim});
+        const fs2_tensor_desc *wp = L.get("pitch_embed.weight", {c.adim, c.n_bins}), *bp = L.get("pitch_embed.bias", {c.adim});
+        if (we && be && wp && bp && h->Te && h->Tp) {
+            const int tot = c.adim * c.n_bins;
+            hipLaunchKernelGGL(onehot_table, dim3((tot + 255) / 256), dim3(256), 0, s, (const float*)we->data, (const float*)be->data, c.adim, c.n_bins, h->Te);
+            hipLaunchKernelGGL(onehot_table, dim3((tot + 255) / 256), dim3(256), 0, s, (const float*)wp->data, (const float*)bp->data, c.adim, c.n_bins, h->Tp);
+        }
+    }
+    h->dec_in = L.gemm({"decoder.embed.0.weight"}, {"decoder.embed.0.bias"}, c.ddim, c.adim, 1, true);
+    h->dec_in_lng = L.copy("decoder.embed.1.weight", {c.ddim});
+    h->dec_in_lnb = L.copy("decoder.embed.1.bias", {c.ddim});
+    h->feat = L.gemm({"feat_out.weight"}, {"feat_out.bias"}, c.odim, c.ddim, 1, true);
+    h->post.clear();
+    for (int l = 0; l < c.postnet_layers; ++l) {
+        const std::string p = "postnet.postnet." + std::to_string(l);
+        const int ic = (l == 0) ? c.odim : c.postnet_chans;
+        const int oc = (l == c.postnet_layers - 1) ? c.odim : c.postnet_chans;
+        h->post.push_back(L.gemm({p + ".0.weight"}, {}, oc, ic, c.postnet_filts, false, c.use_batch_norm ? p + ".1" : std::string()));
+    }
+    if (L.rc) { free_weights(h); return L.rc; }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(s));   // source tensors may be released by the caller after return
+    h->loaded = true;
+    return FS2_OK;
+}
+
+int fs2_set_profiling(fs2_handle* h, int32_t on) {
+    if (!h) return FS2_ERR_ARG;
+    h->prof = on != 0;
+    for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    h->recs.clear();
+    return FS2_OK;
+}
+
+int fs2_get_profile(fs2_handle* h, const char** names, float* ms, double* flops, double* bytes, int32_t cap) {
+    if (!h) return FS2_ERR_ARG;
+    int n = 0;
+    for (auto& r : h->recs) {
+        if (n >= cap) break;
+        hipEventSynchronize(r.e1);
+        float t = 0.f;
+        hipEventElapsedTime(&t, r.e0, r.e1);
+        if (names) names[n] = r.name.c_str();
+        if (ms) ms[n] = t;
+        if (flops) flops[n] = r.flops;
+        if (bytes) bytes[n] = r.bytes;
+        ++n;
+    }
+    return n;
+}
+
+size_t fs2_token_workspace_bytes(const fs2_handle* h, const fs2_batch* b) {
+    if (!h || !b || b->B <= 0 || !b->ilens) return 0;
+    HostLayout L;
+    token_layout(*b, L);
+    return carve_tokens(h->cfg, *b, L, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
+    if (!h || !io) return fail(h, FS2_ERR_ARG, "fs2_encode: null argument");
+    if (!h->loaded) return fail(h, FS2_ERR_STATE, "fs2_encode: weights not loaded");
+    int rc = check_batch(h, io->batch);
+    if (rc) return rc;
+    if (!io->xs || !io->olens || !io->workspace) return fail(h, FS2_ERR_ARG, "fs2_encode: xs/olens/workspace must be given");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    const fs2_config& c = h->cfg;
+    const fs2_batch& b = io->batch;
+    if (h->prof) fs2_set_profiling(h, 1);   // new forward: drop the previous records
+    h->encoded = false;
+    token_layout(b, h->tok);
+    const HostLayout& L = h->tok;
+    if (L.len.size() && *std::max_element(L.len.begin(), L.len.end()) > h->enc.pe_rows)
+        return fail(h, FS2_ERR_ARG, "sequence longer than the positional table (%d rows): extend `pe` and reload", h->enc.pe_rows);
+    int* meta; StackBufs sb; float *p0, *p1, *dlog_rows; int64_t* dint; int* cum; int* o32; bool ok;
+    carve_tokens(c, b, L, io->workspace, io->workspace_bytes, &meta, &sb, &p0, &p1, &dlog_rows, &dint, &cum, &o32, &ok);
+    if (!ok) return fail(h, FS2_ERR_WORKSPACE, "fs2_encode: workspace too small");
+    if ((rc = upload_layout(h, s, L, meta, h->dtok))) return rc;
+    const DevLayout& dl = h->dtok;
+    {
+        Scope sc(h, s, "enc.embed", 0, 4.0 * L.R * c.adim * 2);
+        hipLaunchKernelGGL(embed_pe, dim3((L.R + 3) / 4), dim3(256), 0, s, io->xs, b.Tmax, h->enc_embed, c.idim, c.adim, h->enc.pe,
+                           h->enc.alpha, c.use_scaled_pos_enc ? 1.0f : sqrtf((float)c.adim), dl.row_pos, dl.row_seq, L.R, sb.x0);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if ((rc = run_stack(h, s, "enc", h->enc, c.adim, c.aheads, L.R, L, dl, /*mask_q=*/1, sb))) return rc;
+    if ((rc = run_predictor(h, s, "dur", h->dur, sb.x0, c.adim, L.R, dl.row_pos, p0, p1, dlog_rows))) return rc;
+    {
+        Scope sc(h, s, "dur.post", 0, 0);
+        const int n = b.B * b.Tmax;
+        hipLaunchKernelGGL(dur_finalize, dim3((n + 255) / 256), dim3(256), 0, s, dlog_rows, dl.start, dl.vlen, b.B, b.Tmax, io->d_log, dint);
+        HIP_TRY(h, hipGetLastError());
+        if (io->d_int) HIP_TRY(h, hipMemcpyAsync(io->d_int, dint, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(dur_scan, dim3(b.B), dim3(256), 0, s, io->ds ? io->ds : dint, b.Tmax, dl.vlen, cum, io->olens, o32);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (io->enc_out) {
+        if ((rc = unpack<float>(h, s, sb.x0, c.adim, dl.start, dl.vlen, b.B, b.Tmax, io->enc_out, 0.f))) return rc;
+    }
+    h->enc_final = sb.x0; h->cum = cum; h->enc_B = b.B; h->enc_Tmax = b.Tmax; h->enc_compat = b.compat_padded;
+    h->enc_ws = io->workspace;
+    h->encoded = true;
+    return FS2_OK;
+}
+
+size_t fs2_frame_workspace_bytes(const fs2_handle* h, const fs2_batch* b, const int64_t* olens) {
+    if (!h || !b || !olens || b->B <= 0) return 0;
+    HostLayout L;
+    frame_layout(*b, olens, 0, L);
+    return carve_frames(h->cfg, L, nullptr, 0, nullptr, nullptr);
+}
+
+int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
+    if (!h || !io) return fail(h, FS2_ERR_ARG, "fs2_decode: null argument");
+    if (!h->encoded) return fail(h, FS2_ERR_STATE, "fs2_decode called without a preceding fs2_encode");
+    const fs2_batch& b = io->batch;
+    int rc = check_batch(h, b);
+    if (rc) return rc;
+    if (b.B != h->enc_B || b.Tmax != h->enc_Tmax || b.compat_padded != h->enc_compat || io->token_workspace != h->enc_ws)
+        return fail(h, FS2_ERR_STATE, "fs2_decode: batch does not match the preceding fs2_encode");
+    if (!io->olens || !io->workspace || !io->after) return fail(h, FS2_ERR_ARG, "fs2_decode: olens/workspace/after must be given");
+    const fs2_config& c = h->cfg;
+    int mx = 0;
+    for (int i = 0; i < b.B; ++i) {
+        if (io->olens[i] <= 0) return fail(h, FS2_ERR_ARG, "olens[%d]=%lld", i, (long long)io->olens[i]);
+        mx = std::max(mx, (int)io->olens[i]);
+    }
+    if (io->Lmax < mx) return fail(h, FS2_ERR_ARG, "Lmax %d < longest utterance %d", io->Lmax, mx);
+    if (mx > h->dec.pe_rows) return fail(h, FS2_ERR_ARG, "utterance of %d frames exceeds the positional table (%d rows): extend `pe` and reload", mx, h->dec.pe_rows);
+    HIP_TRY(h, hipSetDevice(c.device));
+    hipStream_t s = (hipStream_t)stream;
+    HostLayout L;
+    frame_layout(b, io->olens, io->masked, L);
+    FrameBufs f; bool ok;
+    carve_frames(c, L, io->workspace, io->workspace_bytes, &f, &ok);
+    if (!ok) return fail(h, FS2_ERR_WORKSPACE, "fs2_decode: workspace too small");
+    DevLayout dl;
+    if ((rc = upload_layout(h, s, L, f.meta, dl))) return rc;
+    const int R = L.R;
+    {   // length regulator
+        Scope sc(h, s, "lr.expand", 0, 4.0 * R * c.adim * 2);
+        hipLaunchKernelGGL(lr_expand, dim3((R + 3) / 4), dim3(256), 0, s, h->enc_final, c.adim, h->dtok.start, h->dtok.vlen, h->cum, b.Tmax,
+                           dl.row_pos, dl.row_seq, 0, dl.vlen, R, f.hfr, f.lri);
+        HIP_TRY(h, hipGetLastError());
+    }
+    const bool need_e = (io->es == nullptr) || io->e_out, need_p = (io->ps == nullptr) || io->p_out;
+    if (need_e && (rc = run_predictor(h, s, "energy", h->energy, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.e_rows))) return rc;
+    if (need_p && (rc = run_predictor(h, s, "pitch", h->pitch, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.p_rows))) return rc;
+    {
+        Scope sc(h, s, "var.embed", 0, 4.0 * R * c.adim * 4);
+        hipLaunchKernelGGL(bucket_embed, dim3((R + 3) / 4), dim3(256), 0, s, f.hfr, c.adim, dl.row_pos, dl.row_seq, R, io->es, io->es_stride,
+                           io->ps, io->ps_stride, f.e_rows, f.p_rows, h->ebins, h->pbins, c.n_bins - 1, h->Te, h->Tp, f.qe, f.qp);
+        HIP_TRY(h, hipGetLastError());
+    }
+    {   // decoder input layer: Linear -> LN -> ReLU -> + alpha * pe   (reference encoder.py:118-125)
+        GemmArgs a = gemm_args(h->dec_in, f.hfr, c.adim, R, dl.row_pos, f.sb.x0, c.ddim);
+        a.ln_g = h->dec_in_lng; a.ln_b = h->dec_in_lnb; a.ln_eps = 1e-5f; a.act_post = 1;
+        a.pe = h->dec.pe; a.pe_ld = c.ddim; a.pe_alpha = h->dec.alpha; a.x_scale = c.use_scaled_pos_enc ? 1.f : sqrtf((float)c.ddim);
+        if ((rc = launch_gemm(h, s, "dec.in", a))) return rc;
+    }
+    const int mask_q = (b.compat_padded && io->masked) ? 1 : 0;
+    if ((rc = run_stack(h, s, "dec", h->dec, c.ddim, c.aheads, R, L, dl, mask_q, f.sb))) return rc;
+    {
+        GemmArgs a = gemm_args(h->feat, f.sb.x0, c.ddim, R, dl.row_pos, f.before, c.odim);
+        if ((rc = launch_gemm(h, s, "feat_out", a))) return rc;
+    }
+    const float* mel_after = f.before;
+    if (c.postnet_layers > 0) {
+        float* pa = f.sb.hid;
+        float* pb = f.sb.hid + (size_t)L.Rpad * c.postnet_chans;
+        const float* in = f.before; int ld = c.odim;
+        for (int l = 0; l < c.postnet_layers; ++l) {
+            const bool last = (l == c.postnet_layers - 1);
+            float* out = last ? f.after : ((l & 1) ? pb : pa);
+            GemmArgs a = gemm_args(h->post[l], in, ld, R, dl.row_pos, out, h->post[l].N);
+            if (!last) a.act_post = 2; else { a.resid = f.before; a.ldr = c.odim; }
+            char nm[32]; snprintf(nm, sizeof nm, "postnet.%d", l);
+            if ((rc = launch_gemm(h, s, nm, a))) return rc;
+            in = out; ld = h->post[l].N;
+        }
+        mel_after = f.after;
+    }
+    {
+        Scope sc(h, s, "unpack", 0, 4.0 * R * c.odim * 4);
+        const int* lim_len = dl.len;    // every stored row (pads carry real values in compat mode)
+        const int* lim_msk = (b.compat_padded && !io->masked) ? dl.len : dl.vlen;
+        if ((rc = unpack<float>(h, s, mel_after, c.odim, dl.start, lim_len, b.B, io->Lmax, io->after, 0.f))) return rc;
+        if (io->before && (rc = unpack<float>(h, s, f.before, c.odim, dl.start, lim_len, b.B, io->Lmax, io->before, 0.f))) return rc;
+        if (io->e_out && (rc = unpack<float>(h, s, f.e_rows, 1, dl.start, lim_msk, b.B, io->Lmax, io->e_out, 0.f))) return rc;
+        if (io->p_out && (rc = unpack<float>(h, s, f.p_rows, 1, dl.start, lim_msk, b.B, io->Lmax, io->p_out, 0.f))) return rc;
+        if (io->qe && (rc = unpack<int>(h, s, f.qe, 1, dl.start, lim_len, b.B, io->Lmax, io->qe, -1))) return rc;
+        if (io->qp && (rc = unpack<int>(h, s, f.qp, 1, dl.start, lim_len, b.B, io->Lmax, io->qp, -1))) return rc;
+        if (io->lr_index && (rc = unpack<int>(h, s, f.lri, 1, dl.start, dl.vlen, b.B, io->Lmax, io->lr_index, -1))) return rc;
+        if (io->dec_out && (rc = unpack<float>(h, s, f.sb.x0, c.ddim, dl.start, lim_len, b.B, io->Lmax, io->dec_out, 0.f))) return rc;
+    }
+    return FS2_OK;
+}
+
+// ---------------------------------------------------------------------------------- single operators
+#define OP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); return FS2_ERR_HIP; } } while (0)
+
+int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
+    if (!o || !o->x || !o->w || o->R <= 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_conv_gemm: bad arguments");
+    if (o->precision != FS2_PREC_FP32) return fail(nullptr, FS2_ERR_UNSUPPORTED, "precision %d not built", o->precision);
+    hipStream_t s = (hipStream_t)stream;
+    Gemm g; g.N = o->N; g.C = o->C; g.ktaps = o->ktaps; g.Cpad = round_up(o->C, kBK);
+    const int Npad = round_up(o->N, 128);
+    const size_t wn = (size_t)Npad * o->ktaps * g.Cpad;
+    OP_TRY(hipMalloc((void**)&g.w, wn * sizeof(float)));
+    int* rp = nullptr;
+    hipMemsetAsync(g.w, 0, wn * sizeof(float), s);
+    const int64_t total = (int64_t)o->N * o->ktaps * g.Cpad;
+    hipLaunchKernelGGL(repack_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, o->w, o->N, o->C, o->ktaps, o->N, g.Cpad,
+                       (const float*)nullptr, (const float*)nullptr, 0.f, g.w);
+    g.bias = const_cast<float*>(o->bias);
+    GemmArgs a = gemm_args(g, o->x, o->C, o->R, nullptr, o->y, o->N);
+    if (o->row_valid) {   // row_valid (0/1) -> row_pos (-1 / 0)
+        OP_TRY(hipMalloc((void**)&rp, (size_t)o->R * sizeof(int)));
+        std::vector<int> hv(o->R);
+        OP_TRY(hipMemcpyAsync(hv.data(), o->row_valid, (size_t)o->R * sizeof(int), hipMemcpyDeviceToHost, s));
+        OP_TRY(hipStreamSynchronize(s));
+        for (auto& v : hv) v = v ? 0 : -1;
+        OP_TRY(hipMemcpyAsync(rp, hv.data(), (size_t)o->R * sizeof(int), hipMemcpyHostToDevice, s));
+        a.row_pos = rp;
+    }
+    a.resid = o->resid; a.ldr = o->N; a.relu_pre = o->relu_pre; a.ln_g = o->ln_gamma; a.ln_b = o->ln_beta; a.ln_eps = o->ln_eps;
+    a.act_post = o->act_post; a.dot_w = o->dot_w; a.dot_b = o->dot_b; a.dot_out = o->dot_out;
+    int rc = launch_gemm(nullptr, s, "op.conv_gemm", a);
+    hipStreamSynchronize(s);
+    hipFree(g.w);
+    if (rp) hipFree(rp);
+    return rc;
+}
+
+int fs2_op_attention(void* stream, const float* qkv, float* ctx, int32_t D, int32_t heads, int32_t B, const int32_t* seq_start,
+                     const int32_t* seq_len, const int32_t* seq_klen, int32_t mask_q, int32_t precision) {
+    if (!qkv || !ctx || B <= 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_attention: bad arguments");
+    if (precision != FS2_PREC_FP32) return fail(nullptr, FS2_ERR_UNSUPPORTED, "precision %d not built", precision);
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<int> host;
+    std::vector<int2> work;
+    for (int b = 0; b < B; ++b) for (int q = 0; q * kAttBQ < seq_len[b]; ++q) work.push_back(make_int2(b, q));
+    host.insert(host.end(), seq_start, seq_start + B);
+    host.insert(host.end(), seq_len, seq_len + B);
+    host.insert(host.end(), seq_klen, seq_klen + B);
+    for (auto& w : work) { host.push_back(w.x); host.push_back(w.y); }
+    int* dev = nullptr;
+    OP_TRY(hipMalloc((void**)&dev, host.size() * sizeof(int) + 16));
+    OP_TRY(hipMemcpyAsync(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    DevLayout dl;
+    dl.start = dev; dl.len = dev + B; dl.klen = dev + 2 * B; dl.work = reinterpret_cast<int2*>(dev + 3 * B);
+    int rc = launch_attention(nullptr, s, "op.attention", qkv, ctx, D, heads, dl, (int)work.size(), mask_q, 0.0);
+    hipStreamSynchronize(s);
+    hipFree(dev);
+    return rc;
+}
+
+int fs2_op_length_regulate(void* stream, const float* hs, const int64_t* ds, const int64_t* ilens_host, int32_t B, int32_t Tmax,
+                           int32_t D, int32_t Lmax, float* out, int32_t* index, int64_t* olens) {
+    if (!hs || !ds || !ilens_host || !out || B <= 0 || D % 4) return fail(nullptr, FS2_ERR_ARG, "fs2_op_length_regulate: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<int> host(2 * B);
+    for (int b = 0; b < B; ++b) { host[b] = b * Tmax; host[B + b] = (int)ilens_host[b]; }
+    int* dev = nullptr;
+    OP_TRY(hipMalloc((void**)&dev, ((size_t)3 * B + (size_t)B * Tmax) * sizeof(int)));
+    OP_TRY(hipMemcpyAsync(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    int *tok_start = dev, *ilen = dev + B, *o32 = dev + 2 * B, *cum = dev + 3 * B;
+    hipLaunchKernelGGL(dur_scan, dim3(B), dim3(256), 0, s, ds, Tmax, ilen, cum, olens, o32);
+    const int R = B * Lmax;
+    hipLaunchKernelGGL(lr_expand, dim3((R + 3) / 4), dim3(256), 0, s, hs, D, tok_start, ilen, cum, Tmax, (const int*)nullptr,
+                       (const int*)nullptr, Lmax, o32, R, out, index);
+    hipError_t e = hipGetLastError();
+    hipStreamSynchronize(s);
+    hipFree(dev);
+    if (e != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "length_regulate: %s", hipGetErrorString(e));
+    return FS2_OK;
+}
+
+int fs2_op_bucketize(void* stream, const float* x, int64_t n, const float* bins, int32_t nb, int32_t* idx) {
+    if (!x || !bins || !idx || n < 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_bucketize: bad arguments");
+    if (n == 0) return FS2_OK;
+    hipLaunchKernelGGL(bucketize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, bins, nb, idx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "bucketize: %s", hipGetErrorString(e));
+    return FS2_OK;
+}
+
+}  // extern "C"

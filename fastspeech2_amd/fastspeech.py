@@ -1,0 +1,463 @@
+"""Drop-in ``FeedForwardTransformer`` whose tensor work runs in libfs2_hip.so on an MI355X.
+
+Mirrors the public surface of the reference module (reference fastspeech.py:28-387):
+``FeedForwardTransformer(idim, odim, hp)``, ``forward(xs, ilens, ys, olens, ds, es, ps)``,
+``inference(x)``, ``_forward(xs, ilens, olens, ds, es, ps, is_inference)``, and the same
+``state_dict()`` key names / shapes, so checkpoints and the
+reference's ``inference.py`` / ``evaluation.py`` call sites work unchanged.
+
+The sub-modules below are *parameter containers only* (standard torch layers used for
+their parameter shapes, default init and state-dict names); none of their ``forward``
+methods is ever called.  All arithmetic happens in the HIP library through the C ABI in
+``include/fs2.h``; there is no CPU / eager fallback: a CPU tensor, a missing library or
+training-mode autograd raises.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+
+__all__ = ["FeedForwardTransformer"]
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter containers (names fixed by the reference's state-dict layout)
+# ----------------------------------------------------------------------------------------------
+def sinusoid_table(n, d):
+    """pe[t,2i]=sin(t*exp(-2i*ln(1e4)/d)), pe[t,2i+1]=cos(.)  (reference core/embedding.py:57-66).
+    Built on the host once (trig tables belong on the host, not in the streaming kernel)."""
+    pos = torch.arange(0, n, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe = torch.zeros(n, d)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.unsqueeze(0)
+
+
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container: the forward pass runs in libfs2_hip.so")
+
+
+class _PositionalTable(_Holder):
+    """`pe` persistent buffer [1, 5000, d] (+ learnable `alpha` when scaled), embedding.py:28-120."""
+
+    def __init__(self, d, scaled, max_len=5000):
+        super().__init__()
+        self.d_model = d
+        self.register_buffer("pe", sinusoid_table(max_len, d))
+        if scaled:
+            self.alpha = nn.Parameter(torch.tensor(1.0))
+
+    def ensure(self, n):
+        if self.pe.shape[1] < n:   # reference extend_pe(): recompute a longer table
+            self.pe = sinusoid_table(n, self.d_model).to(self.pe.device)
+
+
+class _SelfAttention(_Holder):
+    def __init__(self, d):
+        super().__init__()
+        self.linear_q, self.linear_k = nn.Linear(d, d), nn.Linear(d, d)
+        self.linear_v, self.linear_out = nn.Linear(d, d), nn.Linear(d, d)
+
+
+class _FeedForward(_Holder):
+    def __init__(self, d, units, kernel, conv):
+        super().__init__()
+        if conv:
+            self.w_1 = nn.Conv1d(d, units, kernel, padding=(kernel - 1) // 2)
+            self.w_2 = nn.Conv1d(units, d, 1)
+        else:
+            self.w_1, self.w_2 = nn.Linear(d, units), nn.Linear(units, d)
+
+
+class _FFTBlock(_Holder):
+    def __init__(self, d, units, kernel, conv):
+        super().__init__()
+        self.self_attn = _SelfAttention(d)
+        self.feed_forward = _FeedForward(d, units, kernel, conv)
+        self.norm1, self.norm2 = nn.LayerNorm(d), nn.LayerNorm(d)
+        self.concat_linear = nn.Linear(2 * d, d)      # present in checkpoints, unused (concat_after=False)
+
+
+class _FFTStack(_Holder):
+    """core/encoder.py:74-204: `embed` + `encoders_` (+ unused `after_norm`)."""
+
+    def __init__(self, embed, d, units, nblocks, kernel, conv):
+        super().__init__()
+        self.after_norm = nn.LayerNorm(d)
+        self.embed = embed
+        self.encoders_ = nn.ModuleList([_FFTBlock(d, units, kernel, conv) for _ in range(nblocks)])
+
+
+class _ChannelLayerNorm(_Holder):
+    def __init__(self, n):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(n, eps=1e-12)
+
+
+class _ConvStackPredictor(_Holder):
+    """duration_predictor.py:14-86 / variance_predictor.py:7-95."""
+
+    def __init__(self, idim, n_layers=2, n_chans=256, kernel_size=3):
+        super().__init__()
+        self.conv = nn.ModuleList()
+        for i in range(n_layers):
+            self.conv.append(nn.Sequential(
+                nn.Conv1d(idim if i == 0 else n_chans, n_chans, kernel_size, padding=(kernel_size - 1) // 2),
+                nn.ReLU(), _ChannelLayerNorm(n_chans), nn.Dropout(0.5)))
+        self.linear = nn.Linear(n_chans, 1)
+
+
+class _QuantisingPredictor(_Holder):
+    """Energy/Pitch predictor: a bins buffer + a default-shaped conv stack (the reference ignores
+    its ctor args here, variance_predictor.py:125,198)."""
+
+    def __init__(self, idim, bins_name, bins):
+        super().__init__()
+        self._bins_name = bins_name
+        self.register_buffer(bins_name, bins)
+        self.predictor = _ConvStackPredictor(idim)
+
+    def to_one_hot(self, x):
+        """bucketize + one-hot on the caller's device (variance_predictor.py:154-159,227-232)."""
+        return F.one_hot(_bucketize(x, getattr(self, self._bins_name)).long(), 256).float()
+
+
+class _Postnet(_Holder):
+    def __init__(self, odim, n_layers, n_chans, n_filts, use_bn):
+        super().__init__()
+        self.postnet = nn.ModuleList()
+        for l in range(n_layers):
+            ic = odim if l == 0 else n_chans
+            oc = odim if l == n_layers - 1 else n_chans
+            mods = [nn.Conv1d(ic, oc, n_filts, padding=(n_filts - 1) // 2, bias=False)]
+            if use_bn:
+                mods.append(nn.BatchNorm1d(oc))
+            if l != n_layers - 1:
+                mods.append(nn.Tanh())
+            mods.append(nn.Dropout(0.5))
+            self.postnet.append(nn.Sequential(*mods))
+
+
+def _bucketize(x, bins):
+    """torch.bucketize semantics through the HIP kernel (device tensors only)."""
+    _require_device(x)
+    x = x.contiguous().float()
+    out = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    L = _lib.lib()
+    with torch.cuda.device(x.device):
+        _lib.check(L.fs2_op_bucketize(_stream(x.device), x.data_ptr(), x.numel(), bins.contiguous().data_ptr(),
+                                      bins.numel(), out.data_ptr()))
+    return out
+
+
+def _require_device(t):
+    if not t.is_cuda:
+        raise RuntimeError("fastspeech2_amd runs on an MI355X only: got a %s tensor (no CPU fallback; "
+                           "move the module and its inputs to a HIP device)" % t.device)
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# ----------------------------------------------------------------------------------------------
+class FeedForwardTransformer(nn.Module):
+    """Feed-forward Transformer TTS acoustic model (FastSpeech 2) on libfs2_hip.
+
+    Extra (non-reference) knobs, all optional:
+      * ``precision``: "fp32" (f32-input MFMA, default), "bf16x3", "bf16".
+      * ``batch_semantics``: "per_utterance" (default; every utterance is computed exactly as if it
+        were alone -- what ``inference()`` produces; batch invariant, shardable) or "padded_compat"
+        (bit-for-bit the reference's padded-batch behaviour where convolutions and unmasked attention
+        see pad rows).  ``forward()`` (the loss path) always uses "padded_compat".
+    """
+
+    def __init__(self, idim: int, odim: int, hp):
+        super().__init__()
+        m = hp.model
+        self.idim, self.odim = idim, odim
+        self.use_scaled_pos_enc = bool(m.use_scaled_pos_enc)
+        self.use_masking = bool(m.use_masking)
+        self.use_weighted_masking = bool(m.use_weighted_masking)
+        if m.encoder_normalize_before or m.decoder_normalize_before or m.encoder_concat_after or m.decoder_concat_after:
+            raise NotImplementedError("only post-LN FFT blocks without concat_after (the reference default) are implemented")
+        if m.positionwise_layer_type not in ("conv1d", "linear"):
+            raise NotImplementedError("Support only linear or conv1d.")
+        if m.reduction_factor != 1:
+            raise NotImplementedError("reduction_factor != 1")
+        conv = m.positionwise_layer_type == "conv1d"
+        kernel = m.positionwise_conv_kernel_size if conv else 1
+        self._cfg = dict(
+            idim=idim, odim=odim, adim=m.adim, aheads=m.aheads, elayers=m.elayers, eunits=m.eunits, ddim=m.ddim,
+            dlayers=m.dlayers, dunits=m.dunits, ffn_kernel=kernel,
+            dur_layers=m.duration_predictor_layers, dur_chans=m.duration_predictor_chans,
+            dur_kernel=m.duration_predictor_kernel_size, var_layers=2, var_chans=256, var_kernel=3, n_bins=256,
+            postnet_layers=m.postnet_layers, postnet_chans=m.postnet_chans, postnet_filts=m.postnet_filts,
+            use_batch_norm=int(bool(m.use_batch_norm)), use_scaled_pos_enc=int(self.use_scaled_pos_enc),
+            reduction_factor=m.reduction_factor)
+
+        enc_embed = nn.Sequential(nn.Embedding(idim, m.adim, padding_idx=0), _PositionalTable(m.adim, self.use_scaled_pos_enc))
+        self.encoder = _FFTStack(enc_embed, m.adim, m.eunits, m.elayers, kernel, conv)
+        self.duration_predictor = _ConvStackPredictor(m.adim, m.duration_predictor_layers, m.duration_predictor_chans,
+                                                      m.duration_predictor_kernel_size)
+        self.energy_predictor = _QuantisingPredictor(m.adim, "energy_bins",
+                                                     torch.linspace(hp.data.e_min, hp.data.e_max, 255))
+        self.energy_embed = nn.Linear(m.adim, m.adim)
+        self.pitch_predictor = _QuantisingPredictor(
+            m.adim, "pitch_bins",
+            torch.exp(torch.linspace(torch.log(torch.tensor(float(hp.data.p_min))),
+                                     torch.log(torch.tensor(float(hp.data.p_max))), 255)))
+        self.pitch_embed = nn.Linear(m.adim, m.adim)
+        dec_embed = nn.Sequential(nn.Linear(m.adim, m.ddim), nn.LayerNorm(m.ddim), nn.Dropout(0.2), nn.ReLU(),
+                                  _PositionalTable(m.ddim, self.use_scaled_pos_enc))
+        self.decoder = _FFTStack(dec_embed, m.ddim, m.dunits, m.dlayers, kernel, conv)
+        self.postnet = None if m.postnet_layers == 0 else _Postnet(odim, m.postnet_layers, m.postnet_chans,
+                                                                   m.postnet_filts, bool(m.use_batch_norm))
+        self.feat_out = nn.Linear(m.ddim, odim * m.reduction_factor)
+        self._reset_parameters(m.transformer_init, m.initial_encoder_alpha, m.initial_decoder_alpha)
+
+        self.precision = "fp32"
+        self.batch_semantics = "per_utterance"
+        self._handle = None
+        self._handle_device = None
+        self._fingerprint = None
+        self.last_olens = None
+
+    # ------------------------------------------------------------------ init (fastspeech.py:378-387)
+    def _reset_parameters(self, init_type, init_enc_alpha=1.0, init_dec_alpha=1.0):
+        if init_type != "pytorch":
+            fn = {"xavier_uniform": nn.init.xavier_uniform_, "xavier_normal": nn.init.xavier_normal_,
+                  "kaiming_uniform": lambda p: nn.init.kaiming_uniform_(p, nonlinearity="relu"),
+                  "kaiming_normal": lambda p: nn.init.kaiming_normal_(p, nonlinearity="relu")}.get(init_type)
+            if fn is None:
+                raise ValueError("Unknown initialization: " + init_type)
+            for p in self.parameters():
+                if p.dim() > 1:
+                    fn(p.data)
+                elif p.dim() == 1:
+                    p.data.zero_()
+            for mod in self.modules():
+                if isinstance(mod, (nn.Embedding, nn.LayerNorm)):
+                    mod.reset_parameters()
+        if self.use_scaled_pos_enc:
+            self.encoder.embed[-1].alpha.data = torch.tensor(float(init_enc_alpha))
+            self.decoder.embed[-1].alpha.data = torch.tensor(float(init_dec_alpha))
+
+    # ------------------------------------------------------------------ library handle / weights
+    def __del__(self):
+        self._drop_handle()
+
+    def _drop_handle(self):
+        h = getattr(self, "_handle", None)
+        if h is not None:
+            try:
+                _lib.lib().fs2_destroy(h)
+            except Exception:   # interpreter shutdown
+                pass
+            self._handle = None
+
+    def _weights_fingerprint(self):
+        sd = self.state_dict(keep_vars=True)
+        return tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+
+    def _ensure_ready(self, device, need_tok, need_frames=0):
+        """Create the device handle and (re)upload weights whenever any parameter changed."""
+        L = _lib.lib()
+        p0 = self.feat_out.weight
+        if p0.device != device:
+            raise RuntimeError("model is on %s but the input is on %s" % (p0.device, device))
+        self.encoder.embed[-1].ensure(need_tok)
+        self.decoder.embed[-1].ensure(max(need_frames, 1))
+        if self._handle is None or self._handle_device != device:
+            self._drop_handle()
+            cfg = _lib.Config(**self._cfg, device=device.index if device.index is not None else torch.cuda.current_device())
+            h = C.c_void_p()
+            _lib.check(L.fs2_create(C.byref(cfg), C.byref(h)))
+            self._handle, self._handle_device, self._fingerprint = h, device, None
+        fp = self._weights_fingerprint()
+        if fp != self._fingerprint:
+            sd = self.state_dict()
+            keep, descs = [], []
+            for name, t in sd.items():
+                if t.dtype != torch.float32:
+                    continue   # num_batches_tracked (int64) is not used in eval mode
+                t = t.detach().contiguous()
+                keep.append(t)
+                d = _lib.TensorDesc(name.encode(), t.data_ptr(), t.dim(), (C.c_int64 * 4)(*(list(t.shape) + [0] * (4 - t.dim()))))
+                descs.append(d)
+            arr = (_lib.TensorDesc * len(descs))(*descs)
+            with torch.cuda.device(device):
+                _lib.check(L.fs2_load_weights(self._handle, arr, len(descs), _stream(device)), self._handle)
+            self._fingerprint = fp
+        return L
+
+    def refresh_weights(self):
+        """Force a re-upload of the parameters on the next call (normally automatic)."""
+        self._fingerprint = None
+
+    # ------------------------------------------------------------------ the path
+    def _run(self, xs, ilens, olens=None, ds=None, es=None, ps=None, is_inference=False, compat=False,
+             want=("before", "after"), d_override=None):
+        """Runs fs2_encode -> (olens readback) -> fs2_decode.  Returns a dict of device tensors."""
+        _require_device(xs)
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "training (autograd / dropout / BatchNorm batch statistics) is outside the scope of this MI355X "
+                "inference path: call model.eval() and wrap calls in torch.no_grad()")
+        dev = xs.device
+        xs = xs.contiguous().long()
+        B, Tmax = xs.shape
+        il = torch.as_tensor(ilens).detach().to("cpu", torch.int64).contiguous()   # host lengths (reference: .tolist())
+        if il.numel() != B:
+            raise ValueError("ilens has %d entries for a batch of %d" % (il.numel(), B))
+        prec = _lib.PRECISIONS[self.precision]
+        L = self._ensure_ready(dev, Tmax)
+        h = self._handle
+        il_arr = (C.c_int64 * B)(*il.tolist())
+        batch = _lib.Batch(B, Tmax, il_arr, int(compat), prec)
+        out = {}
+        teacher = not is_inference
+        ds_dev = None
+        if teacher:
+            if ds is None or es is None or ps is None:
+                raise ValueError("teacher-forced _forward needs ds, es and ps")
+            ds_dev = ds.to(dev).long().contiguous()
+        elif d_override is not None:
+            ds_dev = d_override.to(dev).long().contiguous()
+        if ds_dev is not None and tuple(ds_dev.shape) != (B, Tmax):
+            raise ValueError("ds must be [B, Tmax] = [%d, %d], got %s" % (B, Tmax, tuple(ds_dev.shape)))
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            tok_ws = torch.empty(L.fs2_token_workspace_bytes(h, C.byref(batch)), dtype=torch.uint8, device=dev)
+            d_log = torch.empty(B, Tmax, dtype=torch.float32, device=dev) if teacher else None
+            d_int = torch.empty(B, Tmax, dtype=torch.int64, device=dev) if is_inference else None
+            olens_dev = torch.empty(B, dtype=torch.int64, device=dev)
+            enc_out = torch.empty(B, Tmax, self._cfg["adim"], device=dev) if "encoder_out" in want else None
+            eio = _lib.EncodeIO(batch, xs.data_ptr(), ds_dev.data_ptr() if ds_dev is not None else None,
+                                d_log.data_ptr() if d_log is not None else None,
+                                d_int.data_ptr() if d_int is not None else None, olens_dev.data_ptr(),
+                                enc_out.data_ptr() if enc_out is not None else None, tok_ws.data_ptr(), tok_ws.numel())
+            _lib.check(L.fs2_encode(h, st, C.byref(eio)), h)
+            ol = olens_dev.cpu()                     # the one host sync of the path (frame counts)
+            self.last_olens = ol
+            if olens is not None:
+                given = torch.as_tensor(olens).detach().to("cpu", torch.int64)
+                if not torch.equal(given, ol):
+                    raise ValueError("olens %s do not match the sums of the durations %s" % (given.tolist(), ol.tolist()))
+            Lmax = int(ol.max())
+            self.decoder.embed[-1].ensure(Lmax)
+            if self._weights_fingerprint() != self._fingerprint:   # pe table grew: reload and redo the encoder
+                return self._run(xs, ilens, olens, ds, es, ps, is_inference, compat, want, d_override)
+            ol_arr = (C.c_int64 * B)(*ol.tolist())
+            frm_ws = torch.empty(L.fs2_frame_workspace_bytes(h, C.byref(batch), ol_arr), dtype=torch.uint8, device=dev)
+            odim = self.odim
+
+            def buf(key, shape, dtype=torch.float32):
+                if key in want:
+                    out[key] = torch.empty(shape, dtype=dtype, device=dev)
+                    return out[key].data_ptr()
+                return None
+
+            es_dev = es.to(dev).float().contiguous() if teacher else None
+            ps_dev = ps.to(dev).float().contiguous() if teacher else None
+            masked = int(teacher and olens is not None) if compat else 0
+            dio = _lib.DecodeIO(
+                batch, ol_arr, Lmax, masked,
+                es_dev.data_ptr() if es_dev is not None else None, ps_dev.data_ptr() if ps_dev is not None else None,
+                es_dev.shape[1] if es_dev is not None else 0, ps_dev.shape[1] if ps_dev is not None else 0,
+                buf("before", (B, Lmax, odim)), buf("after", (B, Lmax, odim)),
+                buf("e_outs", (B, Lmax)), buf("p_outs", (B, Lmax)),
+                buf("qe", (B, Lmax), torch.int32), buf("qp", (B, Lmax), torch.int32),
+                buf("lr_index", (B, Lmax), torch.int32), buf("decoder_out", (B, Lmax, self._cfg["ddim"])),
+                tok_ws.data_ptr(), frm_ws.data_ptr(), frm_ws.numel())
+            if dio.after is None:
+                raise ValueError("'after' must be requested")
+            _lib.check(L.fs2_decode(h, st, C.byref(dio)), h)
+        out["olens"] = ol
+        if d_log is not None:
+            out["d_log"] = d_log
+        if d_int is not None:
+            out["d_int"] = d_int if d_override is None else ds_dev
+        if enc_out is not None:
+            out["encoder_out"] = enc_out
+        return out
+
+    def _forward(self, xs, ilens, olens=None, ds=None, es=None, ps=None, is_inference=False):
+        """reference fastspeech.py:169-243: returns (before, after, d_outs, e, p).
+
+        inference: d_outs int64 durations, e/p the one-hot energy/pitch codes [B, Lmax, 256];
+        otherwise: d_outs log-durations (pads 0), e/p the predictor outputs (pads 0)."""
+        compat = self.batch_semantics == "padded_compat"
+        if is_inference:
+            r = self._run(xs, ilens, is_inference=True, compat=compat, want=("before", "after", "qe", "qp"))
+            one_hot = lambda q: F.one_hot(q.clamp(min=0).long(), 256).float() * (q >= 0).unsqueeze(-1)
+            return r["before"], r["after"], r["d_int"], one_hot(r["qe"]), one_hot(r["qp"])
+        r = self._run(xs, ilens, olens, ds, es, ps, is_inference=False, compat=compat,
+                      want=("before", "after", "e_outs", "p_outs"))
+        return r["before"], r["after"], r["d_log"], r["e_outs"], r["p_outs"]
+
+    def forward(self, xs, ilens, ys, olens, ds, es, ps):
+        """reference fastspeech.py:245-337: losses of the teacher-forced pass; returns (loss, report_keys).
+
+        The forward pass runs on the device (padded_compat semantics, as the reference computes it); the
+        loss algebra on its outputs is plain PyTorch, as in the reference."""
+        _require_device(xs)
+        dev = xs.device
+        il = torch.as_tensor(ilens).to("cpu", torch.int64)
+        ol = torch.as_tensor(olens).to("cpu", torch.int64)
+        xs = xs[:, : int(il.max())]
+        ys = ys[:, : int(ol.max())].to(dev)
+        ds, es, ps = ds.to(dev), es.to(dev).float(), ps.to(dev).float()
+        ds_t = ds[:, : xs.shape[1]]
+        r = self._run(xs, il, ol, ds_t, es, ps, is_inference=False, compat=True,
+                      want=("before", "after", "e_outs", "p_outs"))
+        before, after, d_outs, e_outs, p_outs = r["before"], r["after"], r["d_log"], r["e_outs"], r["p_outs"]
+        ar_t = torch.arange(xs.shape[1], device=dev).unsqueeze(0)
+        ar_l = torch.arange(before.shape[1], device=dev).unsqueeze(0)
+        in_masks = ar_t < il.to(dev).unsqueeze(1)
+        mel_masks = ar_l < ol.to(dev).unsqueeze(1)
+        out_masks = mel_masks.unsqueeze(-1)
+        es, ps = es[:, : before.shape[1]], ps[:, : before.shape[1]]
+        if self.use_masking:
+            d_outs, ds_t = d_outs.masked_select(in_masks), ds_t.masked_select(in_masks)
+            before, after = before.masked_select(out_masks), after.masked_select(out_masks)
+            es, ps = es.masked_select(mel_masks), ps.masked_select(mel_masks)
+            e_outs, p_outs = e_outs.masked_select(mel_masks), p_outs.masked_select(mel_masks)
+            ys = ys.masked_select(out_masks)
+        before_loss = F.l1_loss(before, ys)
+        after_loss = F.l1_loss(after, ys)
+        l1_loss = before_loss + after_loss
+        duration_loss = F.mse_loss(d_outs, torch.log(ds_t.float() + 1.0))
+        energy_loss = F.mse_loss(e_outs, es)
+        pitch_loss = F.mse_loss(p_outs, ps)
+        if self.use_weighted_masking:
+            raise NotImplementedError("use_weighted_masking")
+        loss = l1_loss + duration_loss + energy_loss + pitch_loss
+        report_keys = [{"l1_loss": l1_loss.item()}, {"before_loss": before_loss.item()}, {"after_loss": after_loss.item()},
+                       {"duration_loss": duration_loss.item()}, {"energy_loss": energy_loss.item()},
+                       {"pitch_loss": pitch_loss.item()}, {"loss": loss.item()}]
+        return loss, report_keys
+
+    def inference(self, x):
+        """reference fastspeech.py:339-357: x [T] int64 phoneme ids -> mel [L, odim]."""
+        r = self._run(x.unsqueeze(0), torch.tensor([x.shape[0]]), is_inference=True, want=("after",))
+        return r["after"][0]
+
+    def inference_batch(self, xs, ilens, d_override=None):
+        """Batched free-running synthesis (not in the reference, which only has single-utterance
+        ``inference``): per-utterance semantics; returns (mels [B, Lmax, odim], olens [B] on the host)."""
+        r = self._run(xs, ilens, is_inference=True, compat=False, want=("after",), d_override=d_override)
+        return r["after"], r["olens"]
+
+    def _source_mask(self, ilens):
+        """reference fastspeech.py:359-376 (kept for API parity; the kernels take lengths, not masks)."""
+        il = torch.as_tensor(ilens)
+        m = torch.arange(int(il.max()), device=il.device).unsqueeze(0) < il.unsqueeze(1)
+        m = m.to(self.feat_out.weight.device)
+        return m.unsqueeze(-2) & m.unsqueeze(-1)

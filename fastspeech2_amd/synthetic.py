@@ -1,0 +1,110 @@
+"""Portable synthetic weights and batches.
+
+Everything comes from ``numpy.random.RandomState`` (bit-stable across numpy versions and
+machines), keyed by state-dict name, so the build container (where the reference is
+importable) and the GPU box (where it is not) construct identical models and inputs.
+There is no network for checkpoints or datasets: benchmarks and parity tests run on
+random-init weights of the reference architecture and LJSpeech-shaped synthetic batches.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+# Gamma fit to reference filelists/valid_filelist.txt durations (729 phonemes, mean 7.87).
+DUR_GAMMA_K, DUR_GAMMA_THETA = 2.85, 2.76
+
+
+def _rs(seed, name):
+    return np.random.RandomState((zlib.crc32(name.encode()) + 7919 * seed) & 0x7FFFFFFF)
+
+
+def portable_state_dict(template, seed=0):
+    """Fill a reference-layout state_dict (name -> tensor of the right shape) with portable values.
+
+    ``template`` is any mapping name -> tensor (e.g. ``model.state_dict()``); buffers that are
+    deterministic functions of the config (``pe``, ``energy_bins``, ``pitch_bins``,
+    ``num_batches_tracked``) are kept as constructed."""
+    out = {}
+    for name in sorted(template.keys()):
+        t = template[name]
+        shape = tuple(t.shape)
+        r = _rs(seed, name)
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf in ("pe", "energy_bins", "pitch_bins", "num_batches_tracked"):
+            out[name] = t.clone()
+            continue
+        if leaf == "alpha":
+            v = r.uniform(0.5, 1.5, size=shape)
+        elif leaf == "running_mean":
+            v = r.uniform(-0.5, 0.5, size=shape)
+        elif leaf == "running_var":
+            v = r.uniform(0.5, 2.0, size=shape)
+        elif len(shape) == 1 and leaf == "weight":          # LayerNorm / BatchNorm gain
+            v = 1.0 + r.uniform(-0.1, 0.1, size=shape)
+        elif len(shape) == 1 and leaf == "bias" and (".norm" in name or "layer_norm" in name
+                                                     or "after_norm" in name or name.endswith("embed.1.bias")
+                                                     or "postnet.postnet" in name):
+            v = r.uniform(-0.1, 0.1, size=shape)
+        elif name == "encoder.embed.0.weight":
+            v = r.uniform(-1.0, 1.0, size=shape)
+            v[0] = 0.0                                     # padding_idx row (fastspeech.py:57,65-67)
+        else:
+            if leaf == "weight":
+                fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+            else:                                           # bias of Linear/Conv: fan_in of its weight
+                w = template.get(name[: -len("bias")] + "weight")
+                fan_in = int(np.prod(tuple(w.shape)[1:])) if w is not None and w.dim() > 1 else max(shape[0], 1)
+            bound = 1.0 / np.sqrt(max(fan_in, 1))
+            v = r.uniform(-bound, bound, size=shape)
+        out[name] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape)).to(t.dtype)
+    return out
+
+
+def bias_durations(sd, mean_frames=7.87):
+    """Random-init predictors emit ~0 frames/phoneme; the free-running benchmark
+    sets duration_predictor.linear.bias = ln(1 + mean) so durations are LJSpeech-like."""
+    sd = dict(sd)
+    sd["duration_predictor.linear.bias"] = torch.full((1,), float(np.log(1.0 + mean_frames)))
+    return sd
+
+
+def draw_durations(rs, n):
+    d = np.rint(rs.gamma(DUR_GAMMA_K, DUR_GAMMA_THETA, size=n))
+    return np.clip(d, 1, 40).astype(np.int64)
+
+
+def make_batch(config, seed=None, teacher=True, B=None, tlens=None):
+    """Synthetic batch for BASELINE.json configs c1..c5.
+
+    Returns dict(xs [B,Tmax] i64, ilens [B] i64, ds [B,Tmax] i64, olens [B] i64,
+    es/ps [B,Lmax] f32) on the CPU.  ids ~ U{1..67}; durations Gamma-fit; energy ~ U(0,130.5);
+    pitch: 30 % exactly 0 (unvoiced) else U(71, 676)."""
+    spec = {
+        "c1": (1, 1, lambda r, b: np.full(b, 80)),
+        "c2": (2, 16, lambda r, b: r.randint(64, 129, size=b)),
+        "c3": (3, 64, lambda r, b: np.clip(np.rint(r.normal(75, 30, size=b)), 16, 180).astype(np.int64)),
+        "c4": (4, 256, lambda r, b: r.randint(32, 513, size=b)),
+        "c5": (5, 1024, lambda r, b: np.clip(np.rint(r.normal(75, 30, size=b)), 16, 180).astype(np.int64)),
+    }[config]
+    rs = np.random.RandomState(spec[0] if seed is None else seed)
+    B = spec[1] if B is None else B
+    T = np.asarray(spec[2](rs, B) if tlens is None else tlens, dtype=np.int64)
+    Tmax = int(T.max())
+    xs = np.zeros((B, Tmax), np.int64)
+    ds = np.zeros((B, Tmax), np.int64)
+    for b in range(B):
+        xs[b, : T[b]] = rs.randint(1, 68, size=T[b])
+        ds[b, : T[b]] = draw_durations(rs, T[b])
+    olens = ds.sum(1)
+    Lmax = int(olens.max())
+    es = np.zeros((B, Lmax), np.float32)
+    ps = np.zeros((B, Lmax), np.float32)
+    for b in range(B):
+        L = int(olens[b])
+        es[b, :L] = rs.uniform(0.0, 130.5, size=L)
+        p = rs.uniform(71.0, 676.0, size=L)
+        p[rs.uniform(size=L) < 0.3] = 0.0
+        ps[b, :L] = p
+    out = dict(xs=xs, ilens=T, ds=ds, olens=olens, es=es, ps=ps)
+    return {k: torch.from_numpy(v) for k, v in out.items()}

@@ -1,0 +1,180 @@
+/*
+ * fs2.h -- C ABI of libfs2_hip.so: the MI355X (gfx950) FastSpeech2 mel-generation forward pass.
+ *
+ * The reference (rishikksh20/FastSpeech2) has no FFI: its hot path sits behind a Python
+ * torch.nn.Module, `fastspeech.FeedForwardTransformer` (reference fastspeech.py:28).  This header is
+ * the boundary a maintainer of the reference would bind (ctypes stub in INTEGRATION.md) to replace the
+ * tensor work inside `_forward` (fastspeech.py:169-243) -- encoder/decoder FFT blocks
+ * (core/encoder.py:46-71,185-204; core/attention.py:30-74; core/modules.py:237-248), duration / pitch /
+ * energy predictors (core/duration_modeling/duration_predictor.py:64-86; core/variance_predictor.py:39-60,
+ * 154-159), length regulator (core/duration_modeling/length_regulator.py:38-95) and Postnet
+ * (core/modules.py:350-359) -- with hand-written HIP kernels.
+ *
+ * Conventions: plain pointers and sizes only (no torch types); every function returns 0 or a negative
+ * FS2_ERR_* code and never throws; `fs2_last_error` gives the message.  "device" pointers are HIP device
+ * memory on the handle's device, "host" pointers are ordinary host memory.  All launches go to the
+ * caller's hipStream_t (passed as void*); no function allocates device memory except fs2_create /
+ * fs2_load_weights (weight storage).  A handle is bound to one device and is not thread-safe.
+ *
+ * A forward pass is two calls, because the number of mel frames is data dependent:
+ *   fs2_encode  : phoneme ids -> encoder -> duration predictor -> frame counts (olens, device)
+ *   (caller reads olens back: the one unavoidable host sync of the path)
+ *   fs2_decode  : length regulator -> pitch/energy -> decoder -> mel projection -> Postnet
+ */
+#ifndef FS2_H_
+#define FS2_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS2_OK 0
+#define FS2_ERR_ARG (-1)         /* bad argument / shape                                   */
+#define FS2_ERR_HIP (-2)         /* a HIP runtime call failed                              */
+#define FS2_ERR_STATE (-3)       /* call order violated (e.g. decode before encode)        */
+#define FS2_ERR_WEIGHT (-4)      /* a required tensor is missing or has the wrong shape    */
+#define FS2_ERR_WORKSPACE (-5)   /* workspace too small                                    */
+#define FS2_ERR_UNSUPPORTED (-6) /* configuration outside what the kernels implement       */
+
+/* arithmetic modes of the GEMM-shaped kernels */
+#define FS2_PREC_FP32 0   /* f32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32            */
+#define FS2_PREC_BF16X3 1 /* split-bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 */
+#define FS2_PREC_BF16 2   /* plain bf16 inputs, fp32 accumulate                             */
+
+typedef struct fs2_handle fs2_handle;
+
+/* Model hyper-parameters: the hp.model / hp.data fields FeedForwardTransformer.__init__ reads
+ * (reference fastspeech.py:53-160). */
+typedef struct fs2_config {
+    int32_t idim, odim;                 /* phoneme symbols (68), mel bins (80)               */
+    int32_t adim, aheads, elayers, eunits;
+    int32_t ddim, dlayers, dunits;
+    int32_t ffn_kernel;                 /* positionwise_conv_kernel_size; 1 for "linear"      */
+    int32_t dur_layers, dur_chans, dur_kernel;   /* duration predictor (from hp)              */
+    int32_t var_layers, var_chans, var_kernel;   /* pitch/energy predictors (hard-wired 2/256/3,
+                                                    reference variance_predictor.py:125,198)   */
+    int32_t n_bins;                     /* 256 quantisation levels                            */
+    int32_t postnet_layers, postnet_chans, postnet_filts, use_batch_norm;
+    int32_t use_scaled_pos_enc;
+    int32_t reduction_factor;           /* only 1 is implemented                              */
+    int32_t device;                     /* HIP device ordinal                                 */
+} fs2_config;
+
+/* One reference-layout tensor (state_dict entry), fp32, resident on the device. */
+typedef struct fs2_tensor_desc {
+    const char *name;   /* e.g. "decoder.encoders_.0.feed_forward.w_1.weight" */
+    const void *data;   /* device pointer, contiguous, float32                 */
+    int32_t ndim;
+    int64_t shape[4];
+} fs2_tensor_desc;
+
+/* Host-side description of a batch (lengths are host data: the reference also reads them on the host,
+ * utils/util.py:263-264). */
+typedef struct fs2_batch {
+    int32_t B;              /* utterances                                                      */
+    int32_t Tmax;           /* padded phoneme length of xs                                      */
+    const int64_t *ilens;   /* host [B] phoneme counts                                          */
+    int32_t compat_padded;  /* 0: per-utterance semantics (batch invariant; what inference()
+                               computes).  1: reproduce the reference's padded-batch numerics
+                               (conv / unmasked attention see the pad rows)      */
+    int32_t precision;      /* FS2_PREC_*                                                      */
+} fs2_batch;
+
+typedef struct fs2_encode_io {
+    fs2_batch batch;
+    const int64_t *xs;        /* device [B, Tmax] phoneme ids (0 = pad)                         */
+    const int64_t *ds;        /* device [B, Tmax] durations to use (teacher forcing / override),
+                                 or NULL: use the predicted durations                           */
+    float *d_log;             /* device [B, Tmax] log-domain predictor output, pads = 0, or NULL */
+    int64_t *d_int;           /* device [B, Tmax] clamp(round(exp(y)-1),0), pads = 0, or NULL    */
+    int64_t *olens;           /* device [B] frames per utterance = sum of the durations used
+                                 (an all-zero row counts as all ones, length_regulator.py:86-88) */
+    float *enc_out;           /* device [B, Tmax, adim] encoder output, pads = 0, or NULL        */
+    void *workspace;          /* device, fs2_token_workspace_bytes(); must stay alive and
+                                 untouched until the matching fs2_decode returns                 */
+    size_t workspace_bytes;
+} fs2_encode_io;
+
+typedef struct fs2_decode_io {
+    fs2_batch batch;
+    const int64_t *olens;     /* HOST [B]: the values fs2_encode wrote to its device olens       */
+    int32_t Lmax;             /* padded frame length of the outputs (>= max olens)               */
+    int32_t masked;           /* compat_padded only: 1 = decoder attention / predictor outputs
+                                 masked by olens (teacher-forced `_forward`), 0 = no masks
+                                 (inference)                                                     */
+    const float *es;          /* device [B, es_stride] energies to quantise, or NULL: predict    */
+    const float *ps;          /* device [B, ps_stride] pitches to quantise,  or NULL: predict    */
+    int32_t es_stride, ps_stride;
+    float *before;            /* device [B, Lmax, odim] mel before Postnet (pads = 0 unless compat) */
+    float *after;             /* device [B, Lmax, odim] mel after Postnet                         */
+    float *e_out, *p_out;     /* device [B, Lmax] predictor outputs (or NULL)                     */
+    int32_t *qe, *qp;         /* device [B, Lmax] bucket indices actually embedded (or NULL)      */
+    int32_t *lr_index;        /* device [B, Lmax] phoneme index of every frame, -1 at pads (or NULL) */
+    float *dec_out;           /* device [B, Lmax, ddim] decoder output (or NULL)                  */
+    void *token_workspace;    /* the workspace given to fs2_encode                               */
+    void *workspace;          /* device, fs2_frame_workspace_bytes()                              */
+    size_t workspace_bytes;
+} fs2_decode_io;
+
+/* lifecycle (replaces FeedForwardTransformer.__init__ / .to(device) / load_state_dict,
+ * reference fastspeech.py:37-167, inference.py:156-166) */
+int fs2_create(const fs2_config *cfg, fs2_handle **out);
+void fs2_destroy(fs2_handle *h);
+const char *fs2_last_error(const fs2_handle *h); /* h may be NULL: last creation error */
+int fs2_load_weights(fs2_handle *h, const fs2_tensor_desc *tensors, int32_t n, void *stream);
+
+/* forward pass (replaces FeedForwardTransformer._forward, reference fastspeech.py:169-243) */
+size_t fs2_token_workspace_bytes(const fs2_handle *h, const fs2_batch *batch);
+int fs2_encode(fs2_handle *h, void *stream, const fs2_encode_io *io);
+size_t fs2_frame_workspace_bytes(const fs2_handle *h, const fs2_batch *batch, const int64_t *olens_host);
+int fs2_decode(fs2_handle *h, void *stream, const fs2_decode_io *io);
+
+/* Per-kernel time of the last encode+decode pair when profiling is on (hipEvents around every launch).
+ * names/ms are filled up to `cap`; returns the number of records. */
+int fs2_set_profiling(fs2_handle *h, int32_t on);
+int fs2_get_profile(fs2_handle *h, const char **names, float *ms, double *flops, double *bytes, int32_t cap);
+
+/* ---- single operators, exported for per-kernel parity tests (all pointers device unless noted) ---- */
+
+/* y = epilogue(conv1d_k(x) or linear(x)); x:[R,C] rows packed with zero gap rows already in place;
+ * w: reference layout [N,C,k] (k=1: [N,C]); epilogue order: +bias, +resid, relu_pre, LayerNorm(eps),
+ * act_post (0 none,1 relu,2 tanh), dot with dot_w (+dot_b) -> dot_out[R].  row_valid[R] (int32, may be NULL)
+ * marks rows to be written as zeros when 0.  (reference modules.py:237-248, encoder.py:60-69) */
+typedef struct fs2_op_gemm_args {
+    int32_t R, C, N, ktaps, precision;
+    const float *x, *w, *bias, *resid;
+    int32_t relu_pre;
+    const float *ln_gamma, *ln_beta;
+    float ln_eps;
+    int32_t act_post;
+    const float *dot_w, *dot_b;
+    float *dot_out;
+    float *y;
+    const int32_t *row_valid;
+} fs2_op_gemm_args;
+int fs2_op_conv_gemm(void *stream, const fs2_op_gemm_args *a);
+
+/* scaled-dot-product self-attention over packed sequences: qkv [R, 3*D] (q | k | v, head-major inside
+ * each), ctx [R, D].  seq_start/len/klen: HOST [B].  Query rows >= klen produce zeros when mask_q.
+ * (reference core/attention.py:47-70) */
+int fs2_op_attention(void *stream, const float *qkv, float *ctx, int32_t D, int32_t heads, int32_t B,
+                     const int32_t *seq_start, const int32_t *seq_len, const int32_t *seq_klen,
+                     int32_t mask_q, int32_t precision);
+
+/* length regulator on a padded batch: hs [B,Tmax,D], ds [B,Tmax] (i64), ilens HOST [B] ->
+ * out [B,Lmax,D] (pads 0), index [B,Lmax] (-1 pads), olens device [B].  Lmax must be >= max olens.
+ * (reference length_regulator.py:38-95, utils/util.py:91-104) */
+int fs2_op_length_regulate(void *stream, const float *hs, const int64_t *ds, const int64_t *ilens_host,
+                           int32_t B, int32_t Tmax, int32_t D, int32_t Lmax, float *out, int32_t *index,
+                           int64_t *olens);
+
+/* idx[i] = bucketize(x[i], bins[nb]) (right=False, NaN -> nb)  (variance_predictor.py:158,231) */
+int fs2_op_bucketize(void *stream, const float *x, int64_t n, const float *bins, int32_t nb, int32_t *idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FS2_H_ */

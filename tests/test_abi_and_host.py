@@ -1,0 +1,115 @@
+"""CPU: the C-ABI library loads and exports every symbol include/fs2.h declares; host-side module logic
+(state-dict layout, error behaviour without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from fastspeech2_amd import _lib
+    return _lib.build()      # hipcc cross-compiles gfx950 without a GPU (no-op when up to date)
+
+
+def test_header_symbols_exported(libpath):
+    from fastspeech2_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "fs2.h")).read()
+    declared = sorted(set(re.findall(r"\b(fs2_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    L = ctypes.CDLL(libpath)
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(_lib.EXPORTS) == declared
+
+
+def test_struct_sizes_match_header():
+    """ctypes mirrors of the ABI structs: field counts as in the header (cheap drift detector)."""
+    from fastspeech2_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "fs2.h")).read()
+    body = re.search(r"typedef struct fs2_config \{(.*?)\} fs2_config;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    n = sum(len(decl.split(",")) for decl in re.findall(r"int32_t\s+([^;]+);", body))
+    assert n == len(_lib.Config._fields_)
+    assert ctypes.sizeof(_lib.Batch) == 24 and ctypes.sizeof(_lib.TensorDesc) == 56
+
+
+def test_create_without_gpu_fails_loudly(libpath):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from fastspeech2_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.Config(68, 80, 256, 2, 4, 1024, 384, 4, 1024, 9, 2, 256, 3, 2, 256, 3, 256, 5, 256, 5, 1, 1, 1, 0)
+    h = ctypes.c_void_p()
+    rc = L.fs2_create(ctypes.byref(cfg), ctypes.byref(h))
+    assert rc != 0 and b"no HIP device" in L.fs2_last_error(None)
+
+
+def _model():
+    from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
+    hp = default_hparams()
+    return FeedForwardTransformer(N_PHONEME_SYMBOLS, hp.audio.num_mels, hp), hp
+
+
+def test_state_dict_layout_matches_reference():
+    """Key names / shapes of SURVEY.md Appendix C (captured from the reference's state_dict())."""
+    model, _ = _model()
+    sd = model.state_dict()
+    assert len(sd) == 225
+    assert sum(p.numel() for p in model.parameters()) == 34015605
+    expect = {
+        "encoder.embed.0.weight": (68, 256), "encoder.embed.1.alpha": (), "encoder.embed.1.pe": (1, 5000, 256),
+        "encoder.after_norm.weight": (256,), "encoder.encoders_.3.self_attn.linear_q.weight": (256, 256),
+        "encoder.encoders_.0.feed_forward.w_1.weight": (1024, 256, 9), "encoder.encoders_.0.feed_forward.w_2.weight": (256, 1024, 1),
+        "encoder.encoders_.0.concat_linear.weight": (256, 512), "duration_predictor.conv.1.0.weight": (256, 256, 3),
+        "duration_predictor.conv.0.2.layer_norm.bias": (256,), "duration_predictor.linear.weight": (1, 256),
+        "energy_predictor.energy_bins": (255,), "energy_predictor.predictor.conv.0.0.weight": (256, 256, 3),
+        "pitch_predictor.pitch_bins": (255,), "pitch_embed.weight": (256, 256), "energy_embed.bias": (256,),
+        "decoder.embed.0.weight": (384, 256), "decoder.embed.1.bias": (384,), "decoder.embed.4.alpha": (),
+        "decoder.embed.4.pe": (1, 5000, 384), "decoder.encoders_.2.feed_forward.w_1.weight": (1024, 384, 9),
+        "decoder.encoders_.0.concat_linear.weight": (384, 768), "decoder.after_norm.bias": (384,),
+        "postnet.postnet.0.0.weight": (256, 80, 5), "postnet.postnet.4.0.weight": (80, 256, 5),
+        "postnet.postnet.2.1.running_var": (256,), "postnet.postnet.4.1.num_batches_tracked": (), "feat_out.weight": (80, 384),
+    }
+    for k, shp in expect.items():
+        assert k in sd and tuple(sd[k].shape) == shp, k
+    bins = sd["pitch_predictor.pitch_bins"]
+    assert abs(float(bins[0]) - 71.0) < 1e-4 and abs(float(bins[-1]) - 676.2261) < 1e-2
+    assert float(sd["encoder.embed.0.weight"][0].abs().max()) == 0.0      # padding_idx row
+
+
+def test_cpu_inputs_raise_not_fallback():
+    model, _ = _model()
+    model.eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.inference(torch.ones(5, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model._forward(torch.ones(1, 5, dtype=torch.int64), torch.tensor([5]), is_inference=True)
+
+
+def test_unsupported_configs_raise():
+    from fastspeech2_amd import FeedForwardTransformer
+    _, hp = _model()
+    hp.model.encoder_normalize_before = True
+    with pytest.raises(NotImplementedError):
+        FeedForwardTransformer(68, 80, hp)
+    hp.model.encoder_normalize_before = False
+    hp.model.positionwise_layer_type = "conv2d"
+    with pytest.raises(NotImplementedError):
+        FeedForwardTransformer(68, 80, hp)
+
+
+def test_portable_weights_are_deterministic():
+    from fastspeech2_amd.synthetic import portable_state_dict, make_batch
+    model, _ = _model()
+    a = portable_state_dict(model.state_dict(), 0)
+    b = portable_state_dict(model.state_dict(), 0)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert abs(float(a["feat_out.weight"].abs().max()) - 1 / 384 ** 0.5) < 1e-3
+    c3 = make_batch("c3")
+    assert c3["xs"].shape[0] == 64 and int(c3["olens"].sum()) > 30000
+    assert torch.equal(c3["ds"].sum(1), c3["olens"])

@@ -1,0 +1,178 @@
+"""Per-kernel parity tests through the C ABI (fs2_op_*), each against a plain fp32 PyTorch statement of
+the same reference op computed on the CPU.  Tolerances: fp32 kernels 2e-4 absolute on O(1) data (the
+MFMA fp32 chain and the CPU sum differ only in summation order); integer outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _rand(rs, *shape, scale=1.0):
+    return torch.from_numpy(rs.uniform(-scale, scale, size=shape).astype(np.float32))
+
+
+def _ref_conv(x, w, bias):
+    """x [R,C] one sequence, zero padded; w [N,C,k]."""
+    if w.dim() == 2:
+        return F.linear(x, w, bias)
+    k = w.shape[-1]
+    return F.conv1d(x.t().unsqueeze(0), w, bias, padding=(k - 1) // 2)[0].t()
+
+
+CASES = [
+    # R,   C,    N,    k, bias, resid, relu_pre, ln_eps, act, dot,  name
+    (200, 256, 256, 3, True, False, True, 1e-12, 0, True, "predictor conv + relu + LN + linear head"),
+    (333, 256, 256, 3, True, False, True, 1e-12, 0, False, "predictor conv layer 0"),
+    (300, 384, 1024, 9, True, False, False, None, 1, False, "decoder FFN conv k9 + relu (tile kernel)"),
+    (130, 1024, 384, 1, True, True, False, 1e-5, 0, False, "FFN w_2 + residual + LN (rows NT=24)"),
+    (257, 256, 256, 1, True, True, False, 1e-5, 0, False, "out-proj + residual + LN (rows NT=16)"),
+    (190, 256, 768, 1, True, False, False, None, 0, False, "QKV projection (tile kernel)"),
+    (210, 80, 256, 5, True, False, False, None, 2, False, "postnet layer 0: C=80 k5 tanh"),
+    (210, 256, 80, 5, True, True, False, None, 0, False, "postnet last: N=80 + residual (rows NT=5)"),
+    (100, 384, 80, 1, True, False, False, None, 0, False, "feat_out 384->80"),
+    (70, 256, 384, 1, True, False, False, 1e-5, 1, False, "decoder input layer Linear+LN+ReLU"),
+    (64, 256, 1024, 1, True, False, False, None, 1, False, "linear FFN (k=1) + relu, exact tile rows"),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[-1] for c in CASES])
+def test_conv_gemm(case):
+    from tests import ops_binding as ops
+    R, C, N, k, has_bias, has_res, relu_pre, ln_eps, act, has_dot, _ = case
+    rs = np.random.RandomState(R + C + N + k)
+    dev = _dev()
+    x = _rand(rs, R, C)
+    w = _rand(rs, N, C, k, scale=1.0 / np.sqrt(C * k)) if k > 1 else _rand(rs, N, C, scale=1.0 / np.sqrt(C))
+    bias = _rand(rs, N, scale=0.5) if has_bias else None
+    resid = _rand(rs, R, N) if has_res else None
+    g, bt = (1.0 + _rand(rs, N, scale=0.2), _rand(rs, N, scale=0.2)) if ln_eps is not None else (None, None)
+    dw, db = (_rand(rs, N, scale=0.1), _rand(rs, 1)) if has_dot else (None, None)
+    valid = torch.from_numpy((rs.uniform(size=R) > 0.1).astype(np.int32))
+    # reference
+    y = _ref_conv(x, w, bias)
+    if resid is not None:
+        y = y + resid
+    if relu_pre:
+        y = torch.relu(y)
+    if ln_eps is not None:
+        y = F.layer_norm(y, (N,), g, bt, ln_eps)
+    y = torch.relu(y) if act == 1 else (torch.tanh(y) if act == 2 else y)
+    d = (y @ dw + db) if has_dot else None
+    y = y * valid.unsqueeze(1)
+    to = lambda t: t.to(dev) if t is not None else None
+    yo, do = ops.conv_gemm(to(x), to(w), to(bias), to(resid), relu_pre, (to(g), to(bt)) if g is not None else None,
+                           ln_eps or 1e-5, act, (to(dw), to(db)) if has_dot else None, to(valid))
+    err = float((yo.cpu() - y).abs().max())
+    assert torch.isfinite(yo).all(), "non-finite / unwritten output"
+    assert err < 2e-4, "max-abs %g" % err
+    if has_dot:
+        derr = float(((do.cpu() - d) * valid).abs().max())
+        assert derr < 2e-4, "dot head max-abs %g" % derr
+
+
+def test_conv_gemm_transpose_detecting():
+    """A = identity-like with an ASYMMETRIC weight: catches a swapped C/D row<->col mapping."""
+    from tests import ops_binding as ops
+    dev = _dev()
+    R = C = N = 256
+    x = torch.eye(R)
+    w = torch.arange(N * C, dtype=torch.float32).view(N, C) / (N * C)
+    y, _ = ops.conv_gemm(x.to(dev), w.to(dev))
+    assert torch.allclose(y.cpu(), w.t(), atol=1e-6)
+
+
+@pytest.mark.parametrize("D,heads", [(256, 2), (384, 2)])
+@pytest.mark.parametrize("mask_q", [0, 1])
+def test_attention(D, heads, mask_q):
+    from tests import ops_binding as ops
+    dev = _dev()
+    rs = np.random.RandomState(D + mask_q)
+    lens = [70, 1, 33, 200, 64]
+    klens = [70, 1, 20, 150, 64] if mask_q else lens
+    starts, row = [], 8
+    for l in lens:
+        starts.append(row)
+        row += l + 8
+    qkv = _rand(rs, row, 3 * D, scale=2.0)
+    ctx = ops.attention(qkv.to(dev), D, heads, starts, lens, klens, mask_q).cpu()
+    dk = D // heads
+    worst = 0.0
+    for s, l, kl in zip(starts, lens, klens):
+        q, k, v = (qkv[s:s + l, i * D:(i + 1) * D].view(l, heads, dk).transpose(0, 1) for i in range(3))
+        sc = q @ k.transpose(1, 2) / np.sqrt(dk)
+        sc[:, :, kl:] = float("-inf")
+        a = torch.softmax(sc, dim=-1)
+        o = (a @ v).transpose(0, 1).reshape(l, D)
+        if mask_q:
+            o[kl:] = 0.0
+        worst = max(worst, float((ctx[s:s + l] - o).abs().max()))
+    assert worst < 2e-5, "max-abs %g" % worst
+
+
+def test_attention_spiked_key_forces_rescale():
+    """One key far above the others late in the sequence: exercises the online-softmax rescale branch."""
+    from tests import ops_binding as ops
+    dev = _dev()
+    rs = np.random.RandomState(5)
+    D, heads, l = 256, 2, 130
+    qkv = _rand(rs, l + 16, 3 * D, scale=0.5)
+    qkv[8 + 97, D:2 * D] = qkv[8 + 3, 0:D] * 40.0      # key 97 aligned with query 3
+    ctx = ops.attention(qkv.to(dev), D, heads, [8], [l], [l], 0).cpu()
+    dk = D // heads
+    q, k, v = (qkv[8:8 + l, i * D:(i + 1) * D].double().view(l, heads, dk).transpose(0, 1) for i in range(3))
+    o = (torch.softmax(q @ k.transpose(1, 2) / np.sqrt(dk), -1) @ v).transpose(0, 1).reshape(l, D)
+    assert float((ctx[8:8 + l].double() - o).abs().max()) < 2e-5
+
+
+def test_length_regulator_known_answers(golden_dir):
+    from tests import ops_binding as ops
+    dev = _dev()
+    g = np.load(golden_dir + "/g4_known_answers.npz")
+    hs, ds, il, want = (torch.from_numpy(g[k]) for k in ("lr_hs", "lr_ds", "lr_ilens", "lr_out"))
+    out, idx, olens = ops.length_regulate(hs.to(dev), ds.to(dev), il.tolist(), want.shape[1])
+    assert torch.equal(out.cpu(), want)          # bit-exact copy semantics
+    assert olens.cpu().tolist() == [7, 4, 2]     # all-zero row -> ones; zeros inside skipped
+    assert idx.cpu()[0].tolist() == [0, 1, 1, 2, 2, 2, 4]
+
+
+def test_length_regulator_random_bit_exact():
+    from tests import ops_binding as ops
+    from oracle import fs2_oracle as O
+    dev = _dev()
+    rs = np.random.RandomState(9)
+    B, Tmax, D = 9, 300, 256
+    il = rs.randint(1, Tmax + 1, size=B)
+    il[0] = Tmax
+    ds = torch.from_numpy(rs.randint(0, 12, size=(B, Tmax)).astype(np.int64))
+    ds[3, : il[3]] = 0                                    # all-zero utterance
+    hs = _rand(rs, B, Tmax, D)
+    want, olens, idxs = O.length_regulate(hs, ds, torch.from_numpy(il))
+    out, idx, ol = ops.length_regulate(hs.to(dev), ds.to(dev), il.tolist(), want.shape[1] + 5)
+    assert torch.equal(ol.cpu(), olens)
+    assert torch.equal(out.cpu()[:, : want.shape[1]], want)
+    assert float(out.cpu()[:, want.shape[1]:].abs().max()) == 0.0
+    for b in range(B):
+        assert torch.equal(idx[b, : olens[b]].cpu().long(), idxs[b])
+        assert (idx[b, olens[b]:] == -1).all()
+
+
+def test_bucketize(golden_dir):
+    from tests import ops_binding as ops
+    dev = _dev()
+    g = np.load(golden_dir + "/g4_known_answers.npz")
+    for xk, qk, bk in (("xe", "qe", "energy_bins"), ("xp", "qp", "pitch_bins")):
+        got = ops.bucketize(torch.from_numpy(g[xk]).to(dev), torch.from_numpy(g[bk]).to(dev)).cpu().long()
+        assert got.tolist() == g[qk].tolist()
+    rs = np.random.RandomState(3)
+    bins = torch.from_numpy(g["pitch_bins"])
+    x = torch.from_numpy(rs.uniform(0, 800, size=100000).astype(np.float32))
+    x[::7] = bins[rs.randint(0, 255, size=x[::7].numel())]     # exact boundary hits
+    got = ops.bucketize(x.to(dev), bins.to(dev)).cpu().long()
+    assert torch.equal(got, torch.bucketize(x, bins))

@@ -1,0 +1,88 @@
+"""CPU: the oracle restatement replayed against the golden vectors captured from the real reference
+(oracle/gen_golden.py).  This is what pins the oracle on machines where /root/reference is absent."""
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.fixture(scope="module")
+def env():
+    from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
+    from fastspeech2_amd.synthetic import portable_state_dict
+    from oracle import fs2_oracle as O
+    hp = default_hparams()
+    model = FeedForwardTransformer(N_PHONEME_SYMBOLS, hp.audio.num_mels, hp)
+    sd = portable_state_dict(model.state_dict(), seed=0)
+    return sd, O.config_from_hp(hp, N_PHONEME_SYMBOLS, hp.audio.num_mels), O
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+TOL = 2e-5   # same torch ops on a possibly different CPU/BLAS build: summation-order noise only
+
+
+def test_g1(env, golden_dir):
+    sd, cfg, O = env
+    g = np.load(golden_dir + "/g1_teacher_b1.npz")
+    o = O.padded_forward(sd, cfg, _t(g["xs"]), _t(g["ilens"]), _t(g["olens"]), _t(g["ds"]), _t(g["es"]), _t(g["ps"]))
+    for k in ("before", "after", "d_outs", "e_outs", "p_outs", "encoder_out"):
+        assert float((o[k] - _t(g[k])).abs().max()) <= TOL, k
+    assert o["lr_index"][0].tolist() == g["lr_index"].tolist()
+    assert o["qe"].tolist() == g["qe"].tolist() and o["qp"].tolist() == g["qp"].tolist()
+    rows = _t(g["decoder_rows"])
+    assert float((o["decoder_out"][0][rows] - _t(g["decoder_out_rows"])).abs().max()) <= TOL
+
+
+def test_g2_and_losses(env, golden_dir):
+    sd, cfg, O = env
+    g = np.load(golden_dir + "/g2_teacher_padded_b3.npz")
+    o = O.padded_forward(sd, cfg, _t(g["xs"]), _t(g["ilens"]), _t(g["olens"]), _t(g["ds"]), _t(g["es"]), _t(g["ps"]))
+    for k in ("before", "after", "d_outs", "e_outs", "p_outs"):
+        assert float((o[k] - _t(g[k])).abs().max()) <= TOL, k
+    loss, rep = O.loss_report(o, _t(g["ys"]), _t(g["ilens"]), _t(g["olens"]), _t(g["ds"]), _t(g["es"]), _t(g["ps"]))
+    assert [list(d.keys())[0] for d in rep] == g["report_names"].tolist()
+    assert np.allclose([list(d.values())[0] for d in rep], g["report_values"], rtol=1e-5)
+
+
+def test_g6_per_utterance(env, golden_dir):
+    sd, cfg, O = env
+    g2 = np.load(golden_dir + "/g2_teacher_padded_b3.npz")
+    g6 = np.load(golden_dir + "/g6_teacher_per_utt_b3.npz")
+    o = O.per_utterance_forward(sd, cfg, _t(g2["xs"]), _t(g2["ilens"]), _t(g2["ds"]), _t(g2["es"]), _t(g2["ps"]))
+    for b in range(3):
+        L = int(g2["olens"][b])
+        assert float((o["after"][b, :L] - _t(g6["after_%d" % b])).abs().max()) <= TOL
+        assert float(o["after"][b, L:].abs().max() if L < o["after"].shape[1] else 0) == 0
+
+
+def test_g3_inference(env, golden_dir):
+    sd, cfg, O = env
+    from fastspeech2_amd.synthetic import bias_durations
+    g = np.load(golden_dir + "/g3_inference_t24.npz")
+    o = O.padded_forward(bias_durations(sd, 4.0), cfg, _t(g["x"]).unsqueeze(0), torch.tensor([24]), is_inference=True)
+    assert o["d_outs"][0].tolist() == g["d_outs"][0].tolist()
+    assert float((o["after"][0] - _t(g["mel"])).abs().max()) <= TOL
+
+
+def test_g4_known_answers(env, golden_dir):
+    sd, cfg, O = env
+    g = np.load(golden_dir + "/g4_known_answers.npz")
+    assert O.bucketize(_t(g["xe"]), _t(g["energy_bins"])).tolist() == g["qe"].tolist()
+    assert O.bucketize(_t(g["xp"]), _t(g["pitch_bins"])).tolist() == g["qp"].tolist()
+    assert g["qe"][0] == 0 and g["qe"][5] == 255 and g["qe"][6] == 255          # below range, above range, NaN
+    assert O.duration_from_log(_t(g["dur_log"])).tolist() == g["dur_int"].tolist()
+    assert g["dur_int"].tolist()[:6] == [0, 0, 0, 2, 2, 4]                     # round half to even: .5->0, 1.5->2, 2.5->2, 3.5->4
+    out, olens, idx = O.length_regulate(_t(g["lr_hs"]), _t(g["lr_ds"]), _t(g["lr_ilens"]))
+    assert torch.equal(out, _t(g["lr_out"])) and olens.tolist() == [7, 4, 2]
+    assert torch.equal(~O._len_mask([5, 3, 2], 5), _t(g["pad_mask_5_3_2"]).bool())
+    rows = g["pe_rows"].tolist()
+    assert float((O.positional_table(5000, 256)[rows] - _t(g["pe256"])).abs().max()) <= 1e-6
+    assert float((O.positional_table(5000, 384)[rows] - _t(g["pe384"])).abs().max()) <= 1e-6
+    valid = O._len_mask([6, 3], 6)
+    att = O._mha(sd, "encoder.encoders_.0.self_attn", _t(g["attn_x"]), valid.unsqueeze(-2) & valid.unsqueeze(-1), 2)
+    assert float((att - _t(g["attn_out"])).abs().max()) <= TOL
+    # fully masked query rows -> linear_out.bias   
+    bo = sd["encoder.encoders_.0.self_attn.linear_out.bias"]
+    assert float((att[1, 3:] - bo).abs().max()) <= 1e-6
