@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X FastSpeech2 mel-generation path (BASELINE.json metric: mel-frames/sec).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one full free-running forward of the hot path over one synthetic batch already resident in
+HBM: phoneme ids -> encoder -> duration predictor -> length regulator -> pitch/energy -> decoder -> mel
+projection -> Postnet -> padded mels (and, for N > 1, the RCCL all-gather of the mels over xGMI).
+Workload at every N: BASELINE config c3 per GPU ("batch=64 LJSpeech-shape", the config the >=50x-CPU
+target is quoted on), i.e. weak scaling: rank r synthesises its own 64 utterances and all ranks end up
+with all 64*N mels.  Random-init default model (portable generator, seed 0) with the duration bias set
+so that predicted durations are LJSpeech-like; there is no network for real
+checkpoints or datasets.  value = valid mel frames of all ranks / max-over-ranks wall time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
+DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3", "bf16": "bf16"}
+
+
+def cpu_baseline(sd, cfg, batch, gpu_after, budget_s=14.0):
+    """Times the CPU oracle (the validated port of the reference's fp32 PyTorch path) on the host cores,
+    on a bounded sample of the same batch: (i) per-utterance loop of B=1 calls, (ii) one padded batch of
+    16 utterances; returns the faster in mel-frames/s plus the measured mel max-abs diff GPU vs oracle."""
+    from oracle import fs2_oracle as O
+    xs, il, ds = batch["xs"], batch["ilens"], batch["ds_pred"]
+    B = xs.shape[0]
+    # Pick the thread count that is fastest for this op mix (small GEMM/conv calls: all logical cores of a
+    # 2-socket host oversubscribe badly), so that the CPU side is not handicapped.
+    one = lambda: O.padded_forward(sd, cfg, xs[:1, : int(il[0])], il[:1], is_inference=True, d_override=ds[:1, : int(il[0])])
+    ncpu = os.cpu_count() or 1
+    best_t, best_dt = 1, float("inf")
+    for nt in sorted({t for t in (4, 8, 16, 32, 64, ncpu // 2, ncpu) if 1 <= t <= ncpu}):
+        torch.set_num_threads(nt)
+        one()
+        t0 = time.perf_counter()
+        one()
+        dt_ = time.perf_counter() - t0
+        if dt_ < best_dt:
+            best_t, best_dt = nt, dt_
+        if dt_ > 4 * best_dt:
+            break
+    torch.set_num_threads(best_t)
+    frames, t0, n, worst = 0, time.perf_counter(), 0, 0.0
+    for b in range(B):
+        T = int(il[b])
+        o = O.padded_forward(sd, cfg, xs[b:b + 1, :T], il[b:b + 1], is_inference=True, d_override=ds[b:b + 1, :T])
+        L = int(o["olens"][0])
+        frames += L
+        n += 1
+        worst = max(worst, float((o["after"][0] - gpu_after[b, :L]).abs().max()))
+        if time.perf_counter() - t0 > budget_s:
+            break
+    per_utt = frames / (time.perf_counter() - t0)
+    nb = min(16, B)
+    Tm = int(il[:nb].max())
+    t1 = time.perf_counter()
+    o = O.padded_forward(sd, cfg, xs[:nb, :Tm], il[:nb], is_inference=True, d_override=ds[:nb, :Tm])
+    padded = int(o["olens"].sum()) / (time.perf_counter() - t1)
+    best = max(per_utt, padded)
+    return dict(value=round(best, 1), unit="mel-frames/s", cores=torch.get_num_threads(), kind="port",
+                sample="oracle (validated fp32 PyTorch port of the reference path) on the c3 batch: per-utterance loop over the "
+                       "first %d utterances (%d frames) = %.0f fr/s; one padded batch of %d = %.0f fr/s; faster quoted" %
+                       (n, frames, per_utt, nb, padded)), worst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--precision", default=os.environ.get("FS2_PRECISION", "fp32"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-kernels", action="store_true", help="print the per-kernel hipEvent table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
+    from fastspeech2_amd.parallel import gather_mels
+    from fastspeech2_amd.synthetic import portable_state_dict, bias_durations, make_batch
+
+    hp = default_hparams()
+    odim = hp.audio.num_mels
+    model = FeedForwardTransformer(N_PHONEME_SYMBOLS, odim, hp).eval()
+    sd = bias_durations(portable_state_dict(model.state_dict(), seed=0))
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    model.precision = args.precision
+
+    seed0 = {"c1": 1, "c2": 2, "c3": 3, "c4": 4, "c5": 5}[args.workload]
+    batch = make_batch(args.workload, seed=seed0 + 101 * rank)
+    xs, il = batch["xs"].to(dev), batch["ilens"]
+    B = xs.shape[0]
+    index = list(range(rank * B, (rank + 1) * B))
+
+    def step():
+        mel, olens = model.inference_batch(xs, il)
+        if world > 1:
+            mel, olens = gather_mels(mel, olens, index, B * world)
+        return mel, olens
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            mel, olens_all = step()
+        local_frames = int(model.last_olens.sum())
+        total_frames = int(olens_all.sum())
+        model.set_profiling(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mel, olens_all = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        prof = model.get_profile()
+        model.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel table (hipEvents on the launch stream, accumulated over the timed steps) ----
+    agg = {}
+    for name, ms, fl, by in prof:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += ms
+        a[2] += fl
+    dom = max(agg.items(), key=lambda kv: kv[1][1])
+    dom_name, (dom_n, dom_ms, _) = dom
+    c = model._cfg
+    # algorithmic FLOPs per launch of the dominant kernel, valid frames/tokens only
+    ntok = int(il.sum())
+    per_row = {"dec.ffn1": 2.0 * c["ffn_kernel"] * c["ddim"] * c["dunits"], "enc.ffn1": 2.0 * c["ffn_kernel"] * c["adim"] * c["eunits"],
+               "dec.ffn2_ln": 2.0 * c["dunits"] * c["ddim"], "dec.qkv": 6.0 * c["ddim"] ** 2, "dec.out_ln": 2.0 * c["ddim"] ** 2}
+    rows = ntok if dom_name.startswith("enc") or dom_name.startswith("dur") else local_frames
+    if dom_name in per_row:
+        algo = per_row[dom_name] * rows
+    else:   # fall back to the launch's own count (includes the ~1.5 % gap rows)
+        algo = sum(fl for n_, ms, fl, by in prof if n_ == dom_name) / dom_n
+    avg_ms = dom_ms / dom_n
+    achieved = algo / (avg_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.precision]
+    roofline = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
+                    frac=round(achieved / peak, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
+                    share_of_kernel_time=round(dom_ms / sum(v[1] for v in agg.values()), 3))
+    if args.profile_kernels and rank == 0:
+        tot = sum(v[1] for v in agg.values())
+        for name, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print("%-14s launches %4d  avg %8.3f ms  %5.1f %%  %7.1f TFLOP/s" % (name, n, ms / n, 100 * ms / tot, fl / max(ms, 1e-9) / 1e9),
+                  file=sys.stderr)
+
+    if rank == 0:
+        from oracle import fs2_oracle as O
+        line = {
+            "metric": "mel-frames/sec", "value": round(total_frames * args.steps / dt, 1), "unit": "mel-frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[args.precision],
+            "data": "synthetic",
+            "config": {"workload": "%s: batch=%d LJSpeech-shape per GPU, default.yaml dims, free-running, random-init weights (seed 0), "
+                                   "duration bias ln(1+7.87)" % (args.workload, B),
+                       "utterances_per_gpu": B, "valid_frames_per_step": total_frames, "phonemes_per_gpu": ntok,
+                       "algorithmic_gflop_per_step_per_gpu": round(sum(O.flops(int(t), int(l)) for t, l in zip(il, model.last_olens)) / 1e9, 1),
+                       "parallelism": "utterance-sharded x%d, all-gather(mels) over RCCL" % world if world > 1 else "single GPU"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cfg = O.config_from_hp(hp, N_PHONEME_SYMBOLS, odim)
+            with torch.no_grad():
+                d_pred = model._run(xs, il, is_inference=True, want=("after",))["d_int"].cpu()
+            cb, worst = cpu_baseline(sd, cfg, dict(xs=batch["xs"], ilens=il, ds_pred=d_pred), mel.cpu())
+            line["cpu_baseline"] = cb
+            line["vs_cpu"] = round(line["value"] / cb["value"], 1)
+            line["mel_max_abs_diff"] = worst
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -41,6 +41,8 @@ struct GemmArgs {
     const float* pe; int pe_ld; const float* pe_alpha; float x_scale;  // v = v*x_scale + alpha*pe[pos] if pe
     const float* dot_w; const float* dot_b; float* dot_out;            // dot_out[row] = v . dot_w + dot_b
     float* Y; int ldy;                     // output [R, ldy] or nullptr
+    const void* Wb;                        // split-bf16 weight image (gemm_bf16.h) or nullptr
+    float* scratch;                        // [R, N] scratch for two-pass epilogues when Y == nullptr
 };
 
 __device__ __forceinline__ float wave16_sum(float v) {

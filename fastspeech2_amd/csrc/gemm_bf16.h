@@ -1,0 +1,294 @@
+// bf16 / split-bf16 ("bf16x3") conv-as-GEMM on v_mfma_f32_16x16x32_bf16 (gfx950, 2.5 PFLOP/s dense peak).
+//
+// Same contraction as gemm_f32.h:  Y[m,n] = epi( sum_{tap,c} X[m+tap-P, c] * W[n,tap,c] ), fp32 in HBM on both
+// sides.  Plain bf16 misses the 1e-3 mel tolerance by 20x, so the parity mode splits every
+// operand x = hi + lo (hi = bf16(x), lo = bf16(x - hi), ~16 mantissa bits) and issues three MFMAs per fragment
+// pair, hi*hi + hi*lo + lo*hi, accumulating in fp32 (NSPLIT = 3).  NSPLIT = 1 is plain bf16.
+//   * weights are split once at load time into the exact LDS image: [Npad][tap][chunk][hi k0..31 | lo k0..31]
+//     (128 B per (n, tap, chunk));
+//   * activations stay fp32 in HBM and are split in registers while they are staged into LDS
+//     (v_cvt_pk_bf16_f32: ~3 VALU ops per element, amortised over the 9 taps of the FFN conv).
+// Tile: 128 x 128 outputs per workgroup, 4 waves as 2(M) x 2(N), 64 x 64 per wave (4 x 4 MFMA tiles, 64
+// accumulator registers); ~50 KB LDS and <= 168 VGPRs so that three workgroups share a CU and one's staging
+// / barrier phases overlap the others' MFMAs.  One k-step = 32 channels of one tap: 16 fragment pairs x
+// NSPLIT MFMAs per wave, ONE barrier per k-step: the B tile is double-buffered in LDS (step it+1's tile is
+// written right after the barrier that ends step it-1, its global load having been issued a whole step
+// earlier), the A tile (128 + halo rows) is staged once per 32-channel chunk and shared by all taps (tap t
+// reads it shifted by t rows), its successor prefetched into registers during the chunk's last tap.
+// LDS image (both operands): row r = 128 B = 8 slots of 16 B (slots 0-3: hi k 0-7 .. 24-31, slots 4-7: lo),
+// physical slot = slot ^ ((r >> 1) & 7): the 16 rows touched by one ds_read_b128 lane group land on 16
+// distinct 16-B bank slots (conflict-free), writes are 16 B per lane.
+// MFMA operands: lane l supplies A[i = l&15][k = 8*(l>>4) .. +7] and B[k = 8*(l>>4) .. +7][j = l&15];
+// C/D: col = l&15, row = 4*(l>>4) + reg (same as the fp32 kernels, so the epilogue is shared).
+// grid.x walks the N tiles (fastest) so that the workgroups resident on one XCD (block id % 8) keep re-reading
+// the same weight panel from that XCD's L2.
+#pragma once
+#include "common.h"
+
+namespace fs2 {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int kB16BM = 128, kB16BN = 128;
+constexpr int kB16ARows = kB16BM + kMaxHalo;
+constexpr size_t kB16Lds = (size_t)kB16ARows * 128 + 2 * (size_t)kB16BN * 128;   // A + double-buffered B = 50 KB
+
+struct SplitPair { uint4 hi, lo; };
+
+// 8 consecutive fp32 -> (hi bf16 x8, lo bf16 x8)
+__device__ __forceinline__ SplitPair split8(const float4& p, const float4& q) {
+    const float v[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+    bf16x8_t h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 hb = (__bf16)v[i];
+        h[i] = hb;
+        l[i] = (__bf16)(v[i] - (float)hb);
+    }
+    SplitPair s;
+    s.hi = *reinterpret_cast<uint4*>(&h);
+    s.lo = *reinterpret_cast<uint4*>(&l);
+    return s;
+}
+
+__device__ __forceinline__ int swz(int row, int slot) { return (row << 7) + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <int NSPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_tile_bf16(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    char* As = smem_b;
+    char* Bs0 = smem_b + kB16ARows * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * kB16BN, m0 = blockIdx.y * kB16BM;
+    const int P = (a.ktaps - 1) >> 1;
+    const int lr = lane & 15, lg = lane >> 4;
+    const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = a.Cpad / 32;
+    const int niter = nchunks * a.ktaps;
+    const int a_items = (kB16BM + 2 * P) * 4;     // (row, k-group of 8) pairs of the A tile
+    // Staging registers are named scalars (an indexed array here ends up in scratch memory).
+    float4 ap0, aq0, ap1, aq1, ap2, aq2;
+    uint4 b0, b1, b2, b3;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+#define FS2_GLOAD_A1(i, P_, Q_)                                                                   \
+    {                                                                                             \
+        const int idx = tid + (i) * 256;                                                          \
+        const int r = idx >> 2, g = idx & 3;                                                      \
+        const int row = m0 - P + r, c = ch_ * 32 + g * 8;                                         \
+        P_ = z4; Q_ = z4;                                                                         \
+        if (idx < a_items && row >= 0 && row < a.R && c < a.C) {                                  \
+            const float* src = a.X + (size_t)row * a.ldx + c;                                     \
+            P_ = *reinterpret_cast<const float4*>(src);                                           \
+            Q_ = *reinterpret_cast<const float4*>(src + 4);                                       \
+        }                                                                                         \
+    }
+#define FS2_GLOAD_A(chunk_) { const int ch_ = (chunk_); FS2_GLOAD_A1(0, ap0, aq0) FS2_GLOAD_A1(1, ap1, aq1) FS2_GLOAD_A1(2, ap2, aq2) }
+#define FS2_STORE_A1(i, P_, Q_)                                                                   \
+    {                                                                                             \
+        const int idx = tid + (i) * 256;                                                          \
+        if (idx < a_items) {                                                                      \
+            const int r = idx >> 2, g = idx & 3;                                                  \
+            const SplitPair sp = split8(P_, Q_);                                                  \
+            *reinterpret_cast<uint4*>(As + swz(r, g)) = sp.hi;                                    \
+            *reinterpret_cast<uint4*>(As + swz(r, 4 + g)) = sp.lo;                                \
+        }                                                                                         \
+    }
+#define FS2_STORE_A() { FS2_STORE_A1(0, ap0, aq0) FS2_STORE_A1(1, ap1, aq1) FS2_STORE_A1(2, ap2, aq2) }
+#define FS2_GLOAD_B1(i, V_)                                                                       \
+    {                                                                                             \
+        const int idx = tid + (i) * 256;                                                          \
+        V_ = *reinterpret_cast<const uint4*>(wsrc_ + (size_t)(idx >> 3) * wrow_ + (idx & 7) * 8); \
+    }
+#define FS2_GLOAD_B(it_)                                                                          \
+    {                                                                                             \
+        const int c_ = (it_) / a.ktaps, t_ = (it_) - c_ * a.ktaps;                                \
+        const size_t wrow_ = (size_t)a.ktaps * nchunks * 64;                                      \
+        const __bf16* wsrc_ = Wb + ((size_t)n0 * a.ktaps + t_) * nchunks * 64 + (size_t)c_ * 64;  \
+        FS2_GLOAD_B1(0, b0) FS2_GLOAD_B1(1, b1) FS2_GLOAD_B1(2, b2) FS2_GLOAD_B1(3, b3)           \
+    }
+#define FS2_STORE_B1(i, V_) { const int idx = tid + (i) * 256; *reinterpret_cast<uint4*>(bs_ + swz(idx >> 3, idx & 7)) = V_; }
+#define FS2_STORE_B(buf_) { char* bs_ = Bs0 + (buf_) * (kB16BN * 128); FS2_STORE_B1(0, b0) FS2_STORE_B1(1, b1) FS2_STORE_B1(2, b2) FS2_STORE_B1(3, b3) }
+
+    // prologue: A(chunk 0) and B(0) staged, B(1) in flight
+    FS2_GLOAD_A(0)
+    FS2_GLOAD_B(0)
+    FS2_STORE_A()
+    FS2_STORE_B(0)
+    if (niter > 1) FS2_GLOAD_B(1)
+    for (int it = 0; it < niter; ++it) {
+        const int chunk = it / a.ktaps, tap = it - chunk * a.ktaps;
+        const bool last_tap = (tap == a.ktaps - 1) && (it + 1 < niter);
+        __syncthreads();   // B(it) [and A(chunk) when tap == 0] visible; every wave is done with step it-1
+        if (it + 1 < niter) {
+            FS2_STORE_B((it + 1) & 1)              // buffer last read in step it-1
+            if (it + 2 < niter) FS2_GLOAD_B(it + 2)
+        }
+        if (last_tap) FS2_GLOAD_A(chunk + 1)       // lands while this step's MFMAs run
+        const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
+        bf16x8_t ah[4], al[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int r = wm * 64 + mt * 16 + lr + tap;
+            ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
+            if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = wn * 64 + nt * 16 + lr;
+            const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
+            bf16x8_t bl;
+            if (NSPLIT == 3) bl = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
+            // consecutive MFMAs hit different accumulators (dependency distance 4)
+            if (NSPLIT == 3) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+        }
+        if (last_tap) {
+            __syncthreads();   // all waves finished reading this chunk's A tile
+            FS2_STORE_A()
+        }
+    }
+#undef FS2_GLOAD_A1
+#undef FS2_GLOAD_A
+#undef FS2_STORE_A1
+#undef FS2_STORE_A
+#undef FS2_GLOAD_B1
+#undef FS2_GLOAD_B
+#undef FS2_STORE_B1
+#undef FS2_STORE_B
+    // epilogue (elementwise): bias, residual, activation, gap rows -> 0
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm * 64 + mt * 16 + lg * 4 + r;
+            if (row >= a.R) continue;
+            const bool valid = a.row_pos == nullptr || a.row_pos[row] >= 0;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int col = n0 + wn * 64 + nt * 16 + lr;
+                if (col >= a.N) continue;
+                float v = acc[mt][nt][r];
+                if (a.bias) v += a.bias[col];
+                if (a.resid) v += a.resid[(size_t)row * a.ldr + col];
+                if (a.relu_pre) v = fmaxf(v, 0.f);
+                v = apply_act(v, a.act_post);
+                a.Y[(size_t)row * a.ldy + col] = valid ? v : 0.f;
+            }
+        }
+}
+
+// Row epilogue as its own HBM-bound kernel (used after gemm_tile_bf16 when the op ends in a LayerNorm, a
+// positional-encoding add or the scalar head): in place on Y [R, N], one wavefront per row, N <= 1024.
+//   v = LN(y) (if ln_g) -> act_post -> v*x_scale + alpha*pe[pos] -> store; dot_out[row] = v . dot_w + dot_b
+__global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= a.R) return;
+    const int pos = a.row_pos ? a.row_pos[row] : 0;
+    float* y = a.Y + (size_t)row * a.ldy;
+    if (pos < 0) {
+        for (int c = lane * 4; c < a.N; c += 256) *reinterpret_cast<float4*>(y + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.dot_w && lane == 0) a.dot_out[row] = 0.f;
+        return;
+    }
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane * 4 + j * 256;
+        v[j] = (c < a.N) ? *reinterpret_cast<const float4*>(y + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    if (a.ln_g) {
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)a.N;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = lane * 4 + j * 256;
+            if (c < a.N) {
+                const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
+                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.f / sqrtf(q / (float)a.N + a.ln_eps);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = lane * 4 + j * 256;
+            if (c < a.N) {
+                const float4 g = *reinterpret_cast<const float4*>(a.ln_g + c);
+                const float4 b = *reinterpret_cast<const float4*>(a.ln_b + c);
+                v[j].x = (v[j].x - mean) * rstd * g.x + b.x;
+                v[j].y = (v[j].y - mean) * rstd * g.y + b.y;
+                v[j].z = (v[j].z - mean) * rstd * g.z + b.z;
+                v[j].w = (v[j].w - mean) * rstd * g.w + b.w;
+            }
+        }
+    }
+    const float alpha = (a.pe && a.pe_alpha) ? a.pe_alpha[0] : 1.f;
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane * 4 + j * 256;
+        if (c < a.N) {
+            float4 t = v[j];
+            t.x = apply_act(t.x, a.act_post); t.y = apply_act(t.y, a.act_post);
+            t.z = apply_act(t.z, a.act_post); t.w = apply_act(t.w, a.act_post);
+            if (a.pe) {
+                const float4 p = *reinterpret_cast<const float4*>(a.pe + (size_t)pos * a.pe_ld + c);
+                t.x = t.x * a.x_scale + alpha * p.x; t.y = t.y * a.x_scale + alpha * p.y;
+                t.z = t.z * a.x_scale + alpha * p.z; t.w = t.w * a.x_scale + alpha * p.w;
+            }
+            if (a.dot_w) {
+                const float4 w = *reinterpret_cast<const float4*>(a.dot_w + c);
+                d += (t.x * w.x + t.y * w.y) + (t.z * w.z + t.w * w.w);
+            }
+            *reinterpret_cast<float4*>(y + c) = t;
+        }
+    }
+    if (a.dot_w) {
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        if (lane == 0) a.dot_out[row] = d + (a.dot_b ? a.dot_b[0] : 0.f);
+    }
+}
+
+// weights [N][C][k] fp32 -> split bf16 LDS image [Npad][k][nchunks][hi 32 | lo 32]; optional BatchNorm fold.
+__global__ void repack_weight_bf16(const float* w, int N, int C, int k, int Npad, int nchunks, const float* bn_g,
+                                   const float* bn_v, float bn_eps, __bf16* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)Npad * k * nchunks * 32;
+    if (i >= total) return;
+    const int kk = (int)(i & 31);
+    const int chunk = (int)((i >> 5) % nchunks);
+    const int tap = (int)((i / ((int64_t)32 * nchunks)) % k);
+    const int n = (int)(i / ((int64_t)32 * nchunks * k));
+    const int c = chunk * 32 + kk;
+    float v = 0.f;
+    if (n < N && c < C) {
+        v = w[((size_t)n * C + c) * k + tap];
+        if (bn_g) v *= bn_g[n] / sqrtf(bn_v[n] + bn_eps);
+    }
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    const size_t base = (((size_t)n * k + tap) * nchunks + chunk) * 64;
+    out[base + kk] = hi;
+    out[base + 32 + kk] = lo;
+}
+
+}  // namespace fs2

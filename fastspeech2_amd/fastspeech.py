@@ -461,3 +461,27 @@ class FeedForwardTransformer(nn.Module):
         m = torch.arange(int(il.max()), device=il.device).unsqueeze(0) < il.unsqueeze(1)
         m = m.to(self.feat_out.weight.device)
         return m.unsqueeze(-2) & m.unsqueeze(-1)
+
+
+def _profile_methods():
+    def set_profiling(self, on=True):
+        """hipEvent timing of every kernel launch on the caller's stream (fs2_set_profiling)."""
+        if self._handle is None:
+            raise RuntimeError("run one forward before enabling profiling (the handle is created lazily)")
+        _lib.check(_lib.lib().fs2_set_profiling(self._handle, int(bool(on))), self._handle)
+
+    def get_profile(self, cap=65536):
+        """-> list of (name, ms, flops, bytes) per launch since set_profiling(True)."""
+        L = _lib.lib()
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        fl = (C.c_double * cap)()
+        by = (C.c_double * cap)()
+        n = L.fs2_get_profile(self._handle, names, ms, fl, by, cap)
+        return [(names[i].decode(), float(ms[i]), float(fl[i]), float(by[i])) for i in range(n)]
+
+    FeedForwardTransformer.set_profiling = set_profiling
+    FeedForwardTransformer.get_profile = get_profile
+
+
+_profile_methods()

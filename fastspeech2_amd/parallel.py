@@ -1,0 +1,96 @@
+"""Utterance sharding across the GPUs of one node + the single collective of the path.
+
+The reference has no distributed code at all.  Utterances never interact
+(per-utterance semantics), weights are small (~130 MB) and replicated, so the path shards by independent
+units: every rank holds the (tiny) id batch, takes a cost-balanced subset of the utterances, runs the
+single-GPU path on it, and the only exchange is an all-gather of the final mels over RCCL/xGMI (backend
+"nccl" on ROCm; "gloo" in the CPU tests).  Results are bit-identical to the single-GPU result because
+per-utterance outputs do not depend on batch-mates.
+"""
+import torch
+import torch.distributed as dist
+
+
+def utterance_cost(T, frames_per_token=7.87):
+    """Relative cost model of one utterance from its phoneme count (SURVEY.md section 8d FLOPs formula with
+    L ~= 7.87 T): dominated by the decoder, 40.4 MFLOP/frame + 6144 L^2 attention."""
+    L = frames_per_token * float(T)
+    return T * (23855616.0 + 4096.0 * T) + L * (40383488.0 + 6144.0 * L)
+
+
+def shard_indices(ilens, world_size, costs=None):
+    """Longest-processing-time-first assignment.  Returns a list (one per rank) of utterance indices,
+    each sorted ascending; deterministic, identical on every rank."""
+    ilens = [int(t) for t in ilens]
+    costs = [utterance_cost(t) for t in ilens] if costs is None else [float(c) for c in costs]
+    order = sorted(range(len(ilens)), key=lambda i: (-costs[i], i))
+    load = [0.0] * world_size
+    parts = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        parts[r].append(i)
+        load[r] += costs[i]
+    return [sorted(p) for p in parts]
+
+
+def gather_mels(mel_local, olens_local, index_local, total, group=None):
+    """All-gather the ragged per-rank mel batches and restore the original utterance order.
+
+    mel_local [b, L_local, odim] (pads zero), olens_local [b] (host or device), index_local: the global
+    utterance index of each local row.  Returns (mels [total, Lmax, odim] on mel_local's device, olens
+    [total] int64 on the host).  Two collectives: a tiny one for (count, Lmax, olens, index) metadata and
+    one equal-count all_gather_into_tensor of the mels padded to the global (bmax, Lmax)."""
+    world = dist.get_world_size(group)
+    dev = mel_local.device
+    odim = mel_local.shape[-1]
+    b = mel_local.shape[0]
+    cap = (total + world - 1) // world + total          # generous upper bound on any rank's share
+    meta = torch.full((2 + 2 * cap,), -1, dtype=torch.int64, device=dev)
+    meta[0], meta[1] = b, mel_local.shape[1]
+    meta[2:2 + b] = torch.as_tensor(olens_local, dtype=torch.int64).to(dev)
+    meta[2 + cap:2 + cap + b] = torch.as_tensor(index_local, dtype=torch.int64).to(dev)
+    metas = torch.empty(world * meta.numel(), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(metas, meta, group=group)
+    metas = metas.view(world, -1).cpu()
+    bmax = int(metas[:, 0].max())
+    Lmax = int(metas[:, 2:2 + cap].max())
+    send = mel_local.new_zeros(bmax, Lmax, odim)
+    send[:b, : mel_local.shape[1]] = mel_local
+    recv = mel_local.new_empty(world * bmax, Lmax, odim)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(world, bmax, Lmax, odim)
+    out = mel_local.new_zeros(total, Lmax, odim)
+    olens = torch.zeros(total, dtype=torch.int64)
+    for r in range(world):
+        n = int(metas[r, 0])
+        idx = metas[r, 2 + cap:2 + cap + n]
+        out[idx.to(dev)] = recv[r, :n]
+        olens[idx] = metas[r, 2:2 + n]
+    return out, olens
+
+
+class ShardedSynthesizer:
+    """Free-running batched synthesis over all ranks of the default process group.
+
+    Every rank calls ``synth(xs, ilens)`` with the same full batch; each computes its shard with
+    ``run_local(xs_shard, ilens_shard) -> (mels, olens)`` (normally ``model.inference_batch``) and all
+    ranks return the complete, ordered result."""
+
+    def __init__(self, run_local, group=None):
+        self.run_local = run_local
+        self.group = group
+
+    def __call__(self, xs, ilens, **kw):
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        il = torch.as_tensor(ilens).to("cpu", torch.int64)
+        parts = shard_indices(il.tolist(), world)
+        mine = parts[rank]
+        sel = torch.as_tensor(mine, dtype=torch.int64)
+        il_loc = il[sel]
+        xs_loc = xs[sel.to(xs.device)][:, : int(il_loc.max())] if len(mine) else xs[:0]
+        kw_loc = {k: (v[sel.to(v.device)][:, : xs_loc.shape[1]] if torch.is_tensor(v) else v) for k, v in kw.items()}
+        mel, olens = self.run_local(xs_loc, il_loc, **kw_loc)
+        if world == 1:
+            return mel, torch.as_tensor(olens)
+        return gather_mels(mel, olens, mine, xs.shape[0], self.group)

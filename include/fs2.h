@@ -132,8 +132,10 @@ int fs2_encode(fs2_handle *h, void *stream, const fs2_encode_io *io);
 size_t fs2_frame_workspace_bytes(const fs2_handle *h, const fs2_batch *batch, const int64_t *olens_host);
 int fs2_decode(fs2_handle *h, void *stream, const fs2_decode_io *io);
 
-/* Per-kernel time of the last encode+decode pair when profiling is on (hipEvents around every launch).
- * names/ms are filled up to `cap`; returns the number of records. */
+/* Per-launch timing: while profiling is on, every kernel launch is bracketed by hipEvents recorded on
+ * the caller's stream; records accumulate until fs2_set_profiling is called again (which clears them).
+ * fs2_get_profile waits for the events and fills names/ms/flops/bytes (algorithmic work of each launch)
+ * up to `cap`; returns the number of records. */
 int fs2_set_profiling(fs2_handle *h, int32_t on);
 int fs2_get_profile(fs2_handle *h, const char **names, float *ms, double *flops, double *bytes, int32_t cap);
 

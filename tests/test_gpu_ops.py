@@ -42,8 +42,14 @@ CASES = [
 ]
 
 
+# fp32: exact-fp32 MFMA chain vs CPU sum order.  bf16x3: operands carry ~16 mantissa bits.  bf16: 8 bits
+# (reported, not a parity mode).
+GEMM_TOL = {"fp32": 2e-4, "bf16x3": 6e-4, "bf16": 8e-2}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 @pytest.mark.parametrize("case", CASES, ids=[c[-1] for c in CASES])
-def test_conv_gemm(case):
+def test_conv_gemm(case, precision):
     from tests import ops_binding as ops
     R, C, N, k, has_bias, has_res, relu_pre, ln_eps, act, has_dot, _ = case
     rs = np.random.RandomState(R + C + N + k)
@@ -68,13 +74,16 @@ def test_conv_gemm(case):
     y = y * valid.unsqueeze(1)
     to = lambda t: t.to(dev) if t is not None else None
     yo, do = ops.conv_gemm(to(x), to(w), to(bias), to(resid), relu_pre, (to(g), to(bt)) if g is not None else None,
-                           ln_eps or 1e-5, act, (to(dw), to(db)) if has_dot else None, to(valid))
-    err = float((yo.cpu() - y).abs().max())
-    assert torch.isfinite(yo).all(), "non-finite / unwritten output"
-    assert err < 2e-4, "max-abs %g" % err
+                           ln_eps or 1e-5, act, (to(dw), to(db)) if has_dot else None, to(valid), precision=precision)
+    tol = GEMM_TOL[precision]
+    if not (has_dot and precision != "fp32"):      # two-pass bf16 path keeps its dot-only result in scratch
+        err = float((yo.cpu() - y).abs().max())
+        assert torch.isfinite(yo).all(), "non-finite / unwritten output"
+        print("%s max-abs %.2e" % (precision, err))
+        assert err < tol, "max-abs %g" % err
     if has_dot:
         derr = float(((do.cpu() - d) * valid).abs().max())
-        assert derr < 2e-4, "dot head max-abs %g" % derr
+        assert derr < tol, "dot head max-abs %g" % derr
 
 
 def test_conv_gemm_transpose_detecting():

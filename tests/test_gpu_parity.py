@@ -103,11 +103,22 @@ def test_g3_free_running_inference(env, golden_dir):
     assert _maxabs(mel, g["mel"]) <= MEL_TOL and _maxabs(after[0], g["mel"]) <= MEL_TOL
 
 
-def test_c2_batch_vs_oracle(env):
-    """BASELINE config c2 (B=16, T in 64..128, fp32), teacher-forced, per-utterance semantics."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
+def test_c2_batch_vs_oracle(env, precision):
+    """BASELINE config c2 (B=16, T in 64..128), teacher-forced, per-utterance semantics, in every arithmetic
+    mode.  fp32 and bf16x3 are parity modes (<= 1e-3); plain bf16 is measured and reported only (it cannot
+    meet the tolerance: BASELINE.md section 2)."""
     model, sd, cfg, O = env
     from fastspeech2_amd.synthetic import make_batch
     b = make_batch("c2")
+    model.precision = precision
+    try:
+        _c2_body(model, sd, cfg, O, b, precision)
+    finally:
+        model.precision = "fp32"
+
+
+def _c2_body(model, sd, cfg, O, b, precision):
     with torch.no_grad():
         r = model._run(b["xs"].cuda(), b["ilens"], b["olens"], b["ds"].cuda(), b["es"].cuda(), b["ps"].cuda(),
                        is_inference=False, want=("before", "after", "e_outs", "p_outs", "lr_index", "qe", "qp"))
@@ -119,8 +130,11 @@ def test_c2_batch_vs_oracle(env):
         assert torch.equal(r["qe"][i, :L].cpu().long(), o["qe"][i, :L]) and torch.equal(r["qp"][i, :L].cpu().long(), o["qp"][i, :L])
     d = {k: _maxabs(r[k], o[k]) for k in ("before", "after", "e_outs", "p_outs")}
     d["d_outs"] = _maxabs(r["d_log"], o["d_outs"])
-    print("c2 max-abs vs oracle:", {k: "%.2e" % v for k, v in d.items()})
-    assert max(d.values()) <= MEL_TOL, d
+    print("c2 [%s] max-abs vs oracle:" % precision, {k: "%.2e" % v for k, v in d.items()})
+    if precision == "bf16":
+        assert max(d["before"], d["after"]) < 0.5     # sanity only
+    else:
+        assert max(d.values()) <= MEL_TOL, d
 
 
 def test_batch_invariance_and_order(env):
@@ -142,7 +156,17 @@ def test_batch_invariance_and_order(env):
     assert torch.equal(solo[0], a1[5, : int(ol1[5])])
 
 
-def test_full_size_c3_properties(env):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_full_size_c3_properties(env, precision):
+    model = env[0]
+    model.precision = precision
+    try:
+        _c3_body(env, precision)
+    finally:
+        model.precision = "fp32"
+
+
+def _c3_body(env, precision):
     """BASELINE config c3 (B=64 LJSpeech-shape), free-running with forced durations: frame counts equal the
     duration sums, pads are exactly zero, outputs finite, and a sampled utterance matches the oracle."""
     model, sd, cfg, O = env
@@ -164,7 +188,7 @@ def test_full_size_c3_properties(env):
     T = int(b["ilens"][i])
     o = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], is_inference=True, d_override=b["ds"][i:i + 1, :T])
     L = int(b["olens"][i])
-    print("c3 longest utterance (L=%d) mel max-abs vs oracle %.2e" % (L, _maxabs(after[i, :L], o["after"][0])))
+    print("c3 [%s] longest utterance (L=%d) mel max-abs vs oracle %.2e" % (precision, L, _maxabs(after[i, :L], o["after"][0])))
     assert _maxabs(after[i, :L], o["after"][0]) <= MEL_TOL
 
 
