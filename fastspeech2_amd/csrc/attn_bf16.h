@@ -1,0 +1,279 @@
+// Split-bf16 ("bf16x3") / plain-bf16 flash-style self-attention on v_mfma_f32_16x16x32_bf16.
+// Same algorithm and register choreography as attn_f32.h (transposed scores S^T = K.Q^T so that P is born in
+// the A-operand layout of P.V, online softmax in registers), with every operand split x = hi + lo (bf16) and
+// three MFMAs per fragment pair (lo*hi + hi*lo + hi*hi, fp32 accumulate).  Replaces reference
+// core/attention.py:55-70.
+//
+// Two kernels:
+//  * qkv_split   : one pass over the fp32 QKV projection [R, 3D] -> bf16 hi/lo planes  QK [R, 2D]  (Q pre-scaled
+//                  by 1/sqrt(d_k), row-major) and  V^T [D, Rvt]  (key index contiguous), because the MFMA wants
+//                  the contraction index contiguous per lane: d for Q.K^T, the key for P.V.
+//  * attn_bf16   : per (utterance, head, 64-query tile) streams 32-key tiles of K and V^T through LDS.
+//
+// MFMA 16x16x32 operands: lane l supplies A[i = l&15][k = 8g..8g+7] and B[k = 8g..8g+7][j = l&15], g = l>>4;
+// C/D: col = l&15, row = 4g + reg.
+//   S^T sub-tile t (16 keys x 16 queries): A = K rows, B = Q rows.  Row i of sub-tile t is loaded from key
+//   8*(i>>2) + 4t + (i&3), so that after both sub-tiles lane (q, g) holds the scores of keys 8g..8g+7 of the
+//   32-key tile in order -- exactly the A-operand k-slots of the P.V MFMA against V^T stored in natural key order.
+// LDS: K tile rows = keys, [hi d_k | lo d_k] bf16 per row, 16-B slot index XOR-swizzled with the row's position
+// i inside its sub-tile (rows are a multiple of 256 B apart, so unswizzled every lane of a ds_read_b128 group
+// would hit the same bank slot); V^T tile rows = head-dim n, [hi 32 keys | lo 32 keys] = 128 B, swizzled like
+// the GEMM tiles (gemm_bf16.h swz()).
+#pragma once
+#include "common.h"
+#include "gemm_bf16.h"
+
+namespace fs2 {
+
+constexpr int kAttAlign = 32;   // utterance starts are multiples of this many rows (16-B aligned V^T tiles)
+
+struct QkvSplitArgs {
+    const float* qkv; int R; int Rvt; int D; int dk; float scale;
+    __bf16 *qk_hi, *qk_lo;     // [R][2D]
+    __bf16 *vt_hi, *vt_lo;     // [D][Rvt]
+};
+
+// grid.x = Rvt / 32 row tiles; 256 threads.
+__global__ __launch_bounds__(256) void qkv_split(QkvSplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float vt_s[];   // [32][D + 1]
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * 32;
+    const int D = a.D, ld = 3 * D;
+    // Q | K : 8 consecutive columns per item, row-major copy with split
+    const int groups = 2 * D / 8;
+    for (int idx = tid; idx < 32 * groups; idx += 256) {
+        const int r = idx / groups, c = (idx - r * groups) * 8;
+        const int row = r0 + r;
+        if (row >= a.R) continue;
+        const float* src = a.qkv + (size_t)row * ld + c;
+        float4 p = *reinterpret_cast<const float4*>(src), q = *reinterpret_cast<const float4*>(src + 4);
+        if (c < D) {
+            p.x *= a.scale; p.y *= a.scale; p.z *= a.scale; p.w *= a.scale;
+            q.x *= a.scale; q.y *= a.scale; q.z *= a.scale; q.w *= a.scale;
+        }
+        const SplitPair s = split8(p, q);
+        *reinterpret_cast<uint4*>(a.qk_hi + (size_t)row * 2 * D + c) = s.hi;
+        *reinterpret_cast<uint4*>(a.qk_lo + (size_t)row * 2 * D + c) = s.lo;
+    }
+    // V : transpose a [32 rows][D] tile through LDS
+    const int ldv = D + 1;
+    for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
+        const int r = idx / (D / 4), c = (idx - r * (D / 4)) * 4;
+        const int row = r0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < a.R) v = *reinterpret_cast<const float4*>(a.qkv + (size_t)row * ld + 2 * D + c);
+        float* d = vt_s + r * ldv + c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < D * 4; idx += 256) {
+        const int n = idx >> 2, j = idx & 3;           // head-dim column n, keys 8j..8j+7 of the tile
+        float4 p, q;
+        const float* s = vt_s + (8 * j) * ldv + n;
+        p.x = s[0]; p.y = s[ldv]; p.z = s[2 * ldv]; p.w = s[3 * ldv];
+        q.x = s[4 * ldv]; q.y = s[5 * ldv]; q.z = s[6 * ldv]; q.w = s[7 * ldv];
+        const SplitPair sp = split8(p, q);
+        const size_t off = (size_t)n * a.Rvt + r0 + 8 * j;
+        *reinterpret_cast<uint4*>(a.vt_hi + off) = sp.hi;
+        *reinterpret_cast<uint4*>(a.vt_lo + off) = sp.lo;
+    }
+}
+
+struct AttnB16Args {
+    const __bf16 *qk_hi, *qk_lo; int ldqk;     // [R][2D]
+    const __bf16 *vt_hi, *vt_lo; int Rvt;      // [D][Rvt]
+    float* ctx; int ldc;
+    const int* start; const int* len; const int* klen;
+    const int2* work;
+    int D; int mask_q;
+};
+
+template <int DK>
+constexpr size_t attn_b16_lds_bytes() { return (size_t)32 * DK * 4 + (size_t)DK * 128; }
+
+template <int DK, int NSPLIT>
+__global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_a[];
+    constexpr int KROW = DK * 4;            // bytes per K row: [hi DK bf16 | lo DK bf16]
+    constexpr int KSL = DK / 8;             // 16-B slots per plane per row (24 or 16: multiples of 8)
+    constexpr int NC = DK / 32;             // k-steps of Q.K^T
+    constexpr int NT = DK / 16;             // n-tiles of O
+    char* Ks = smem_a;
+    char* Vs = smem_a + 32 * KROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int2 wk = a.work[blockIdx.x];
+    const int b = wk.x, h = blockIdx.y;
+    const int s0 = a.start[b], len = a.len[b], klen = a.klen[b];
+    const int q0 = wk.y * 64 + wave * 16;
+
+    // Q fragments (B operand of S^T): row q0 + lr, d = 32c + 8g .. +7
+    bf16x8_t qh[NC], ql[NC];
+    {
+        const int qrow = q0 + lr;
+        const bool ok = qrow < len;
+        const size_t off = (size_t)(s0 + (ok ? qrow : 0)) * a.ldqk + (size_t)h * DK + lg * 8;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            u32x4 vh = u32x4{0, 0, 0, 0}, vl = vh;
+            if (ok) {
+                vh = *reinterpret_cast<const u32x4*>(a.qk_hi + off + c * 32);
+                vl = *reinterpret_cast<const u32x4*>(a.qk_lo + off + c * 32);
+            }
+            qh[c] = *reinterpret_cast<bf16x8_t*>(&vh);
+            ql[c] = *reinterpret_cast<bf16x8_t*>(&vl);
+        }
+    }
+    f32x4 o[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const __bf16* kh_base = a.qk_hi + a.D + (size_t)h * DK;
+    const __bf16* kl_base = a.qk_lo + a.D + (size_t)h * DK;
+    const __bf16* vh_base = a.vt_hi + (size_t)h * DK * a.Rvt;
+    const __bf16* vl_base = a.vt_lo + (size_t)h * DK * a.Rvt;
+
+    // Staging: NLD 16-byte loads per thread per operand tile, all issued back-to-back (no branches), held in the
+    // same registers for K and V^T in turn.  K(t+1) is fetched while P.V(t) runs, V^T(t) while Q.K^T(t) + softmax run.
+    constexpr int NLD = DK / 32;     // 32 * 2*KSL / 256 == DK * 8 / 256
+    u32x4 stg[NLD];
+    const int ntiles = (klen + 31) / 32;
+#define FS2_LOAD_K(key0_)                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < NLD; ++u) {                                                       \
+        const int idx = tid + u * 256;                                                                      \
+        const int key = idx / (2 * KSL), s = idx - key * (2 * KSL);                                         \
+        const __bf16* src = ((s >= KSL) ? kl_base - KSL * 8 : kh_base) + (size_t)(s0 + (key0_) + key) * a.ldqk + s * 8; \
+        stg[u] = *reinterpret_cast<const u32x4*>(src);                                                      \
+    }
+#define FS2_STORE_K()                                                                                       \
+    _Pragma("unroll") for (int u = 0; u < NLD; ++u) {                                                       \
+        const int idx = tid + u * 256;                                                                      \
+        const int key = idx / (2 * KSL), s = idx - key * (2 * KSL);                                         \
+        const int i = ((key >> 1) & 12) | (key & 3);                                                        \
+        *reinterpret_cast<u32x4*>(Ks + key * KROW + ((s ^ i) << 4)) = stg[u];                               \
+    }
+#define FS2_LOAD_V(key0_)                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < NLD; ++u) {                                                       \
+        const int idx = tid + u * 256;                                                                      \
+        const int n = idx >> 3, s = idx & 7;                                                                \
+        const __bf16* src = ((s & 4) ? vl_base : vh_base) + (size_t)n * a.Rvt + s0 + (key0_) + (s & 3) * 8; \
+        stg[u] = *reinterpret_cast<const u32x4*>(src);                                                      \
+    }
+#define FS2_STORE_V()                                                                                       \
+    _Pragma("unroll") for (int u = 0; u < NLD; ++u) {                                                       \
+        const int idx = tid + u * 256;                                                                      \
+        *reinterpret_cast<u32x4*>(Vs + swz(idx >> 3, idx & 7)) = stg[u];                                    \
+    }
+    if (ntiles > 0) {
+        FS2_LOAD_K(0)
+        FS2_STORE_K()
+    }
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int key0 = kt * 32;
+        __syncthreads();          // (A) K(kt) visible; every wave is done with P.V(kt-1), so the V^T buffer is free
+        FS2_LOAD_V(key0)          // in flight during Q.K^T and the softmax
+        f32x4 st[2];
+        st[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const char* krow0 = Ks + (8 * (lr >> 2) + (lr & 3)) * KROW;     // sub-tile 0 row; sub-tile 1 is 4 keys further
+            const char* krow1 = krow0 + 4 * KROW;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int sh = ((c * 4 + lg) ^ lr) << 4, sl = ((KSL + c * 4 + lg) ^ lr) << 4;
+                const bf16x8_t kh0 = *reinterpret_cast<const bf16x8_t*>(krow0 + sh);
+                const bf16x8_t kh1 = *reinterpret_cast<const bf16x8_t*>(krow1 + sh);
+                if (NSPLIT == 3) {
+                    const bf16x8_t kl0 = *reinterpret_cast<const bf16x8_t*>(krow0 + sl);
+                    const bf16x8_t kl1 = *reinterpret_cast<const bf16x8_t*>(krow1 + sl);
+                    st[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl0, qh[c], st[0], 0, 0, 0);
+                    st[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl1, qh[c], st[1], 0, 0, 0);
+                    st[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0, ql[c], st[0], 0, 0, 0);
+                    st[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1, ql[c], st[1], 0, 0, 0);
+                }
+                st[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0, qh[c], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1, qh[c], st[1], 0, 0, 0);
+            }
+        }
+        // st[t][r] = score of key key0 + 8g + 4t + r for query lr (Q was pre-scaled)
+        float p[8];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = key0 + 8 * lg + 4 * t + r;
+                const float s = (key < klen) ? st[t][r] : -INFINITY;
+                p[t * 4 + r] = s;
+                tmax = fmaxf(tmax, s);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            p[j] = expf(p[j] - m_new);
+            psum += p[j];
+        }
+        psum += __shfl_xor(psum, 16);
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ar = __shfl(alpha, lg * 4 + r);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) o[n][r] *= ar;
+        }
+        bf16x8_t ph, pl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const __bf16 hb = (__bf16)p[j];
+            ph[j] = hb;
+            pl[j] = (__bf16)(p[j] - (float)hb);
+        }
+        FS2_STORE_V()
+        __syncthreads();          // (B) V^T(kt) visible; every wave is done with Q.K^T(kt), so the K buffer is free
+        if (kt + 1 < ntiles) FS2_LOAD_K(key0 + 32)     // in flight during P.V
+        constexpr int PG = (DK > 128) ? 2 : 4;     // n-tiles in flight: independent accumulators between dependent MFMAs
+#pragma unroll
+        for (int n4 = 0; n4 < NT; n4 += PG) {
+            bf16x8_t vh[PG], vl[PG];
+#pragma unroll
+            for (int u = 0; u < PG; ++u) {
+                const int row = (n4 + u) * 16 + lr;
+                vh[u] = *reinterpret_cast<const bf16x8_t*>(Vs + swz(row, lg));
+                if (NSPLIT == 3) vl[u] = *reinterpret_cast<const bf16x8_t*>(Vs + swz(row, 4 + lg));
+            }
+            if (NSPLIT == 3) {
+#pragma unroll
+                for (int u = 0; u < PG; ++u) o[n4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh[u], o[n4 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < PG; ++u) o[n4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl[u], o[n4 + u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < PG; ++u) o[n4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[u], o[n4 + u], 0, 0, 0);
+        }
+        if (kt + 1 < ntiles) FS2_STORE_K()
+    }
+#undef FS2_LOAD_K
+#undef FS2_STORE_K
+#undef FS2_LOAD_V
+#undef FS2_STORE_V
+    const float linv = (l_run > 0.f) ? 1.f / l_run : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float li = __shfl(linv, lg * 4 + r);
+        const int qrow = q0 + lg * 4 + r;
+        if (qrow >= len) continue;
+        const bool dead = a.mask_q && qrow >= klen;
+        float* dst = a.ctx + (size_t)(s0 + qrow) * a.ldc + (size_t)h * DK + lr;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) dst[n * 16] = dead ? 0.f : o[n][r] * li;
+    }
+}
+
+}  // namespace fs2

@@ -51,14 +51,14 @@ __global__ __launch_bounds__(256) void attn_f32(AttnArgs a) {
     const float* vbase = a.qkv + 2 * a.D + (size_t)h * DK;
 
     // Q fragments for query row q0 + lr: NC float4 at k = 16c + 4*lg
-    float4 qf[NC];
+    f32x4 qf[NC];
     {
         const int qrow = q0 + lr;
         const bool ok = qrow < len;
         const float* qp = qbase + (size_t)(s0 + (ok ? qrow : 0)) * a.ld + lg * 4;
 #pragma unroll
         for (int c = 0; c < NC; ++c)
-            qf[c] = ok ? *reinterpret_cast<const float4*>(qp + c * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            qf[c] = ok ? *reinterpret_cast<const f32x4*>(qp + c * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     f32x4 o[NC];
 #pragma unroll
@@ -69,17 +69,27 @@ __global__ __launch_bounds__(256) void attn_f32(AttnArgs a) {
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * kAttKT;
         __syncthreads();
-        for (int idx = tid; idx < kAttKT * (DK / 4); idx += 256) {
-            const int r = idx / (DK / 4), c4 = idx - r * (DK / 4);
-            const int key = key0 + r;
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (key < klen) {
+        {   // all loads of the tile are issued before the first LDS write (no branch between them)
+            constexpr int NLD = kAttKT * (DK / 4) / 256;
+            f32x4 kreg[NLD], vreg[NLD];
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int idx = tid + u * 256;
+                const int r = idx / (DK / 4), c4 = idx - r * (DK / 4);
+                const int key = min(key0 + r, klen - 1);           // clamp: rows >= klen are masked below
                 const size_t off = (size_t)(s0 + key) * a.ld + c4 * 4;
-                kv = *reinterpret_cast<const float4*>(kbase + off);
-                vv = *reinterpret_cast<const float4*>(vbase + off);
+                kreg[u] = *reinterpret_cast<const f32x4*>(kbase + off);
+                vreg[u] = *reinterpret_cast<const f32x4*>(vbase + off);
             }
-            *reinterpret_cast<float4*>(Ks + r * LDK + c4 * 4) = kv;
-            *reinterpret_cast<float4*>(Vs + r * LDK + c4 * 4) = vv;
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int idx = tid + u * 256;
+                const int r = idx / (DK / 4), c4 = idx - r * (DK / 4);
+                const bool ok = key0 + r < klen;
+                const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(Ks + r * LDK + c4 * 4) = ok ? kreg[u] : z;
+                *reinterpret_cast<f32x4*>(Vs + r * LDK + c4 * 4) = ok ? vreg[u] : z;
+            }
         }
         __syncthreads();
 
@@ -89,8 +99,8 @@ __global__ __launch_bounds__(256) void attn_f32(AttnArgs a) {
         st[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const float4 k0 = *reinterpret_cast<const float4*>(Ks + lr * LDK + c * 16 + lg * 4);
-            const float4 k1 = *reinterpret_cast<const float4*>(Ks + (16 + lr) * LDK + c * 16 + lg * 4);
+            const f32x4 k0 = *reinterpret_cast<const f32x4*>(Ks + lr * LDK + c * 16 + lg * 4);
+            const f32x4 k1 = *reinterpret_cast<const f32x4*>(Ks + (16 + lr) * LDK + c * 16 + lg * 4);
             st[0] = mfma16(k0.x, qf[c].x, st[0]);
             st[1] = mfma16(k1.x, qf[c].x, st[1]);
             st[0] = mfma16(k0.y, qf[c].y, st[0]);

@@ -6,6 +6,9 @@
 namespace fs2 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// NOTE: register-resident staging arrays must use these native vector types.  Arrays of HIP's float4 / uint4
+// (struct wrappers) larger than 64 bytes are not scalarised by hipcc and end up in scratch memory.
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kGap = 8;        // zero rows between packed sequences (>= largest conv halo, 4)

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/fs2.h"
+#include "attn_bf16.h"
 #include "attn_f32.h"
 #include "common.h"
 #include "elementwise.h"
@@ -255,12 +256,59 @@ int launch_attention(fs2_handle* h, hipStream_t s, const char* name, const float
     return FS2_OK;
 }
 
+template <int DK, int NSPLIT>
+hipError_t launch_attn_b16_t(hipStream_t s, dim3 grid, const AttnB16Args& a) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16<DK, NSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_b16_lds_bytes<DK>());
+        attr = true;
+    }
+    hipLaunchKernelGGL((attn_bf16<DK, NSPLIT>), grid, dim3(256), attn_b16_lds_bytes<DK>(), s, a);
+    return hipGetLastError();
+}
+
+// qkv fp32 [R,3D] -> split planes -> attention.  planes: qk_hi/lo [Rvt][2D], vt_hi/lo [D][Rvt] (Rvt % 32 == 0)
+int launch_attention_b16(fs2_handle* h, hipStream_t s, const char* name, const float* qkv, float* ctx, int D, int heads, int R, int Rvt,
+                         const DevLayout& dl, int nwork, int mask_q, double flops, int precision, __bf16* qkh, __bf16* qkl, __bf16* vth,
+                         __bf16* vtl) {
+    const int dk = D / heads;
+    if (nwork == 0) return FS2_OK;
+    {
+        char nm[112];
+        snprintf(nm, sizeof nm, "%s.split", name);
+        Scope sc(h, s, nm, 0.0, 4.0 * R * 3.0 * D * 2);
+        static bool attr = false;
+        if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_split), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (1024 + 1) * 4); attr = true; }
+        QkvSplitArgs q;
+        q.qkv = qkv; q.R = R; q.Rvt = Rvt; q.D = D; q.dk = dk; q.scale = 1.0f / sqrtf((float)dk);
+        q.qk_hi = qkh; q.qk_lo = qkl; q.vt_hi = vth; q.vt_lo = vtl;
+        if (D > 1024) return fail(h, FS2_ERR_UNSUPPORTED, "attention dim %d > 1024", D);
+        hipLaunchKernelGGL(qkv_split, dim3(Rvt / 32), dim3(256), (size_t)32 * (D + 1) * 4, s, q);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(h, FS2_ERR_HIP, "%s launch: %s", nm, hipGetErrorString(e));
+    }
+    AttnB16Args a;
+    a.qk_hi = qkh; a.qk_lo = qkl; a.ldqk = 2 * D; a.vt_hi = vth; a.vt_lo = vtl; a.Rvt = Rvt; a.ctx = ctx; a.ldc = D;
+    a.start = dl.start; a.len = dl.len; a.klen = dl.klen; a.work = dl.work; a.D = D; a.mask_q = mask_q;
+    Scope sc(h, s, name, flops, 0.0);
+    dim3 grid(nwork, heads);
+    hipError_t e;
+    const bool x3 = precision == FS2_PREC_BF16X3;
+    if (dk == 128) e = x3 ? launch_attn_b16_t<128, 3>(s, grid, a) : launch_attn_b16_t<128, 1>(s, grid, a);
+    else if (dk == 192) e = x3 ? launch_attn_b16_t<192, 3>(s, grid, a) : launch_attn_b16_t<192, 1>(s, grid, a);
+    else if (dk == 64) e = x3 ? launch_attn_b16_t<64, 3>(s, grid, a) : launch_attn_b16_t<64, 1>(s, grid, a);
+    else return fail(h, FS2_ERR_UNSUPPORTED, "attention head dim %d not in {64,128,192}", dk);
+    if (e != hipSuccess) return fail(h, FS2_ERR_HIP, "%s launch: %s", name, hipGetErrorString(e));
+    return FS2_OK;
+}
+
 // ------------------------------------------------------------------ layouts
 void build_layout(HostLayout& L, int B, const std::vector<int>& len, const std::vector<int>& klen, const std::vector<int>& vlen) {
     L.B = B; L.len = len; L.klen = klen; L.vlen = vlen;
     L.start.resize(B); L.work.clear();
     int row = kGap;
     for (int b = 0; b < B; ++b) {
+        row = round_up(row, kAttAlign);     // 32-row aligned starts: 16-byte aligned V^T key tiles (attn_bf16.h)
         L.start[b] = row;
         for (int q = 0; q * kAttBQ < len[b]; ++q) L.work.push_back(make_int2(b, q));
         row += len[b] + kGap;
@@ -292,7 +340,7 @@ int upload_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, D
 }
 
 // ------------------------------------------------------------------ FFT block stack
-struct StackBufs { float *x0, *x1, *qkv, *ctx, *hid; };
+struct StackBufs { float *x0, *x1, *qkv, *ctx, *hid; __bf16 *qkh, *qkl, *vth, *vtl; };
 
 // x0 holds the input; returns the buffer holding the output (x0 again).
 int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, int D, int heads, int R,
@@ -307,7 +355,9 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         GemmArgs a = gemm_args(ly.qkv, b.x0, D, R, dl.row_pos, b.qkv, 3 * D);
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.attn", tag);
-        if ((rc = launch_attention(h, s, nm, b.qkv, b.ctx, D, heads, dl, (int)L.work.size(), mask_q, att_flops))) return rc;
+        if (prec == FS2_PREC_FP32) rc = launch_attention(h, s, nm, b.qkv, b.ctx, D, heads, dl, (int)L.work.size(), mask_q, att_flops);
+        else rc = launch_attention_b16(h, s, nm, b.qkv, b.ctx, D, heads, R, L.Rpad, dl, (int)L.work.size(), mask_q, att_flops, prec, b.qkh, b.qkl, b.vth, b.vtl);
+        if (rc) return rc;
         snprintf(nm, sizeof nm, "%s.out_ln", tag);
         a = gemm_args(ly.out, b.ctx, D, R, dl.row_pos, b.x1, D);
         a.resid = b.x0; a.ldr = D; a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
@@ -508,6 +558,10 @@ size_t carve_tokens(const fs2_config& c, const fs2_batch& b, const HostLayout& L
     float* qkv = bp.take<float>(R * 3 * c.adim);
     float* ctx = bp.take<float>(R * c.adim);
     float* hid = bp.take<float>(R * c.eunits);
+    __bf16* qkh = bp.take<__bf16>(R * 2 * c.adim);
+    __bf16* qkl = bp.take<__bf16>(R * 2 * c.adim);
+    __bf16* vth = bp.take<__bf16>(R * c.adim);
+    __bf16* vtl = bp.take<__bf16>(R * c.adim);
     float* q0 = bp.take<float>(R * c.dur_chans);
     float* q1 = bp.take<float>(R * c.dur_chans);
     float* dl = bp.take<float>(R);
@@ -515,7 +569,7 @@ size_t carve_tokens(const fs2_config& c, const fs2_batch& b, const HostLayout& L
     int* cu = bp.take<int>((size_t)b.B * b.Tmax);
     int* o32 = bp.take<int>(b.B);
     if (meta) *meta = m;
-    if (sb) { sb->x0 = x0; sb->x1 = x1; sb->qkv = qkv; sb->ctx = ctx; sb->hid = hid; }
+    if (sb) { sb->x0 = x0; sb->x1 = x1; sb->qkv = qkv; sb->ctx = ctx; sb->hid = hid; sb->qkh = qkh; sb->qkl = qkl; sb->vth = vth; sb->vtl = vtl; }
     if (p0) *p0 = q0;
     if (p1) *p1 = q1;
     if (dlog_rows) *dlog_rows = dl;
@@ -545,6 +599,10 @@ size_t carve_frames(const fs2_config& c, const HostLayout& L, void* ws, size_t c
     f.sb.qkv = bp.take<float>(R * 3 * c.ddim);
     f.sb.ctx = bp.take<float>(R * c.ddim);
     f.sb.hid = bp.take<float>(R * (size_t)std::max(c.dunits, 2 * c.postnet_chans));
+    f.sb.qkh = bp.take<__bf16>(R * 2 * c.ddim);
+    f.sb.qkl = bp.take<__bf16>(R * 2 * c.ddim);
+    f.sb.vth = bp.take<__bf16>(R * c.ddim);
+    f.sb.vtl = bp.take<__bf16>(R * c.ddim);
     f.before = bp.take<float>(R * c.odim);
     f.after = bp.take<float>(R * c.odim);
     f.qe = bp.take<int>(R);
@@ -877,11 +935,16 @@ int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
 int fs2_op_attention(void* stream, const float* qkv, float* ctx, int32_t D, int32_t heads, int32_t B, const int32_t* seq_start,
                      const int32_t* seq_len, const int32_t* seq_klen, int32_t mask_q, int32_t precision) {
     if (!qkv || !ctx || B <= 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_attention: bad arguments");
-    (void)precision;   // attention runs on the f32-input matrix core in every mode for now
+    if (precision < FS2_PREC_FP32 || precision > FS2_PREC_BF16) return fail(nullptr, FS2_ERR_ARG, "unknown precision %d", precision);
     hipStream_t s = (hipStream_t)stream;
     std::vector<int> host;
     std::vector<int2> work;
-    for (int b = 0; b < B; ++b) for (int q = 0; q * kAttBQ < seq_len[b]; ++q) work.push_back(make_int2(b, q));
+    int R = 0;
+    for (int b = 0; b < B; ++b) {
+        for (int q = 0; q * kAttBQ < seq_len[b]; ++q) work.push_back(make_int2(b, q));
+        R = std::max(R, seq_start[b] + seq_len[b]);
+        if (precision != FS2_PREC_FP32 && seq_start[b] % kAttAlign) return fail(nullptr, FS2_ERR_ARG, "bf16 attention needs sequence starts aligned to %d rows", kAttAlign);
+    }
     host.insert(host.end(), seq_start, seq_start + B);
     host.insert(host.end(), seq_len, seq_len + B);
     host.insert(host.end(), seq_klen, seq_klen + B);
@@ -891,7 +954,18 @@ int fs2_op_attention(void* stream, const float* qkv, float* ctx, int32_t D, int3
     OP_TRY(hipMemcpyAsync(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
     DevLayout dl;
     dl.start = dev; dl.len = dev + B; dl.klen = dev + 2 * B; dl.work = reinterpret_cast<int2*>(dev + 3 * B);
-    int rc = launch_attention(nullptr, s, "op.attention", qkv, ctx, D, heads, dl, (int)work.size(), mask_q, 0.0);
+    int rc;
+    if (precision == FS2_PREC_FP32) {
+        rc = launch_attention(nullptr, s, "op.attention", qkv, ctx, D, heads, dl, (int)work.size(), mask_q, 0.0);
+    } else {
+        const int Rvt = round_up(R, 128);
+        __bf16* planes = nullptr;
+        OP_TRY(hipMalloc((void**)&planes, (size_t)Rvt * D * 6 * sizeof(__bf16)));
+        __bf16 *qkh = planes, *qkl = planes + (size_t)Rvt * 2 * D, *vth = qkl + (size_t)Rvt * 2 * D, *vtl = vth + (size_t)Rvt * D;
+        rc = launch_attention_b16(nullptr, s, "op.attention", qkv, ctx, D, heads, R, Rvt, dl, (int)work.size(), mask_q, 0.0, precision, qkh, qkl, vth, vtl);
+        hipStreamSynchronize(s);
+        hipFree(planes);
+    }
     hipStreamSynchronize(s);
     hipFree(dev);
     return rc;

@@ -61,18 +61,17 @@ __global__ __launch_bounds__(256) void gemm_tile_f32(GemmArgs a) {
     const int nchunks = a.Cpad / kBK;
     const int niter = nchunks * a.ktaps;
     constexpr int BREG = kTileBN * (kBK / 4) / 256;   // 4 float4 per thread
-    float4 breg[BREG];
-    auto gload_B = [&](int it) {
-        const int chunk = it / a.ktaps, tap = it - chunk * a.ktaps;
-#pragma unroll
-        for (int i = 0; i < BREG; ++i) {
-            const int idx = tid + i * 256;
-            const int n = idx >> 3, kq = idx & 7;
-            breg[i] = *reinterpret_cast<const float4*>(a.W + ((size_t)(n0 + n) * a.ktaps + tap) * a.Cpad +
-                                                       chunk * kBK + kq * 4);
-        }
-    };
-    gload_B(0);
+    f32x4 breg[BREG];    // native vector type: stays in registers (common.h note)
+#define FS2_GLOAD_B(it_)                                                                                     \
+    {                                                                                                        \
+        const int c_ = (it_) / a.ktaps, t_ = (it_) - c_ * a.ktaps;                                           \
+        _Pragma("unroll") for (int i = 0; i < BREG; ++i) {                                                   \
+            const int idx = tid + i * 256;                                                                   \
+            breg[i] = *reinterpret_cast<const f32x4*>(a.W + ((size_t)(n0 + (idx >> 3)) * a.ktaps + t_) * a.Cpad + \
+                                                       c_ * kBK + (idx & 7) * 4);                            \
+        }                                                                                                    \
+    }
+    FS2_GLOAD_B(0)
     for (int it = 0; it < niter; ++it) {
         const int chunk = it / a.ktaps, tap = it - chunk * a.ktaps;
         __syncthreads();   // everyone finished reading As/Bs of the previous iteration
@@ -80,19 +79,19 @@ __global__ __launch_bounds__(256) void gemm_tile_f32(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < BREG; ++i) {
             const int idx = tid + i * 256;
-            *reinterpret_cast<float4*>(Bs + (idx >> 3) * kLd + (idx & 7) * 4) = breg[i];
+            *reinterpret_cast<f32x4*>(Bs + (idx >> 3) * kLd + (idx & 7) * 4) = breg[i];
         }
         __syncthreads();
-        if (it + 1 < niter) gload_B(it + 1);
+        if (it + 1 < niter) FS2_GLOAD_B(it + 1)
 #pragma unroll
         for (int kk = 0; kk < kBK / 16; ++kk) {
-            float4 af[4], bf[4];
+            f32x4 af[4], bf[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
-                af[mt] = *reinterpret_cast<const float4*>(As + (wm * 64 + mt * 16 + lr + tap) * kLd + kk * 16 + lg * 4);
+                af[mt] = *reinterpret_cast<const f32x4*>(As + (wm * 64 + mt * 16 + lr + tap) * kLd + kk * 16 + lg * 4);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                bf[nt] = *reinterpret_cast<const float4*>(Bs + (wn * 64 + nt * 16 + lr) * kLd + kk * 16 + lg * 4);
+                bf[nt] = *reinterpret_cast<const f32x4*>(Bs + (wn * 64 + nt * 16 + lr) * kLd + kk * 16 + lg * 4);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -104,6 +103,7 @@ __global__ __launch_bounds__(256) void gemm_tile_f32(GemmArgs a) {
                 }
         }
     }
+#undef FS2_GLOAD_B
     // epilogue: row = 4*lg + reg, col = lr inside each 16x16 tile
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -157,19 +157,17 @@ __global__ __launch_bounds__(256) void gemm_rows_f32(GemmArgs a) {
     const int niter = nchunks * a.ktaps;
     constexpr int NB4 = BN * (kBK / 4);                 // float4 per B tile
     constexpr int BREG = (NB4 + 255) / 256;
-    float4 breg[BREG];
-    auto gload_B = [&](int it) {
-        const int chunk = it / a.ktaps, tap = it - chunk * a.ktaps;
-#pragma unroll
-        for (int i = 0; i < BREG; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < NB4) {
-                const int n = idx >> 3, kq = idx & 7;
-                breg[i] = *reinterpret_cast<const float4*>(a.W + ((size_t)n * a.ktaps + tap) * a.Cpad + chunk * kBK + kq * 4);
-            }
-        }
-    };
-    gload_B(0);
+    f32x4 breg[BREG];
+#define FS2_GLOAD_B(it_)                                                                                     \
+    {                                                                                                        \
+        const int c_ = (it_) / a.ktaps, t_ = (it_) - c_ * a.ktaps;                                           \
+        _Pragma("unroll") for (int i = 0; i < BREG; ++i) {                                                   \
+            const int idx = tid + i * 256;                                                                   \
+            if (idx < NB4)                                                                                   \
+                breg[i] = *reinterpret_cast<const f32x4*>(a.W + ((size_t)(idx >> 3) * a.ktaps + t_) * a.Cpad + c_ * kBK + (idx & 7) * 4); \
+        }                                                                                                    \
+    }
+    FS2_GLOAD_B(0)
     for (int it = 0; it < niter; ++it) {
         const int chunk = it / a.ktaps, tap = it - chunk * a.ktaps;
         __syncthreads();
@@ -177,10 +175,10 @@ __global__ __launch_bounds__(256) void gemm_rows_f32(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < BREG; ++i) {
             const int idx = tid + i * 256;
-            if (idx < NB4) *reinterpret_cast<float4*>(Bs + (idx >> 3) * kLd + (idx & 7) * 4) = breg[i];
+            if (idx < NB4) *reinterpret_cast<f32x4*>(Bs + (idx >> 3) * kLd + (idx & 7) * 4) = breg[i];
         }
         __syncthreads();
-        if (it + 1 < niter) gload_B(it + 1);
+        if (it + 1 < niter) FS2_GLOAD_B(it + 1)
 #pragma unroll
         for (int kk = 0; kk < kBK / 16; ++kk) {
             const float4 af = *reinterpret_cast<const float4*>(As + (wave * 16 + lr + tap) * kLd + kk * 16 + lg * 4);
@@ -195,6 +193,7 @@ __global__ __launch_bounds__(256) void gemm_rows_f32(GemmArgs a) {
         }
     }
 
+#undef FS2_GLOAD_B
     // ---- epilogue: each (lg, r) pair is one output row spread over 16 lanes x NT tiles ----
     const float inv_n = 1.f / (float)a.N;
     const float alpha = (a.pe && a.pe_alpha) ? a.pe_alpha[0] : 1.f;
