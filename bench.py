@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3")
-    ap.add_argument("--precision", default=os.environ.get("FS2_PRECISION", "fp32"))
+    ap.add_argument("--precision", default=os.environ.get("FS2_PRECISION", "bf16x3"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-kernels", action="store_true", help="print the per-kernel hipEvent table to stderr")
     args = ap.parse_args()

@@ -63,4 +63,54 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// Elementwise epilogue of a 64 x 64 wave tile held as acc[4][4] (16 x 16 MFMA tiles, C layout col = l&15,
+// row = 4*(l>>4) + reg).  All loads of a 16-row slab (row flags, residual) are issued before its stores and the
+// pointers are __restrict__, so the compiler does not serialise a memory round trip per element behind
+// possibly-aliasing stores (that cost ~25 us per workgroup before).
+__device__ __forceinline__ void tile_epilogue_64x64(const GemmArgs& a, f32x4 (&acc)[4][4], int row_base, int col_base, int lr, int lg,
+                                                    bool relu_first) {
+    const float* __restrict__ biasp = a.bias;
+    const float* __restrict__ residp = a.resid;
+    const int* __restrict__ rpos = a.row_pos;
+    float* __restrict__ Y = a.Y;
+    float bv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = col_base + nt * 16 + lr;
+        bv[nt] = (biasp && col < a.N) ? biasp[col] : 0.f;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        bool inb[4], valid[4];
+        float rv[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row_base + mt * 16 + lg * 4 + r;
+            inb[r] = row < a.R;
+            valid[r] = inb[r] && (rpos == nullptr || rpos[row] >= 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row_base + mt * 16 + lg * 4 + r;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int col = col_base + nt * 16 + lr;
+                rv[r][nt] = (residp && inb[r] && col < a.N) ? residp[(size_t)row * a.ldr + col] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row_base + mt * 16 + lg * 4 + r;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int col = col_base + nt * 16 + lr;
+                float v = acc[mt][nt][r] + bv[nt] + rv[r][nt];
+                if (relu_first) v = fmaxf(v, 0.f);
+                v = apply_act(v, a.act_post);
+                if (inb[r] && col < a.N) Y[(size_t)row * a.ldy + col] = valid[r] ? v : 0.f;
+            }
+        }
+    }
+}
+
 }  // namespace fs2

@@ -171,25 +171,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_bf16(GemmArgs a) {
 #undef FS2_STORE_B1
 #undef FS2_STORE_B
     // epilogue (elementwise): bias, residual, activation, gap rows -> 0
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm * 64 + mt * 16 + lg * 4 + r;
-            if (row >= a.R) continue;
-            const bool valid = a.row_pos == nullptr || a.row_pos[row] >= 0;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int col = n0 + wn * 64 + nt * 16 + lr;
-                if (col >= a.N) continue;
-                float v = acc[mt][nt][r];
-                if (a.bias) v += a.bias[col];
-                if (a.resid) v += a.resid[(size_t)row * a.ldr + col];
-                if (a.relu_pre) v = fmaxf(v, 0.f);
-                v = apply_act(v, a.act_post);
-                a.Y[(size_t)row * a.ldy + col] = valid ? v : 0.f;
-            }
-        }
+    tile_epilogue_64x64(a, acc, m0 + wm * 64, n0 + wn * 64, lr, lg, a.relu_pre != 0);
 }
 
 // Row epilogue as its own HBM-bound kernel (used after gemm_tile_bf16 when the op ends in a LayerNorm, a

@@ -105,24 +105,7 @@ __global__ __launch_bounds__(256) void gemm_tile_f32(GemmArgs a) {
     }
 #undef FS2_GLOAD_B
     // epilogue: row = 4*lg + reg, col = lr inside each 16x16 tile
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm * 64 + mt * 16 + lg * 4 + r;
-            if (row >= a.R) continue;
-            const bool valid = a.row_pos == nullptr || a.row_pos[row] >= 0;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int col = n0 + wn * 64 + nt * 16 + lr;
-                if (col >= a.N) continue;
-                float v = acc[mt][nt][r];
-                if (a.bias) v += a.bias[col];
-                if (a.resid) v += a.resid[(size_t)row * a.ldr + col];
-                v = apply_act(v, a.act_post);
-                a.Y[(size_t)row * a.ldy + col] = valid ? v : 0.f;
-            }
-        }
+    tile_epilogue_64x64(a, acc, m0 + wm * 64, n0 + wn * 64, lr, lg, false);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -198,11 +181,20 @@ __global__ __launch_bounds__(256) void gemm_rows_f32(GemmArgs a) {
     const float inv_n = 1.f / (float)a.N;
     const float alpha = (a.pe && a.pe_alpha) ? a.pe_alpha[0] : 1.f;
     const float dotb = (a.dot_w && a.dot_b) ? a.dot_b[0] : 0.f;
+    const float* __restrict__ biasp = a.bias;
+    const float* __restrict__ residp = a.resid;
+    const int* __restrict__ rposp = a.row_pos;
+    int posr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {       // row flags of all four rows up front (one latency, not four)
+        const int row = m0 + wave * 16 + lg * 4 + r;
+        posr[r] = (row < a.R) ? (rposp ? rposp[row] : 0) : -1;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = m0 + wave * 16 + lg * 4 + r;
         const bool inb = row < a.R;
-        const int pos = inb ? (a.row_pos ? a.row_pos[row] : 0) : -1;
+        const int pos = posr[r];
         const bool valid = pos >= 0;
         float v[NT];
         float s = 0.f;
@@ -210,8 +202,8 @@ __global__ __launch_bounds__(256) void gemm_rows_f32(GemmArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
             const int col = nt * 16 + lr;
             float t = acc[nt][r];
-            if (a.bias) t += a.bias[col];
-            if (a.resid && inb) t += a.resid[(size_t)row * a.ldr + col];
+            if (biasp) t += biasp[col];
+            if (residp && inb) t += residp[(size_t)row * a.ldr + col];
             if (a.relu_pre) t = fmaxf(t, 0.f);
             v[nt] = t;
             s += t;
