@@ -66,7 +66,7 @@ class OpGemmArgs(C.Structure):
 
 # every symbol include/fs2.h declares (tests check the library exports all of them)
 EXPORTS = ["fs2_create", "fs2_destroy", "fs2_last_error", "fs2_load_weights", "fs2_token_workspace_bytes",
-           "fs2_encode", "fs2_frame_workspace_bytes", "fs2_decode", "fs2_set_profiling", "fs2_get_profile",
+           "fs2_encode", "fs2_frame_workspace_bytes", "fs2_decode", "fs2_set_profiling", "fs2_set_profile_filter", "fs2_get_profile",
            "fs2_op_conv_gemm", "fs2_op_attention", "fs2_op_length_regulate", "fs2_op_bucketize"]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
@@ -123,6 +123,8 @@ def lib():
     L.fs2_decode.restype = C.c_int
     L.fs2_set_profiling.argtypes = [vp, i32]
     L.fs2_set_profiling.restype = C.c_int
+    L.fs2_set_profile_filter.argtypes = [vp, C.c_char_p]
+    L.fs2_set_profile_filter.restype = C.c_int
     L.fs2_get_profile.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), i32]
     L.fs2_get_profile.restype = C.c_int

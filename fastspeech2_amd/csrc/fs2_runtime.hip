@@ -84,6 +84,7 @@ struct fs2_handle {
     void* enc_ws = nullptr;
     // profiling
     bool prof = false;
+    std::string prof_filter;      // when non-empty only launches with exactly this name are bracketed
     std::vector<ProfRec> recs;
 };
 
@@ -124,7 +125,7 @@ struct Bump {   // carve a caller-provided workspace
 struct Scope {
     fs2_handle* h; hipStream_t s; size_t idx = (size_t)-1;
     Scope(fs2_handle* h_, hipStream_t s_, const char* name, double flops, double bytes) : h(h_), s(s_) {
-        if (h && h->prof) {
+        if (h && h->prof && (h->prof_filter.empty() || h->prof_filter == name)) {
             ProfRec r; r.name = name; r.flops = flops; r.bytes = bytes;
             hipEventCreate(&r.e0); hipEventCreate(&r.e1);
             hipEventRecord(r.e0, s);
@@ -161,8 +162,31 @@ hipError_t launch_tile(hipStream_t s, const GemmArgs& a) {
 
 bool rows_supported(int N) { return N == 80 || N == 256 || N == 384; }
 
+template <int NSPLIT, bool K1>
+hipError_t launch_glds_bf16_t(hipStream_t s, const GemmArgs& a) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_bf16<NSPLIT, K1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds_lds_bytes<K1>());
+        attr = true;
+    }
+    const int nN = (a.N + kB16BN - 1) / kB16BN, nM = (a.R + kB16BM - 1) / kB16BM;
+    hipLaunchKernelGGL((gemm_glds_bf16<NSPLIT, K1>), dim3(nN * nM), dim3(256), glds_lds_bytes<K1>(), s, a);
+    return hipGetLastError();
+}
+
+// Kernel choice per shape (measured on MI355X, c3): the 9-tap FFN conv is ~10 % faster register-staged
+// (gemm_tile_bf16: the fp32->bf16 split happens once per chunk, not once per tap); k = 1 GEMMs are ~5-15 % faster
+// with LDS-DMA staging (gemm_glds_bf16: A and B double-buffered, no staging registers).  FS2_GEMM=regs|glds forces one.
+int gemm_choice() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FS2_GEMM"); v = !e ? 0 : (!strcmp(e, "glds") ? 1 : (!strcmp(e, "regs") ? 2 : 0)); }
+    return v;
+}
+bool use_glds(int ktaps) { const int c = gemm_choice(); return c == 1 || (c == 0 && ktaps == 1); }
+
 template <int NSPLIT>
 hipError_t launch_tile_bf16(hipStream_t s, const GemmArgs& a) {
+    if (use_glds(a.ktaps)) return a.ktaps == 1 ? launch_glds_bf16_t<NSPLIT, true>(s, a) : launch_glds_bf16_t<NSPLIT, false>(s, a);
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_bf16<NSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kB16Lds);
@@ -721,6 +745,12 @@ int fs2_set_profiling(fs2_handle* h, int32_t on) {
     h->prof = on != 0;
     for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     h->recs.clear();
+    return FS2_OK;
+}
+
+int fs2_set_profile_filter(fs2_handle* h, const char* name) {
+    if (!h) return FS2_ERR_ARG;
+    h->prof_filter = name ? name : "";
     return FS2_OK;
 }
 

@@ -4,7 +4,7 @@
 // sides.  Plain bf16 misses the 1e-3 mel tolerance by 20x, so the parity mode splits every
 // operand x = hi + lo (hi = bf16(x), lo = bf16(x - hi), ~16 mantissa bits) and issues three MFMAs per fragment
 // pair, hi*hi + hi*lo + lo*hi, accumulating in fp32 (NSPLIT = 3).  NSPLIT = 1 is plain bf16.
-//   * weights are split once at load time into the exact LDS image: [Npad][tap][chunk][hi k0..31 | lo k0..31]
+//   * weights are split once at load time into the exact LDS image: [Npad][chunk][tap][hi 32 | lo 32] (k-step order)
 //     (128 B per (n, tap, chunk));
 //   * activations stay fp32 in HBM and are split in registers while they are staged into LDS
 //     (v_cvt_pk_bf16_f32: ~3 VALU ops per element, amortised over the 9 taps of the FFN conv).
@@ -53,6 +53,12 @@ __device__ __forceinline__ SplitPair split8(const float4& p, const float4& q) {
 
 __device__ __forceinline__ int swz(int row, int slot) { return (row << 7) + ((slot ^ ((row >> 1) & 7)) << 4); }
 
+// Channel order inside a 32-channel chunk of the bf16 images: the 16-byte slot g (k-group of lane-group g) holds
+// channels {4g..4g+3} and {16+4g..16+4g+3}.  Any permutation is legal as long as A and B agree (the MFMA sums over
+// k); this one lets a lane fetch its 8 A values as two 16-byte pieces at fp32 slots g and 4+g of a row that is kept
+// in natural fp32 order in LDS (gemm_glds_bf16), the same conflict-free slot pattern as the split hi/lo image.
+__device__ __host__ __forceinline__ int kperm(int p) { const int slot = p >> 3, j = p & 7; return (j < 4) ? 4 * slot + j : 16 + 4 * slot + (j - 4); }
+
 template <int NSPLIT>
 __global__ __launch_bounds__(256, 2) void gemm_tile_bf16(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
@@ -83,12 +89,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_bf16(GemmArgs a) {
     {                                                                                             \
         const int idx = tid + (i) * 256;                                                          \
         const int r = idx >> 2, g = idx & 3;                                                      \
-        const int row = m0 - P + r, c = ch_ * 32 + g * 8;                                         \
+        const int row = m0 - P + r, c = ch_ * 32 + g * 4;            /* kperm: {4g..} and {16+4g..} */ \
         P_ = z4; Q_ = z4;                                                                         \
-        if (idx < a_items && row >= 0 && row < a.R && c < a.C) {                                  \
+        if (idx < a_items && row >= 0 && row < a.R) {                                             \
             const float* src = a.X + (size_t)row * a.ldx + c;                                     \
-            P_ = *reinterpret_cast<const float4*>(src);                                           \
-            Q_ = *reinterpret_cast<const float4*>(src + 4);                                       \
+            if (c < a.C) P_ = *reinterpret_cast<const float4*>(src);                              \
+            if (c + 16 < a.C) Q_ = *reinterpret_cast<const float4*>(src + 16);                    \
         }                                                                                         \
     }
 #define FS2_GLOAD_A(chunk_) { const int ch_ = (chunk_); FS2_GLOAD_A1(0, ap0, aq0) FS2_GLOAD_A1(1, ap1, aq1) FS2_GLOAD_A1(2, ap2, aq2) }
@@ -103,63 +109,58 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_bf16(GemmArgs a) {
         }                                                                                         \
     }
 #define FS2_STORE_A() { FS2_STORE_A1(0, ap0, aq0) FS2_STORE_A1(1, ap1, aq1) FS2_STORE_A1(2, ap2, aq2) }
-#define FS2_GLOAD_B1(i, V_)                                                                       \
-    {                                                                                             \
-        const int idx = tid + (i) * 256;                                                          \
-        V_ = *reinterpret_cast<const uint4*>(wsrc_ + (size_t)(idx >> 3) * wrow_ + (idx & 7) * 8); \
-    }
-#define FS2_GLOAD_B(it_)                                                                          \
-    {                                                                                             \
-        const int c_ = (it_) / a.ktaps, t_ = (it_) - c_ * a.ktaps;                                \
-        const size_t wrow_ = (size_t)a.ktaps * nchunks * 64;                                      \
-        const __bf16* wsrc_ = Wb + ((size_t)n0 * a.ktaps + t_) * nchunks * 64 + (size_t)c_ * 64;  \
-        FS2_GLOAD_B1(0, b0) FS2_GLOAD_B1(1, b1) FS2_GLOAD_B1(2, b2) FS2_GLOAD_B1(3, b3)           \
-    }
+#define FS2_GLOAD_B1(i, V_) { V_ = *reinterpret_cast<const uint4*>(wp + (size_t)(i) * wstride); }
+#define FS2_GLOAD_B() { FS2_GLOAD_B1(0, b0) FS2_GLOAD_B1(1, b1) FS2_GLOAD_B1(2, b2) FS2_GLOAD_B1(3, b3) wp += 64; }
 #define FS2_STORE_B1(i, V_) { const int idx = tid + (i) * 256; *reinterpret_cast<uint4*>(bs_ + swz(idx >> 3, idx & 7)) = V_; }
 #define FS2_STORE_B(buf_) { char* bs_ = Bs0 + (buf_) * (kB16BN * 128); FS2_STORE_B1(0, b0) FS2_STORE_B1(1, b1) FS2_STORE_B1(2, b2) FS2_STORE_B1(3, b3) }
 
+    // this thread's slice of the weight image: row n0 + (tid>>3) (+32 per load), 16-byte slot tid&7, k-step `it`
+    const size_t wstride = (size_t)32 * niter * 64;                 // 32 rows further
+    const __bf16* wp = Wb + ((size_t)(n0 + (tid >> 3)) * niter) * 64 + (tid & 7) * 8;
     // prologue: A(chunk 0) and B(0) staged, B(1) in flight
     FS2_GLOAD_A(0)
-    FS2_GLOAD_B(0)
+    FS2_GLOAD_B()
     FS2_STORE_A()
     FS2_STORE_B(0)
-    if (niter > 1) FS2_GLOAD_B(1)
-    for (int it = 0; it < niter; ++it) {
-        const int chunk = it / a.ktaps, tap = it - chunk * a.ktaps;
-        const bool last_tap = (tap == a.ktaps - 1) && (it + 1 < niter);
-        __syncthreads();   // B(it) [and A(chunk) when tap == 0] visible; every wave is done with step it-1
-        if (it + 1 < niter) {
-            FS2_STORE_B((it + 1) & 1)              // buffer last read in step it-1
-            if (it + 2 < niter) FS2_GLOAD_B(it + 2)
-        }
-        if (last_tap) FS2_GLOAD_A(chunk + 1)       // lands while this step's MFMAs run
-        const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
-        bf16x8_t ah[4], al[4];
+    if (niter > 1) FS2_GLOAD_B()
+    int it = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        for (int tap = 0; tap < a.ktaps; ++tap, ++it) {     // no integer division on the critical path
+            const bool last_tap = (tap == a.ktaps - 1) && (chunk + 1 < nchunks);
+            __syncthreads();   // B(it) [and A(chunk) when tap == 0] visible; every wave is done with step it-1
+            if (it + 1 < niter) {
+                FS2_STORE_B((it + 1) & 1)              // buffer last read in step it-1
+                if (it + 2 < niter) FS2_GLOAD_B()
+            }
+            if (last_tap) FS2_GLOAD_A(chunk + 1)       // lands while this step's MFMAs run
+            const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
+            bf16x8_t ah[4], al[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int r = wm * 64 + mt * 16 + lr + tap;
-            ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
-            if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = wn * 64 + nt * 16 + lr;
-            const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
-            bf16x8_t bl;
-            if (NSPLIT == 3) bl = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
-            // consecutive MFMAs hit different accumulators (dependency distance 4)
-            if (NSPLIT == 3) {
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+            for (int mt = 0; mt < 4; ++mt) {
+                const int r = wm * 64 + mt * 16 + lr + tap;
+                ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
+                if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
             }
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
-        }
-        if (last_tap) {
-            __syncthreads();   // all waves finished reading this chunk's A tile
-            FS2_STORE_A()
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = wn * 64 + nt * 16 + lr;
+                const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
+                bf16x8_t bl;
+                if (NSPLIT == 3) bl = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
+                // consecutive MFMAs hit different accumulators (dependency distance 4)
+                if (NSPLIT == 3) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+            }
+            if (last_tap) {
+                __syncthreads();   // all waves finished reading this chunk's A tile
+                FS2_STORE_A()
+            }
         }
     }
 #undef FS2_GLOAD_A1
@@ -171,6 +172,126 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_bf16(GemmArgs a) {
 #undef FS2_STORE_B1
 #undef FS2_STORE_B
     // epilogue (elementwise): bias, residual, activation, gap rows -> 0
+    tile_epilogue_64x64(a, acc, m0 + wm * 64, n0 + wn * 64, lr, lg, a.relu_pre != 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gemm_glds_bf16: same tile, same math, staged with LDS-DMA (global_load_lds, 16 B per lane, lane j -> base + 16 j;
+// semantics verified by tools/probes/glds_probe.hip).  Nothing is staged through registers, so the kernel fits three
+// workgroups per CU (conv form: 50 KB LDS, <= 168 VGPRs) and one's barrier / DMA phases hide under the others' MFMAs.
+//   * A tile: fp32, natural channel order, row = 128 B, slots XOR-swizzled through the per-lane SOURCE address (the
+//     DMA destination is lane-linear); split into hi/lo bf16 in registers when the MFMA fragment is read
+//     (two ds_read_b128 at slots g and 4+g -> kperm order).  Rows outside [0,R) and channels >= C are fetched from a
+//     16-byte zero constant instead of being predicated (a masked DMA lane would leave stale LDS bytes).
+//   * B tile: the split-bf16 weight image, double-buffered; step it+1's tile is requested right after the barrier
+//     that ends step it-1 and is complete at the next barrier (hipcc drains LDS-DMA at __syncthreads()).
+//   * K1 (ktaps == 1): the A tile changes every step, so it is double-buffered too (68 KB LDS, two workgroups/CU);
+//     conv form: one A buffer, refilled behind an extra barrier once per 32-channel chunk (every ktaps steps).
+typedef __attribute__((address_space(3))) void lds_void_t;
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // DMA source for out-of-range pieces
+
+template <bool K1>
+constexpr size_t glds_lds_bytes() { return (size_t)(K1 ? 2 : 1) * kB16ARows * 128 + 2 * (size_t)kB16BN * 128; }
+
+template <int NSPLIT, bool K1>
+__global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_g[];
+    char* As0 = smem_g;
+    char* Bs0 = smem_g + (K1 ? 2 : 1) * kB16ARows * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nN = (a.N + kB16BN - 1) / kB16BN;
+    const int tn = blockIdx.x % nN, tm = blockIdx.x / nN;
+    const int n0 = tn * kB16BN, m0 = tm * kB16BM;
+    const int P = (a.ktaps - 1) >> 1;
+    const int lr = lane & 15, lg = lane >> 4;
+    const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = a.Cpad / 32;
+    const int niter = nchunks * a.ktaps;
+    const int a_instr = (kB16BM + 2 * P + 7) >> 3;       // 1-KB DMA instructions (8 rows each) of one A tile
+    const int jrow = lane >> 3, jslot = lane & 7;        // this lane's (row, physical slot) inside a DMA instruction
+
+    // A tile of 32-channel chunk `ch` -> buffer `buf`; wave w issues instructions w, w+4, ...
+    auto dma_A = [&](int ch, int buf) {
+        char* base = As0 + buf * (kB16ARows * 128);
+        for (int q = wave; q < a_instr; q += 4) {
+            const int r = q * 8 + jrow;                              // tile row
+            const int s = jslot ^ ((r >> 1) & 7);                    // logical slot (4 floats) stored at this position
+            const int row = m0 - P + r, c = ch * 32 + s * 4;
+            const bool ok = row >= 0 && row < a.R && c < a.C;
+            const float* src = ok ? a.X + (size_t)row * a.ldx + c : g_zero16;
+            __builtin_amdgcn_global_load_lds(src, (lds_void_t*)(base + q * 1024), 16, 0, 0);
+        }
+    };
+    auto dma_B = [&](int it, int buf) {
+        char* base = Bs0 + buf * (kB16BN * 128);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = wave + u * 4;                              // 16 instructions per tile
+            const int n = q * 8 + jrow;
+            const int s = jslot ^ ((n >> 1) & 7);
+            const __bf16* src = Wb + ((size_t)(n0 + n) * niter + it) * 64 + s * 8;
+            __builtin_amdgcn_global_load_lds(src, (lds_void_t*)(base + q * 1024), 16, 0, 0);
+        }
+    };
+
+    dma_A(0, 0);
+    dma_B(0, 0);
+    int it = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        for (int tap = 0; tap < a.ktaps; ++tap, ++it) {
+            __syncthreads();   // DMA of step `it` landed (hipcc waits vmcnt(0) here); every wave is done with step it-1
+            if (it + 1 < niter) {
+                dma_B(it + 1, (it + 1) & 1);
+                if (K1) dma_A(it + 1, (it + 1) & 1);
+            }
+            const char* As = As0 + (K1 ? (it & 1) : 0) * (kB16ARows * 128);
+            const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
+            bf16x8_t ah[4], al[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int r = wm * 64 + mt * 16 + lr + tap;
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(As + swz(r, lg));
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(As + swz(r, 4 + lg));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const __bf16 h0 = (__bf16)x0[j], h1 = (__bf16)x1[j];
+                    ah[mt][j] = h0;
+                    ah[mt][4 + j] = h1;
+                    if (NSPLIT == 3) {
+                        al[mt][j] = (__bf16)(x0[j] - (float)h0);
+                        al[mt][4 + j] = (__bf16)(x1[j] - (float)h1);
+                    }
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = wn * 64 + nt * 16 + lr;
+                const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
+                bf16x8_t bl;
+                if (NSPLIT == 3) bl = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
+                if (NSPLIT == 3) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+            }
+            if (!K1 && tap == a.ktaps - 1 && chunk + 1 < nchunks) {
+                __syncthreads();              // every wave has read its last fragments of this chunk's A tile
+                dma_A(chunk + 1, 0);
+            }
+        }
+    }
     tile_epilogue_64x64(a, acc, m0 + wm * 64, n0 + wn * 64, lr, lg, a.relu_pre != 0);
 }
 
@@ -250,7 +371,7 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
     }
 }
 
-// weights [N][C][k] fp32 -> split bf16 LDS image [Npad][k][nchunks][hi 32 | lo 32]; optional BatchNorm fold.
+// weights [N][C][k] fp32 -> split bf16 LDS image [Npad][nchunks][k][hi 32 | lo 32]; optional BatchNorm fold.
 __global__ void repack_weight_bf16(const float* w, int N, int C, int k, int Npad, int nchunks, const float* bn_g,
                                    const float* bn_v, float bn_eps, __bf16* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -260,7 +381,7 @@ __global__ void repack_weight_bf16(const float* w, int N, int C, int k, int Npad
     const int chunk = (int)((i >> 5) % nchunks);
     const int tap = (int)((i / ((int64_t)32 * nchunks)) % k);
     const int n = (int)(i / ((int64_t)32 * nchunks * k));
-    const int c = chunk * 32 + kk;
+    const int c = chunk * 32 + kperm(kk);
     float v = 0.f;
     if (n < N && c < C) {
         v = w[((size_t)n * C + c) * k + tap];
@@ -268,7 +389,7 @@ __global__ void repack_weight_bf16(const float* w, int N, int C, int k, int Npad
     }
     const __bf16 hi = (__bf16)v;
     const __bf16 lo = (__bf16)(v - (float)hi);
-    const size_t base = (((size_t)n * k + tap) * nchunks + chunk) * 64;
+    const size_t base = (((size_t)n * nchunks + chunk) * k + tap) * 64;     // k-step order: it = chunk * k + tap
     out[base + kk] = hi;
     out[base + 32 + kk] = lo;
 }

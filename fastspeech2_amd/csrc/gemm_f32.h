@@ -62,18 +62,18 @@ __global__ __launch_bounds__(256) void gemm_tile_f32(GemmArgs a) {
     const int niter = nchunks * a.ktaps;
     constexpr int BREG = kTileBN * (kBK / 4) / 256;   // 4 float4 per thread
     f32x4 breg[BREG];    // native vector type: stays in registers (common.h note)
-#define FS2_GLOAD_B(it_)                                                                                     \
+#define FS2_GLOAD_B(c_, t_)                                                                                  \
     {                                                                                                        \
-        const int c_ = (it_) / a.ktaps, t_ = (it_) - c_ * a.ktaps;                                           \
         _Pragma("unroll") for (int i = 0; i < BREG; ++i) {                                                   \
             const int idx = tid + i * 256;                                                                   \
-            breg[i] = *reinterpret_cast<const f32x4*>(a.W + ((size_t)(n0 + (idx >> 3)) * a.ktaps + t_) * a.Cpad + \
-                                                       c_ * kBK + (idx & 7) * 4);                            \
+            breg[i] = *reinterpret_cast<const f32x4*>(a.W + ((size_t)(n0 + (idx >> 3)) * a.ktaps + (t_)) * a.Cpad + \
+                                                       (c_) * kBK + (idx & 7) * 4);                          \
         }                                                                                                    \
     }
-    FS2_GLOAD_B(0)
-    for (int it = 0; it < niter; ++it) {
-        const int chunk = it / a.ktaps, tap = it - chunk * a.ktaps;
+    FS2_GLOAD_B(0, 0)
+    int it = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk)
+    for (int tap = 0; tap < a.ktaps; ++tap, ++it) {       // nested loops: no integer division per k-step
         __syncthreads();   // everyone finished reading As/Bs of the previous iteration
         if (tap == 0) stage_A(As, a, m0 - P, kTileBM + 2 * P, chunk * kBK, tid, 256);
 #pragma unroll
@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256) void gemm_tile_f32(GemmArgs a) {
             *reinterpret_cast<f32x4*>(Bs + (idx >> 3) * kLd + (idx & 7) * 4) = breg[i];
         }
         __syncthreads();
-        if (it + 1 < niter) FS2_GLOAD_B(it + 1)
+        if (it + 1 < niter) {
+            if (tap + 1 < a.ktaps) FS2_GLOAD_B(chunk, tap + 1) else FS2_GLOAD_B(chunk + 1, 0)
+        }
 #pragma unroll
         for (int kk = 0; kk < kBK / 16; ++kk) {
             f32x4 af[4], bf[4];
@@ -141,18 +143,18 @@ __global__ __launch_bounds__(256) void gemm_rows_f32(GemmArgs a) {
     constexpr int NB4 = BN * (kBK / 4);                 // float4 per B tile
     constexpr int BREG = (NB4 + 255) / 256;
     f32x4 breg[BREG];
-#define FS2_GLOAD_B(it_)                                                                                     \
+#define FS2_GLOAD_B(c_, t_)                                                                                  \
     {                                                                                                        \
-        const int c_ = (it_) / a.ktaps, t_ = (it_) - c_ * a.ktaps;                                           \
         _Pragma("unroll") for (int i = 0; i < BREG; ++i) {                                                   \
             const int idx = tid + i * 256;                                                                   \
             if (idx < NB4)                                                                                   \
-                breg[i] = *reinterpret_cast<const f32x4*>(a.W + ((size_t)(idx >> 3) * a.ktaps + t_) * a.Cpad + c_ * kBK + (idx & 7) * 4); \
+                breg[i] = *reinterpret_cast<const f32x4*>(a.W + ((size_t)(idx >> 3) * a.ktaps + (t_)) * a.Cpad + (c_) * kBK + (idx & 7) * 4); \
         }                                                                                                    \
     }
-    FS2_GLOAD_B(0)
-    for (int it = 0; it < niter; ++it) {
-        const int chunk = it / a.ktaps, tap = it - chunk * a.ktaps;
+    FS2_GLOAD_B(0, 0)
+    int it = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk)
+    for (int tap = 0; tap < a.ktaps; ++tap, ++it) {
         __syncthreads();
         if (tap == 0) stage_A(As, a, m0 - P, kRowsBM + 2 * P, chunk * kBK, tid, 256);
 #pragma unroll
@@ -161,7 +163,9 @@ __global__ __launch_bounds__(256) void gemm_rows_f32(GemmArgs a) {
             if (idx < NB4) *reinterpret_cast<f32x4*>(Bs + (idx >> 3) * kLd + (idx & 7) * 4) = breg[i];
         }
         __syncthreads();
-        if (it + 1 < niter) FS2_GLOAD_B(it + 1)
+        if (it + 1 < niter) {
+            if (tap + 1 < a.ktaps) FS2_GLOAD_B(chunk, tap + 1) else FS2_GLOAD_B(chunk + 1, 0)
+        }
 #pragma unroll
         for (int kk = 0; kk < kBK / 16; ++kk) {
             const float4 af = *reinterpret_cast<const float4*>(As + (wave * 16 + lr + tap) * kLd + kk * 16 + lg * 4);

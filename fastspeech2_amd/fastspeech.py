@@ -464,10 +464,12 @@ class FeedForwardTransformer(nn.Module):
 
 
 def _profile_methods():
-    def set_profiling(self, on=True):
-        """hipEvent timing of every kernel launch on the caller's stream (fs2_set_profiling)."""
+    def set_profiling(self, on=True, only=None):
+        """hipEvent timing of kernel launches on the caller's stream (fs2_set_profiling); ``only`` = name of the
+        single launch site to bracket (keeps the event overhead out of a timed region)."""
         if self._handle is None:
             raise RuntimeError("run one forward before enabling profiling (the handle is created lazily)")
+        _lib.check(_lib.lib().fs2_set_profile_filter(self._handle, only.encode() if only else None), self._handle)
         _lib.check(_lib.lib().fs2_set_profiling(self._handle, int(bool(on))), self._handle)
 
     def get_profile(self, cap=65536):

@@ -137,6 +137,7 @@ int fs2_decode(fs2_handle *h, void *stream, const fs2_decode_io *io);
  * fs2_get_profile waits for the events and fills names/ms/flops/bytes (algorithmic work of each launch)
  * up to `cap`; returns the number of records. */
 int fs2_set_profiling(fs2_handle *h, int32_t on);
+int fs2_set_profile_filter(fs2_handle *h, const char *name); /* NULL / "": every launch; else only launches of that name */
 int fs2_get_profile(fs2_handle *h, const char **names, float *ms, double *flops, double *bytes, int32_t cap);
 
 /* ---- single operators, exported for per-kernel parity tests (all pointers device unless noted) ---- */

@@ -219,3 +219,35 @@ def test_errors(env):
     with pytest.raises(ValueError):                                        # olens inconsistent with ds
         model._forward(torch.ones(1, 4, dtype=torch.int64, device="cuda:0"), torch.tensor([4]), torch.tensor([3]),
                        torch.ones(1, 4, dtype=torch.int64), torch.ones(1, 4), torch.ones(1, 4))
+
+
+def test_full_size_c4_length_regulator_stress(env):
+    """BASELINE config c4 (B=256, 32..512 phonemes, ~0.5 M frames, Lmax > 4000, with Postnet): frame counts,
+    zero pads, sorted + exact length-regulator indices for every utterance, and one mid-length utterance against
+    the oracle.  Utterances longer than the 5000-row positional table force the table to be extended."""
+    model, sd, cfg, O = env
+    from fastspeech2_amd.synthetic import make_batch
+    b = make_batch("c4")
+    model.precision = "bf16x3"
+    try:
+        with torch.no_grad():
+            r = model._run(b["xs"].cuda(), b["ilens"], is_inference=True, d_override=b["ds"].cuda(), want=("after", "lr_index"))
+    finally:
+        model.precision = "fp32"
+    assert torch.equal(r["olens"], b["olens"])
+    after, lri = r["after"], r["lr_index"].cpu().long()
+    assert torch.isfinite(after).all()
+    ar = torch.arange(after.shape[1], device=after.device).unsqueeze(0)
+    pad = ar >= b["olens"].to(after.device).unsqueeze(1)
+    assert float((after.abs().amax(-1) * pad).max()) == 0.0                       # pads exactly zero
+    for i in range(after.shape[0]):
+        L, T = int(b["olens"][i]), int(b["ilens"][i])
+        idx = lri[i, :L]
+        assert torch.equal(idx, torch.repeat_interleave(torch.arange(T), b["ds"][i, :T])), i   # bit-exact
+        assert (lri[i, L:] == -1).all()
+    i = int(torch.argsort(b["olens"])[len(b["olens"]) // 2])
+    T, L = int(b["ilens"][i]), int(b["olens"][i])
+    o = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], is_inference=True, d_override=b["ds"][i:i + 1, :T])
+    d = _maxabs(after[i, :L], o["after"][0])
+    print("c4: %d frames, Lmax %d, median utterance (L=%d) mel max-abs vs oracle %.2e" % (int(b["olens"].sum()), after.shape[1], L, d))
+    assert d <= MEL_TOL
