@@ -251,3 +251,47 @@ def test_full_size_c4_length_regulator_stress(env):
     d = _maxabs(after[i, :L], o["after"][0])
     print("c4: %d frames, Lmax %d, median utterance (L=%d) mel max-abs vs oracle %.2e" % (int(b["olens"].sum()), after.shape[1], L, d))
     assert d <= MEL_TOL
+
+
+VARIANTS = {
+    "linear_ffn": dict(positionwise_layer_type="linear", positionwise_conv_kernel_size=1),          # modules.py:186-201
+    "plain_posenc": dict(use_scaled_pos_enc=False),                                                 # embedding.py:68-80
+    "no_batchnorm": dict(use_batch_norm=False),
+    "no_postnet": dict(postnet_layers=0),
+    "ddim256_arch": dict(ddim=256, dunits=1024, elayers=2, dlayers=3, postnet_layers=3),            # assets/model.txt era
+    "conv_k3_ffn": dict(positionwise_conv_kernel_size=3, duration_predictor_layers=3),
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_config_variants_vs_oracle(name, precision):
+    """Non-default hp.model settings the reference supports: same kernels, different
+    shapes / epilogues, each checked against the oracle on a small teacher-forced batch in both parity modes."""
+    from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
+    from fastspeech2_amd.synthetic import portable_state_dict, make_batch
+    from oracle import fs2_oracle as O
+    hp = default_hparams()
+    for k, v in VARIANTS[name].items():
+        hp.model[k] = v
+    model = FeedForwardTransformer(N_PHONEME_SYMBOLS, 80, hp).eval()
+    sd = portable_state_dict(model.state_dict(), seed=3)
+    model.load_state_dict(sd)
+    model = model.to("cuda:0")
+    model.precision = precision
+    cfg = O.config_from_hp(hp, N_PHONEME_SYMBOLS, 80)
+    b = make_batch("c2", B=3, tlens=[40, 23, 57])
+    with torch.no_grad():
+        r = model._run(b["xs"].cuda(), b["ilens"], b["olens"], b["ds"].cuda(), b["es"].cuda(), b["ps"].cuda(),
+                       is_inference=False, want=("before", "after", "e_outs", "p_outs"))
+        x = b["xs"][0, :40].cuda()
+        mel = model.inference(x)                       # free-running single utterance (durations ~0 with random weights)
+    o = O.per_utterance_forward(sd, cfg, b["xs"], b["ilens"], b["ds"], b["es"], b["ps"])
+    d = {k: _maxabs(r[k], o[k]) for k in ("before", "after", "e_outs", "p_outs")}
+    d["d_outs"] = _maxabs(r["d_log"], o["d_outs"])
+    print("variant %s [%s]:" % (name, precision), {k: "%.1e" % v for k, v in d.items()})
+    assert max(d.values()) <= MEL_TOL, d
+    oi = O.padded_forward(sd, cfg, b["xs"][:1, :40], b["ilens"][:1], is_inference=True)
+    if precision == "fp32":
+        assert mel.shape == tuple(oi["after"][0].shape)
+        assert _maxabs(mel, oi["after"][0]) <= MEL_TOL
