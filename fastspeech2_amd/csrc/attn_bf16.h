@@ -196,38 +196,44 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
                 st[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1, qh[c], st[1], 0, 0, 0);
             }
         }
-        // st[t][r] = score of key key0 + 8g + 4t + r for query lr (Q was pre-scaled)
+        // st[t][r] = log2(e) * score of key key0 + 8g + 4t + r for query lr (Q was pre-scaled by log2(e)/sqrt(d_k)),
+        // so the softmax runs on v_exp_f32 (2^x) directly.
         float p[8];
-        float tmax = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = key0 + 8 * lg + 4 * t + r;
-                const float s = (key < klen) ? st[t][r] : -INFINITY;
-                p[t * 4 + r] = s;
-                tmax = fmaxf(tmax, s);
+            for (int r = 0; r < 4; ++r) p[t * 4 + r] = st[t][r];
+        if (key0 + 32 > klen) {            // only the last tile of an utterance has masked keys (wave-uniform branch)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int key = key0 + 8 * lg + 4 * (j >> 2) + (j & 3);
+                if (key >= klen) p[j] = -INFINITY;
             }
+        }
+        float tmax = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = expf(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            p[j] = expf(p[j] - m_new);
+            p[j] = __builtin_amdgcn_exp2f(p[j] - m_new);
             psum += p[j];
         }
         psum += __shfl_xor(psum, 16);
         psum += __shfl_xor(psum, 32);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+        if (__any(m_new != m_run)) {       // some row's running max moved: rescale the accumulators (rare after the first tiles)
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 2^(-inf) = 0 on the first tile
+            l_run *= alpha;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float ar = __shfl(alpha, lg * 4 + r);
+            for (int r = 0; r < 4; ++r) {
+                const float ar = __shfl(alpha, lg * 4 + r);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) o[n][r] *= ar;
+                for (int n = 0; n < NT; ++n) o[n][r] *= ar;
+            }
+            m_run = m_new;
         }
+        l_run += psum;
         bf16x8_t ph, pl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {

@@ -45,6 +45,9 @@ struct GemmArgs {
     const float* dot_w; const float* dot_b; float* dot_out;            // dot_out[row] = v . dot_w + dot_b
     float* Y; int ldy;                     // output [R, ldy] or nullptr
     const void* Wb;                        // split-bf16 weight image (gemm_bf16.h) or nullptr
+    // fused QKV epilogue (bf16 attention operands, attn_bf16.h): when qk_hi != nullptr the tile is not written to Y
+    // but split into bf16 hi/lo planes: columns [0,2D) -> qk_hi/lo [Rvt][2D] (Q scaled by q_scale), [2D,3D) -> V^T [D][Rvt]
+    void *qk_hi, *qk_lo, *vt_hi, *vt_lo; int att_D; int Rvt; float q_scale;
     float* scratch;                        // [R, N] scratch for two-pass epilogues when Y == nullptr
 };
 

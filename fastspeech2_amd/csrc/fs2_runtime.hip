@@ -169,7 +169,7 @@ hipError_t launch_glds_bf16_t(hipStream_t s, const GemmArgs& a) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_bf16<NSPLIT, K1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds_lds_bytes<K1>());
         attr = true;
     }
-    const int nN = (a.N + kB16BN - 1) / kB16BN, nM = (a.R + kB16BM - 1) / kB16BM;
+    const int nN = (a.N + kB16BN - 1) / kB16BN, nM = ((a.qk_hi ? a.Rvt : a.R) + kB16BM - 1) / kB16BM;
     hipLaunchKernelGGL((gemm_glds_bf16<NSPLIT, K1>), dim3(nN * nM), dim3(256), glds_lds_bytes<K1>(), s, a);
     return hipGetLastError();
 }
@@ -186,7 +186,7 @@ bool use_glds(int ktaps) { const int c = gemm_choice(); return c == 1 || (c == 0
 
 template <int NSPLIT>
 hipError_t launch_tile_bf16(hipStream_t s, const GemmArgs& a) {
-    if (use_glds(a.ktaps)) return a.ktaps == 1 ? launch_glds_bf16_t<NSPLIT, true>(s, a) : launch_glds_bf16_t<NSPLIT, false>(s, a);
+    if (use_glds(a.ktaps) || a.qk_hi) return a.ktaps == 1 ? launch_glds_bf16_t<NSPLIT, true>(s, a) : launch_glds_bf16_t<NSPLIT, false>(s, a);
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_bf16<NSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kB16Lds);
@@ -212,8 +212,9 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         if (a.C % 8 != 0 || a.N % 4 != 0 || (need_rows && a.N > 1024)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: bf16 path needs C %% 8 == 0, N %% 4 == 0 (N <= 1024 with a row epilogue)", name);
         GemmArgs t = a;
         t.W = reinterpret_cast<const float*>(a.Wb);
-        if (!t.Y) { t.Y = a.scratch; t.ldy = a.N; }
-        if (!t.Y) return fail(h, FS2_ERR_ARG, "%s: no output or scratch buffer", name);
+        if (!t.Y && !t.qk_hi) { t.Y = a.scratch; t.ldy = a.N; }
+        if (!t.Y && !t.qk_hi) return fail(h, FS2_ERR_ARG, "%s: no output or scratch buffer", name);
+        if (t.qk_hi && (a.ktaps != 1 || a.att_D % kB16BN != 0 || a.N != 3 * a.att_D)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: fused QKV split needs D %% 128 == 0", name);
         if (need_rows) t.act_post = 0;
         {
             Scope sc(h, s, name, flops, bytes);
@@ -228,9 +229,28 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
             hipLaunchKernelGGL(ln_rows, dim3((a.R + 3) / 4), dim3(256), 0, s, r);
             e = hipGetLastError();
         }
+    } else if (need_rows && a.N >= 128 && a.N <= 1024 && a.N % 4 == 0 && (a.Y || a.scratch) && !getenv("FS2_F32_ROWS")) {
+        // fp32, LayerNorm-terminated: 128x128 MFMA tiles + the HBM-bound row kernel (2x faster than the row-complete
+        // GEMM, whose 16-rows-per-wave shape re-stages the whole weight matrix for every 64 rows)
+        GemmArgs t = a;
+        if (!t.Y) { t.Y = a.scratch; t.ldy = a.N; }
+        t.act_post = 0;
+        {
+            Scope sc(h, s, name, flops, bytes);
+            e = launch_tile(s, t);
+        }
+        if (e == hipSuccess) {
+            char nm[112];
+            snprintf(nm, sizeof nm, "%s.rows", name);
+            Scope sc(h, s, nm, 0.0, 8.0 * a.R * a.N);
+            GemmArgs r = a;
+            r.Y = t.Y; r.ldy = t.ldy;
+            hipLaunchKernelGGL(ln_rows, dim3((a.R + 3) / 4), dim3(256), 0, s, r);
+            e = hipGetLastError();
+        }
     } else {
         Scope sc(h, s, name, flops, bytes);
-        if (need_rows || a.relu_pre || (a.N < 128 && rows_supported(a.N))) {
+        if (need_rows || (a.N < 128 && rows_supported(a.N))) {
             if (!rows_supported(a.N)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: row-epilogue GEMM needs N in {80,256,384}, got %d", name, a.N);
             if (a.N == 80) e = launch_rows<5>(s, a);
             else if (a.N == 256) e = launch_rows<16>(s, a);
@@ -297,14 +317,14 @@ int launch_attention_b16(fs2_handle* h, hipStream_t s, const char* name, const f
                          __bf16* vtl) {
     const int dk = D / heads;
     if (nwork == 0) return FS2_OK;
-    {
+    if (qkv != nullptr) {
         char nm[112];
         snprintf(nm, sizeof nm, "%s.split", name);
         Scope sc(h, s, nm, 0.0, 4.0 * R * 3.0 * D * 2);
         static bool attr = false;
         if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_split), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (1024 + 1) * 4); attr = true; }
         QkvSplitArgs q;
-        q.qkv = qkv; q.R = R; q.Rvt = Rvt; q.D = D; q.dk = dk; q.scale = 1.0f / sqrtf((float)dk);
+        q.qkv = qkv; q.R = R; q.Rvt = Rvt; q.D = D; q.dk = dk; q.scale = 1.4426950408889634f / sqrtf((float)dk);   // log2(e)/sqrt(d_k): softmax in base 2
         q.qk_hi = qkh; q.qk_lo = qkl; q.vt_hi = vth; q.vt_lo = vtl;
         if (D > 1024) return fail(h, FS2_ERR_UNSUPPORTED, "attention dim %d > 1024", D);
         hipLaunchKernelGGL(qkv_split, dim3(Rvt / 32), dim3(256), (size_t)32 * (D + 1) * 4, s, q);
@@ -377,10 +397,15 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         int rc;
         snprintf(nm, sizeof nm, "%s.qkv", tag);
         GemmArgs a = gemm_args(ly.qkv, b.x0, D, R, dl.row_pos, b.qkv, 3 * D);
+        const bool fused_split = prec != FS2_PREC_FP32 && D % kB16BN == 0 && gemm_choice() != 2;
+        if (fused_split) {   // bf16 attention operands straight from the GEMM epilogue (no fp32 QKV round trip)
+            a.Y = nullptr; a.qk_hi = b.qkh; a.qk_lo = b.qkl; a.vt_hi = b.vth; a.vt_lo = b.vtl; a.att_D = D; a.Rvt = L.Rpad;
+            a.q_scale = 1.4426950408889634f / sqrtf((float)(D / heads));
+        }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.attn", tag);
         if (prec == FS2_PREC_FP32) rc = launch_attention(h, s, nm, b.qkv, b.ctx, D, heads, dl, (int)L.work.size(), mask_q, att_flops);
-        else rc = launch_attention_b16(h, s, nm, b.qkv, b.ctx, D, heads, R, L.Rpad, dl, (int)L.work.size(), mask_q, att_flops, prec, b.qkh, b.qkl, b.vth, b.vtl);
+        else rc = launch_attention_b16(h, s, nm, fused_split ? nullptr : b.qkv, b.ctx, D, heads, R, L.Rpad, dl, (int)L.work.size(), mask_q, att_flops, prec, b.qkh, b.qkl, b.vth, b.vtl);
         if (rc) return rc;
         snprintf(nm, sizeof nm, "%s.out_ln", tag);
         a = gemm_args(ly.out, b.ctx, D, R, dl.row_pos, b.x1, D);

@@ -29,6 +29,9 @@ namespace fs2 {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
+#ifndef FS2_SETPRIO
+#define FS2_SETPRIO 1
+#endif
 constexpr int kB16BM = 128, kB16BN = 128;
 constexpr int kB16ARows = kB16BM + kMaxHalo;
 constexpr size_t kB16Lds = (size_t)kB16ARows * 128 + 2 * (size_t)kB16BN * 128;   // A + double-buffered B = 50 KB
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_bf16(GemmArgs a) {
                 ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
                 if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
             }
+            if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);     // favour the wave that is feeding the matrix pipe
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int n = wn * 64 + nt * 16 + lr;
@@ -157,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_bf16(GemmArgs a) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
             }
+            if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
             if (last_tap) {
                 __syncthreads();   // all waves finished reading this chunk's A tile
                 FS2_STORE_A()
@@ -173,6 +178,73 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_bf16(GemmArgs a) {
 #undef FS2_STORE_B
     // epilogue (elementwise): bias, residual, activation, gap rows -> 0
     tile_epilogue_64x64(a, acc, m0 + wm * 64, n0 + wn * 64, lr, lg, a.relu_pre != 0);
+}
+
+// Fused QKV epilogue: the 128 x 128 fp32 tile (+bias) goes through LDS once and leaves as the split-bf16 attention
+// operands, 16 bytes per store: Q|K columns row-major (8 consecutive columns of one row per lane), V columns
+// transposed (8 consecutive rows of one column per lane -> V^T [D][Rvt], key index contiguous).  Rows that are gaps
+// or beyond R are written as zeros (P = 0 times a non-finite V would poison the P.V sum).
+constexpr int kQkvLd = kB16BN + 4;      // fp32 tile row stride in LDS (floats)
+__device__ __forceinline__ void qkv_split_epilogue(const GemmArgs& a, f32x4 (&acc)[4][4], float* tile, int m0, int n0, int wm, int wn,
+                                                   int lr, int lg, int tid) {
+    const float* __restrict__ biasp = a.bias;
+    const int* __restrict__ rpos = a.row_pos;
+    __syncthreads();                      // the operand buffers are dead: reuse them for the output tile
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int cl = wn * 64 + nt * 16 + lr;
+        const float bv = (biasp && n0 + cl < a.N) ? biasp[n0 + cl] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[(wm * 64 + mt * 16 + lg * 4 + r) * kQkvLd + cl] = acc[mt][nt][r] + bv;
+    }
+    __syncthreads();
+    const int D = a.att_D;
+    __bf16* qkh = reinterpret_cast<__bf16*>(a.qk_hi);
+    __bf16* qkl = reinterpret_cast<__bf16*>(a.qk_lo);
+    __bf16* vth = reinterpret_cast<__bf16*>(a.vt_hi);
+    __bf16* vtl = reinterpret_cast<__bf16*>(a.vt_lo);
+    if (n0 < 2 * D) {                     // Q | K tile (tiles never straddle 2D: D is a multiple of 128)
+        const float sc = (n0 < D) ? a.q_scale : 1.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = tid + u * 256;
+            const int r = idx >> 4, c = (idx & 15) * 8;
+            const int row = m0 + r;
+            if (row >= a.Rvt) continue;
+            const bool ok = row < a.R && (rpos == nullptr || rpos[row] >= 0);
+            const float* t = tile + r * kQkvLd + c;
+            float4 p = *reinterpret_cast<const float4*>(t), q = *reinterpret_cast<const float4*>(t + 4);
+            const float f = ok ? sc : 0.f;
+            p.x *= f; p.y *= f; p.z *= f; p.w *= f; q.x *= f; q.y *= f; q.z *= f; q.w *= f;
+            const SplitPair sp = split8(p, q);
+            const size_t off = (size_t)row * 2 * D + n0 + c;
+            *reinterpret_cast<uint4*>(qkh + off) = sp.hi;
+            *reinterpret_cast<uint4*>(qkl + off) = sp.lo;
+        }
+    } else {                              // V tile -> V^T
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = tid + u * 256;
+            // column c, rows 8j .. 8j+7 of the tile; 4 consecutive lanes share a column (64-byte V^T segments),
+            // consecutive lane quads take consecutive columns (different LDS banks)
+            const int c = (idx >> 2) & 127, j = ((idx >> 9) << 2) | (idx & 3);
+            const int row = m0 + 8 * j;
+            if (row >= a.Rvt) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int rr = row + e;
+                const bool ok = rr < a.R && (rpos == nullptr || rpos[rr] >= 0);
+                v[e] = ok ? tile[(8 * j + e) * kQkvLd + c] : 0.f;
+            }
+            const SplitPair sp = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+            const size_t off = (size_t)(n0 - 2 * D + c) * a.Rvt + row;
+            *reinterpret_cast<uint4*>(vth + off) = sp.hi;
+            *reinterpret_cast<uint4*>(vtl + off) = sp.lo;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -292,7 +364,8 @@ __global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
             }
         }
     }
-    tile_epilogue_64x64(a, acc, m0 + wm * 64, n0 + wn * 64, lr, lg, a.relu_pre != 0);
+    if (K1 && a.qk_hi != nullptr) qkv_split_epilogue(a, acc, reinterpret_cast<float*>(smem_g), m0, n0, wm, wn, lr, lg, tid);
+    else tile_epilogue_64x64(a, acc, m0 + wm * 64, n0 + wn * 64, lr, lg, a.relu_pre != 0);
 }
 
 // Row epilogue as its own HBM-bound kernel (used after gemm_tile_bf16 when the op ends in a LayerNorm, a

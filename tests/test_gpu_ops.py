@@ -86,6 +86,14 @@ def test_conv_gemm(case, precision):
         assert derr < tol, "dot head max-abs %g" % derr
 
 
+@pytest.mark.parametrize("case", [c for c in CASES if c[7] is not None], ids=[c[-1] for c in CASES if c[7] is not None])
+def test_conv_gemm_fp32_row_complete_kernel(case, monkeypatch):
+    """The row-complete fp32 GEMM (LayerNorm inside the MFMA epilogue) is no longer the default for N >= 128;
+    keep it covered."""
+    monkeypatch.setenv("FS2_F32_ROWS", "1")
+    test_conv_gemm(case, "fp32")
+
+
 def test_conv_gemm_transpose_detecting():
     """A = identity-like with an ASYMMETRIC weight: catches a swapped C/D row<->col mapping."""
     from tests import ops_binding as ops
