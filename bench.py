@@ -94,8 +94,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("FS2_FORCE_DIST") == "1"    # FS2_FORCE_DIST: exercise the RCCL path with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
@@ -118,7 +120,7 @@ def main():
 
     def step():
         mel, olens = model.inference_batch(xs, il)
-        if world > 1:
+        if use_dist:
             mel, olens = gather_mels(mel, olens, index, B * world)
         return mel, olens
 
@@ -138,19 +140,19 @@ def main():
         dom_site = max(scout.items(), key=lambda kv: kv[1])[0]
         kernel_ms_per_step = sum(scout.values())
         model.set_profiling(True, only=None if args.profile_kernels else dom_site)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             mel, olens_all = step()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         dt = time.perf_counter() - t0
         prof = model.get_profile()
         model.set_profiling(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -213,7 +215,7 @@ def main():
             line["vs_cpu"] = round(line["value"] / cb["value"], 1)
             line["mel_max_abs_diff"] = worst
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

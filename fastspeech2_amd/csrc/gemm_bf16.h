@@ -28,6 +28,7 @@
 namespace fs2 {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void_t;
 
 #ifndef FS2_SETPRIO
 #define FS2_SETPRIO 1
@@ -63,7 +64,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row << 7) + ((sl
 __device__ __host__ __forceinline__ int kperm(int p) { const int slot = p >> 3, j = p & 7; return (j < 4) ? 4 * slot + j : 16 + 4 * slot + (j - 4); }
 
 template <int NSPLIT>
-__global__ __launch_bounds__(256, 2) void gemm_tile_bf16(GemmArgs a) {
+__global__ __launch_bounds__(256, 3) void gemm_tile_bf16(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     char* As = smem_b;
     char* Bs0 = smem_b + kB16ARows * 128;
@@ -117,24 +118,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_bf16(GemmArgs a) {
 #define FS2_STORE_B1(i, V_) { const int idx = tid + (i) * 256; *reinterpret_cast<uint4*>(bs_ + swz(idx >> 3, idx & 7)) = V_; }
 #define FS2_STORE_B(buf_) { char* bs_ = Bs0 + (buf_) * (kB16BN * 128); FS2_STORE_B1(0, b0) FS2_STORE_B1(1, b1) FS2_STORE_B1(2, b2) FS2_STORE_B1(3, b3) }
 
-    // this thread's slice of the weight image: row n0 + (tid>>3) (+32 per load), 16-byte slot tid&7, k-step `it`
-    const size_t wstride = (size_t)32 * niter * 64;                 // 32 rows further
-    const __bf16* wp = Wb + ((size_t)(n0 + (tid >> 3)) * niter) * 64 + (tid & 7) * 8;
-    // prologue: A(chunk 0) and B(0) staged, B(1) in flight
+    // B tiles go global -> LDS by DMA (no staging registers, no ds_write): wave w issues 1-KB instructions w, w+4, ...;
+    // lane j of an instruction fills (row 8q + (j>>3), physical slot j&7), i.e. fetches the logical slot (j&7)^swizzle.
+    const int jrow = lane >> 3, jslot = lane & 7;
+    // rows wave*8 + jrow + 32u, u = 0..3: the swizzle term ((n >> 1) & 7) does not depend on u, so one pointer + a
+    // uniform stride addresses all four instructions
+    const int nb = wave * 8 + jrow;
+    const __bf16* wlane0 = Wb + ((size_t)(n0 + nb) * niter) * 64 + (jslot ^ ((nb >> 1) & 7)) * 8;
+    const size_t wustride = (size_t)32 * niter * 64;
+#define FS2_DMA_B(it_, buf_)                                                                                      \
+    {                                                                                                             \
+        char* bb_ = Bs0 + (buf_) * (kB16BN * 128);                                                                \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                             \
+            __builtin_amdgcn_global_load_lds(wlane0 + u * wustride + (size_t)(it_) * 64, (lds_void_t*)(bb_ + (wave + u * 4) * 1024), 16, 0, 0); \
+    }
+    // prologue: A(chunk 0) and B(0) staged
     FS2_GLOAD_A(0)
-    FS2_GLOAD_B()
+    FS2_DMA_B(0, 0)
     FS2_STORE_A()
-    FS2_STORE_B(0)
-    if (niter > 1) FS2_GLOAD_B()
     int it = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         for (int tap = 0; tap < a.ktaps; ++tap, ++it) {     // no integer division on the critical path
             const bool last_tap = (tap == a.ktaps - 1) && (chunk + 1 < nchunks);
-            __syncthreads();   // B(it) [and A(chunk) when tap == 0] visible; every wave is done with step it-1
-            if (it + 1 < niter) {
-                FS2_STORE_B((it + 1) & 1)              // buffer last read in step it-1
-                if (it + 2 < niter) FS2_GLOAD_B()
-            }
+            __syncthreads();   // DMA of B(it) landed (drained at the barrier), A(chunk) visible; step it-1 is finished
+            if (it + 1 < niter) FS2_DMA_B(it + 1, (it + 1) & 1)      // buffer last read in step it-1
             if (last_tap) FS2_GLOAD_A(chunk + 1)       // lands while this step's MFMAs run
             const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
             bf16x8_t ah[4], al[4];
@@ -168,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_bf16(GemmArgs a) {
             }
         }
     }
+#undef FS2_DMA_B
 #undef FS2_GLOAD_A1
 #undef FS2_GLOAD_A
 #undef FS2_STORE_A1
@@ -259,7 +267,6 @@ __device__ __forceinline__ void qkv_split_epilogue(const GemmArgs& a, f32x4 (&ac
 //     that ends step it-1 and is complete at the next barrier (hipcc drains LDS-DMA at __syncthreads()).
 //   * K1 (ktaps == 1): the A tile changes every step, so it is double-buffered too (68 KB LDS, two workgroups/CU);
 //     conv form: one A buffer, refilled behind an extra barrier once per 32-channel chunk (every ktaps steps).
-typedef __attribute__((address_space(3))) void lds_void_t;
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // DMA source for out-of-range pieces
 
 template <bool K1>

@@ -33,40 +33,72 @@ def shard_indices(ilens, world_size, costs=None):
     return [sorted(p) for p in parts]
 
 
+def _segments(lengths_dev, total):
+    """For ragged segments of the given lengths (device int64 [n], sum == total, known on the host):
+    (segment id, position inside the segment) of every element, computed on the device without a sync."""
+    n = lengths_dev.numel()
+    seg = torch.repeat_interleave(torch.arange(n, device=lengths_dev.device), lengths_dev, output_size=total)
+    start = torch.cumsum(lengths_dev, 0) - lengths_dev
+    pos = torch.arange(total, device=lengths_dev.device) - start[seg]
+    return seg, pos
+
+
 def gather_mels(mel_local, olens_local, index_local, total, group=None):
     """All-gather the ragged per-rank mel batches and restore the original utterance order.
 
     mel_local [b, L_local, odim] (pads zero), olens_local [b] (host or device), index_local: the global
     utterance index of each local row.  Returns (mels [total, Lmax, odim] on mel_local's device, olens
-    [total] int64 on the host).  Two collectives: a tiny one for (count, Lmax, olens, index) metadata and
-    one equal-count all_gather_into_tensor of the mels padded to the global (bmax, Lmax)."""
+    [total] int64 on the host).
+
+    Only VALID frames travel: each rank packs its utterances back to back ([frames, odim], 2-3x fewer bytes
+    than the padded batch), the packs are padded to the largest rank's frame count for one equal-count
+    all_gather_into_tensor (RCCL over xGMI), and every rank scatters the received rows into the padded,
+    ordered result with device-side index arithmetic.  A small all-gather of (count, olens, index)
+    metadata precedes it (its host read-back sizes the buffers)."""
     world = dist.get_world_size(group)
     dev = mel_local.device
     odim = mel_local.shape[-1]
-    b = mel_local.shape[0]
-    cap = (total + world - 1) // world + total          # generous upper bound on any rank's share
-    meta = torch.full((2 + 2 * cap,), -1, dtype=torch.int64, device=dev)
-    meta[0], meta[1] = b, mel_local.shape[1]
-    meta[2:2 + b] = torch.as_tensor(olens_local, dtype=torch.int64).to(dev)
-    meta[2 + cap:2 + cap + b] = torch.as_tensor(index_local, dtype=torch.int64).to(dev)
+    b, Lloc = mel_local.shape[0], mel_local.shape[1]
+    cap = total                                         # upper bound on any rank's utterance count
+    ol_loc = torch.as_tensor(olens_local, dtype=torch.int64)
+    meta = torch.full((1 + 2 * cap,), -1, dtype=torch.int64)
+    meta[0] = b
+    meta[1:1 + b] = ol_loc.cpu()
+    meta[1 + cap:1 + cap + b] = torch.as_tensor(index_local, dtype=torch.int64)
+    meta = meta.to(dev)
     metas = torch.empty(world * meta.numel(), dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(metas, meta, group=group)
-    metas = metas.view(world, -1).cpu()
-    bmax = int(metas[:, 0].max())
-    Lmax = int(metas[:, 2:2 + cap].max())
-    send = mel_local.new_zeros(bmax, Lmax, odim)
-    send[:b, : mel_local.shape[1]] = mel_local
-    recv = mel_local.new_empty(world * bmax, Lmax, odim)
+    metas = metas.view(world, -1).cpu()                 # host needs the sizes (one sync per gather)
+    counts = metas[:, 0].tolist()
+    ol_all = [metas[r, 1:1 + counts[r]] for r in range(world)]
+    gidx_all = [metas[r, 1 + cap:1 + cap + counts[r]] for r in range(world)]
+    nfr = [int(o.sum()) for o in ol_all]
+    nmax, Lmax = max(max(nfr), 1), max(int(o.max()) if o.numel() else 0 for o in ol_all)
+    rank = dist.get_rank(group)
+    # pack the local valid frames
+    send = mel_local.new_zeros(nmax, odim)
+    if nfr[rank] > 0:
+        seg, pos = _segments(ol_loc.to(dev), nfr[rank])
+        send[: nfr[rank]] = mel_local.reshape(b * Lloc, odim).index_select(0, seg * Lloc + pos)
+    recv = mel_local.new_empty(world * nmax, odim)
     dist.all_gather_into_tensor(recv, send, group=group)
-    recv = recv.view(world, bmax, Lmax, odim)
-    out = mel_local.new_zeros(total, Lmax, odim)
+    # scatter every rank's pack into the ordered padded result
+    lens_cat = torch.cat(ol_all).to(dev)
+    gidx_cat = torch.cat(gidx_all).to(dev)
+    rank_of = torch.cat([torch.full((counts[r],), r, dtype=torch.int64) for r in range(world)]).to(dev)
+    nall = sum(nfr)
+    out = mel_local.new_zeros(total * Lmax, odim)
+    if nall > 0:
+        seg, pos = _segments(lens_cat, nall)
+        # offset of each utterance inside its rank's pack
+        start_all = torch.cumsum(lens_cat, 0) - lens_cat
+        rank_base = torch.tensor([sum(nfr[:r]) for r in range(world)], dtype=torch.int64, device=dev)
+        src = rank_of[seg] * nmax + (start_all[seg] - rank_base[rank_of[seg]]) + pos
+        dst = gidx_cat[seg] * Lmax + pos
+        out.index_copy_(0, dst, recv.index_select(0, src))
     olens = torch.zeros(total, dtype=torch.int64)
-    for r in range(world):
-        n = int(metas[r, 0])
-        idx = metas[r, 2 + cap:2 + cap + n]
-        out[idx.to(dev)] = recv[r, :n]
-        olens[idx] = metas[r, 2:2 + n]
-    return out, olens
+    olens[torch.cat(gidx_all)] = torch.cat(ol_all)
+    return out.view(total, Lmax, odim), olens
 
 
 class ShardedSynthesizer:
