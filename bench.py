@@ -101,7 +101,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
-    from fastspeech2_amd.parallel import gather_mels
+    from fastspeech2_amd.parallel import gather_packed
     from fastspeech2_amd.synthetic import portable_state_dict, bias_durations, make_batch
 
     hp = default_hparams()
@@ -119,10 +119,10 @@ def main():
     index = list(range(rank * B, (rank + 1) * B))
 
     def step():
-        mel, olens = model.inference_batch(xs, il)
-        if use_dist:
-            mel, olens = gather_mels(mel, olens, index, B * world)
-        return mel, olens
+        if not use_dist:
+            return model.inference_batch(xs, il)
+        packed, olens = model.inference_batch(xs, il, packed=True)          # valid frames only travel over xGMI
+        return gather_packed(packed, olens, index, B * world)
 
     with torch.no_grad():
         for _ in range(max(args.warmup, 1)):

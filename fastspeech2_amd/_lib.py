@@ -53,7 +53,8 @@ class DecodeIO(C.Structure):
                 ("es", C.c_void_p), ("ps", C.c_void_p), ("es_stride", C.c_int32), ("ps_stride", C.c_int32),
                 ("before", C.c_void_p), ("after", C.c_void_p), ("e_out", C.c_void_p), ("p_out", C.c_void_p),
                 ("qe", C.c_void_p), ("qp", C.c_void_p), ("lr_index", C.c_void_p), ("dec_out", C.c_void_p),
-                ("token_workspace", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("token_workspace", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("after_packed", C.c_void_p)]
 
 
 class OpGemmArgs(C.Structure):
@@ -67,7 +68,7 @@ class OpGemmArgs(C.Structure):
 # every symbol include/fs2.h declares (tests check the library exports all of them)
 EXPORTS = ["fs2_create", "fs2_destroy", "fs2_last_error", "fs2_load_weights", "fs2_token_workspace_bytes",
            "fs2_encode", "fs2_frame_workspace_bytes", "fs2_decode", "fs2_set_profiling", "fs2_set_profile_filter", "fs2_get_profile",
-           "fs2_op_conv_gemm", "fs2_op_attention", "fs2_op_length_regulate", "fs2_op_bucketize"]
+           "fs2_op_conv_gemm", "fs2_op_attention", "fs2_op_length_regulate", "fs2_op_unpack_rows", "fs2_op_bucketize"]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
 
@@ -134,6 +135,8 @@ def lib():
     L.fs2_op_attention.restype = C.c_int
     L.fs2_op_length_regulate.argtypes = [vp, vp, vp, i64p, i32, i32, i32, i32, vp, vp, vp]
     L.fs2_op_length_regulate.restype = C.c_int
+    L.fs2_op_unpack_rows.argtypes = [vp, vp, i32, i32, C.POINTER(i32), C.POINTER(i32), i32, vp]
+    L.fs2_op_unpack_rows.restype = C.c_int
     L.fs2_op_bucketize.argtypes = [vp, vp, C.c_int64, vp, i32, vp]
     L.fs2_op_bucketize.restype = C.c_int
     _lib = L

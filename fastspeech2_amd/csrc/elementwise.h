@@ -214,6 +214,20 @@ __global__ void unpack_rows(const T* src, int W, const int* start, const int* li
     dst[i] = (j < limit[b]) ? src[(size_t)(start[b] + j) * W + w] : fill;
 }
 
+// gapped packed rows -> dense packed rows (valid frames only, utterances back to back): dst row cum[b] + j
+__global__ void pack_rows(const float* src, int W, const int* row_pos, const int* row_seq, const int* vlen, const int* cum, int R,
+                          float* dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w4 = W / 4;
+    if (i >= (int64_t)R * w4) return;
+    const int row = (int)(i / w4), c = (int)(i - (int64_t)row * w4) * 4;
+    const int b = row_seq[row];
+    if (b < 0) return;
+    const int j = row_pos[row];
+    if (j >= vlen[b]) return;
+    *reinterpret_cast<float4*>(dst + (size_t)(cum[b] + j) * W + c) = *reinterpret_cast<const float4*>(src + (size_t)row * W + c);
+}
+
 // ---- weight repacking (run once per load_state_dict) ----
 // conv / linear weight [N][C][k] -> [Npad][k][Cpad], zero padded, optionally scaled per output channel by
 // gamma / sqrt(var + eps) (eval-mode BatchNorm folded into the Postnet convs, reference modules.py:285-348).

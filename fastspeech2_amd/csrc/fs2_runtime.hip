@@ -938,6 +938,17 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         if (io->qp && (rc = unpack<int>(h, s, f.qp, 1, dl.start, lim_len, b.B, io->Lmax, io->qp, -1))) return rc;
         if (io->lr_index && (rc = unpack<int>(h, s, f.lri, 1, dl.start, dl.vlen, b.B, io->Lmax, io->lr_index, -1))) return rc;
         if (io->dec_out && (rc = unpack<float>(h, s, f.sb.x0, c.ddim, dl.start, lim_len, b.B, io->Lmax, io->dec_out, 0.f))) return rc;
+        if (io->after_packed) {
+            if (c.odim % 4) return fail(h, FS2_ERR_UNSUPPORTED, "after_packed needs odim %% 4 == 0");
+            std::vector<int> cum(b.B);
+            int run = 0;
+            for (int i = 0; i < b.B; ++i) { cum[i] = run; run += (int)io->olens[i]; }
+            int* dcum = f.qe;    // the bucket-index rows are already unpacked: reuse their storage for the offsets
+            HIP_TRY(h, hipMemcpyAsync(dcum, cum.data(), cum.size() * sizeof(int), hipMemcpyHostToDevice, s));
+            const int64_t n = (int64_t)R * (c.odim / 4);
+            hipLaunchKernelGGL(pack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mel_after, c.odim, dl.row_pos, dl.row_seq, dl.vlen, dcum, R, io->after_packed);
+            HIP_TRY(h, hipGetLastError());
+        }
     }
     return FS2_OK;
 }
@@ -1044,6 +1055,27 @@ int fs2_op_length_regulate(void* stream, const float* hs, const int64_t* ds, con
     hipStreamSynchronize(s);
     hipFree(dev);
     if (e != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "length_regulate: %s", hipGetErrorString(e));
+    return FS2_OK;
+}
+
+int fs2_op_unpack_rows(void* stream, const float* src, int32_t W, int32_t B, const int32_t* starts, const int32_t* lens, int32_t Lout,
+                       float* dst) {
+    if (!src || !dst || !starts || !lens || B <= 0 || W <= 0 || Lout <= 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_unpack_rows: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    // per-process scratch for the two small index arrays (grown on demand, never freed: a few KB)
+    static int* dev = nullptr; static int cap = 0;
+    if (2 * B > cap) {
+        if (dev) hipFree(dev);
+        cap = std::max(2 * B, 4096);
+        OP_TRY(hipMalloc((void**)&dev, (size_t)cap * sizeof(int)));
+    }
+    std::vector<int> host(2 * B);
+    for (int i = 0; i < B; ++i) { host[i] = starts[i]; host[B + i] = lens[i]; }
+    OP_TRY(hipMemcpyAsync(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    const int64_t total = (int64_t)B * Lout * W;
+    hipLaunchKernelGGL(unpack_rows<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, W, dev, dev + B, B, Lout, dst, 0.f);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "unpack_rows: %s", hipGetErrorString(e));
     return FS2_OK;
 }
 

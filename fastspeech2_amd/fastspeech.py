@@ -375,7 +375,8 @@ class FeedForwardTransformer(nn.Module):
                 buf("e_outs", (B, Lmax)), buf("p_outs", (B, Lmax)),
                 buf("qe", (B, Lmax), torch.int32), buf("qp", (B, Lmax), torch.int32),
                 buf("lr_index", (B, Lmax), torch.int32), buf("decoder_out", (B, Lmax, self._cfg["ddim"])),
-                tok_ws.data_ptr(), frm_ws.data_ptr(), frm_ws.numel())
+                tok_ws.data_ptr(), frm_ws.data_ptr(), frm_ws.numel(),
+                buf("after_packed", (int(ol.sum()), odim)))
             if dio.after is None:
                 raise ValueError("'after' must be requested")
             _lib.check(L.fs2_decode(h, st, C.byref(dio)), h)
@@ -449,11 +450,13 @@ class FeedForwardTransformer(nn.Module):
         r = self._run(x.unsqueeze(0), torch.tensor([x.shape[0]]), is_inference=True, want=("after",))
         return r["after"][0]
 
-    def inference_batch(self, xs, ilens, d_override=None):
+    def inference_batch(self, xs, ilens, d_override=None, packed=False):
         """Batched free-running synthesis (not in the reference, which only has single-utterance
-        ``inference``): per-utterance semantics; returns (mels [B, Lmax, odim], olens [B] on the host)."""
-        r = self._run(xs, ilens, is_inference=True, compat=False, want=("after",), d_override=d_override)
-        return r["after"], r["olens"]
+        ``inference``): per-utterance semantics; returns (mels [B, Lmax, odim], olens [B] on the host), or with
+        ``packed=True`` (valid frames back to back [sum(olens), odim], olens): the form the multi-GPU gather ships."""
+        want = ("after", "after_packed") if packed else ("after",)
+        r = self._run(xs, ilens, is_inference=True, compat=False, want=want, d_override=d_override)
+        return (r["after_packed"] if packed else r["after"]), r["olens"]
 
     def _source_mask(self, ilens):
         """reference fastspeech.py:359-376 (kept for API parity; the kernels take lengths, not masks)."""

@@ -101,6 +101,62 @@ def gather_mels(mel_local, olens_local, index_local, total, group=None):
     return out.view(total, Lmax, odim), olens
 
 
+def unpack_rows(packed, starts, lens, Lout):
+    """packed [n, W] -> [len(lens), Lout, W] zero padded.  HIP kernel (fs2_op_unpack_rows) on the GPU; plain torch on
+    the CPU (only the gloo tests take that branch)."""
+    B, W = len(lens), packed.shape[1]
+    if packed.is_cuda:
+        import ctypes as C
+        from . import _lib
+        out = torch.empty(B, Lout, W, dtype=torch.float32, device=packed.device)
+        arr = lambda v: (C.c_int32 * B)(*[int(i) for i in v])
+        with torch.cuda.device(packed.device):
+            _lib.check(_lib.lib().fs2_op_unpack_rows(C.c_void_p(torch.cuda.current_stream(packed.device).cuda_stream),
+                                                     packed.data_ptr(), W, B, arr(starts), arr(lens), Lout, out.data_ptr()))
+        return out
+    out = packed.new_zeros(B, Lout, W)
+    for i, (s0, L) in enumerate(zip(starts, lens)):
+        out[i, :L] = packed[s0:s0 + L]
+    return out
+
+
+def gather_packed(packed_local, olens_local, index_local, total, group=None):
+    """Same contract as gather_mels for an already packed local batch [sum(olens_local), odim] (what
+    ``FeedForwardTransformer.inference_batch(packed=True)`` returns): metadata all-gather (sizes -> host), one
+    equal-count all_gather_into_tensor of the packs, one unpack kernel into the ordered padded result."""
+    world = dist.get_world_size(group)
+    dev = packed_local.device
+    odim = packed_local.shape[-1]
+    ol_loc = torch.as_tensor(olens_local, dtype=torch.int64).cpu()
+    b, cap = ol_loc.numel(), total
+    meta = torch.full((1 + 2 * cap,), -1, dtype=torch.int64)
+    meta[0] = b
+    meta[1:1 + b] = ol_loc
+    meta[1 + cap:1 + cap + b] = torch.as_tensor(index_local, dtype=torch.int64)
+    meta = meta.to(dev)
+    metas = torch.empty(world * meta.numel(), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(metas, meta, group=group)
+    metas = metas.view(world, -1).cpu()
+    counts = metas[:, 0].tolist()
+    nfr = [int(metas[r, 1:1 + counts[r]].sum()) for r in range(world)]
+    nmax = max(max(nfr), 1)
+    if packed_local.shape[0] == nmax:
+        send = packed_local.contiguous()
+    else:
+        send = packed_local.new_zeros(nmax, odim)
+        send[: packed_local.shape[0]] = packed_local
+    recv = packed_local.new_empty(world * nmax, odim)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    starts = [0] * total
+    lens = [0] * total
+    for r in range(world):
+        off = r * nmax
+        for g, L in zip(metas[r, 1 + cap:1 + cap + counts[r]].tolist(), metas[r, 1:1 + counts[r]].tolist()):
+            starts[g], lens[g] = off, L
+            off += L
+    return unpack_rows(recv, starts, lens, max(lens)), torch.tensor(lens, dtype=torch.int64)
+
+
 class ShardedSynthesizer:
     """Free-running batched synthesis over all ranks of the default process group.
 

@@ -117,6 +117,8 @@ typedef struct fs2_decode_io {
     void *token_workspace;    /* the workspace given to fs2_encode                               */
     void *workspace;          /* device, fs2_frame_workspace_bytes()                              */
     size_t workspace_bytes;
+    float *after_packed;      /* device [sum(olens), odim]: the valid frames of `after`, utterances back to
+                                 back in batch order (what the multi-GPU all-gather ships), or NULL          */
 } fs2_decode_io;
 
 /* lifecycle (replaces FeedForwardTransformer.__init__ / .to(device) / load_state_dict,
@@ -173,6 +175,11 @@ int fs2_op_attention(void *stream, const float *qkv, float *ctx, int32_t D, int3
 int fs2_op_length_regulate(void *stream, const float *hs, const int64_t *ds, const int64_t *ilens_host,
                            int32_t B, int32_t Tmax, int32_t D, int32_t Lmax, float *out, int32_t *index,
                            int64_t *olens);
+
+/* dst [B, Lout, W] <- packed rows src [sum(lens), W] (utterance b = rows [starts[b], starts[b]+lens[b])), zero
+ * padded; starts/lens: HOST [B].  Inverse of fs2_decode_io.after_packed; replaces utils/util.py:91-104 pad_2d_tensor. */
+int fs2_op_unpack_rows(void *stream, const float *src, int32_t W, int32_t B, const int32_t *starts, const int32_t *lens,
+                       int32_t Lout, float *dst);
 
 /* idx[i] = bucketize(x[i], bins[nb]) (right=False, NaN -> nb)  (variance_predictor.py:158,231) */
 int fs2_op_bucketize(void *stream, const float *x, int64_t n, const float *bins, int32_t nb, int32_t *idx);

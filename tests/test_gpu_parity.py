@@ -295,3 +295,21 @@ def test_config_variants_vs_oracle(name, precision):
     if precision == "fp32":
         assert mel.shape == tuple(oi["after"][0].shape)
         assert _maxabs(mel, oi["after"][0]) <= MEL_TOL
+
+
+def test_packed_output_and_unpack_kernel(env):
+    """`after_packed` (valid frames back to back, what the multi-GPU all-gather ships) and its inverse
+    fs2_op_unpack_rows reproduce the padded output bit-for-bit."""
+    model, sd, cfg, O = env
+    from fastspeech2_amd.synthetic import make_batch
+    from fastspeech2_amd.parallel import unpack_rows
+    b = make_batch("c3", B=9)
+    with torch.no_grad():
+        r = model._run(b["xs"].cuda(), b["ilens"], is_inference=True, d_override=b["ds"].cuda(), want=("after", "after_packed"))
+    ol = r["olens"].tolist()
+    assert r["after_packed"].shape == (sum(ol), 80)
+    starts = [sum(ol[:i]) for i in range(len(ol))]
+    for i, (s0, L) in enumerate(zip(starts, ol)):
+        assert torch.equal(r["after_packed"][s0:s0 + L], r["after"][i, :L])
+    back = unpack_rows(r["after_packed"], starts, ol, r["after"].shape[1])
+    assert torch.equal(back, r["after"])

@@ -39,6 +39,14 @@ def _worker(rank, world, port, q):
     from fastspeech2_amd.parallel import ShardedSynthesizer
     xs, il = _make_inputs()
     mel, ol = ShardedSynthesizer(_fake_run_local)(xs, il)
+    # packed form (what bench.py ships over RCCL): same result
+    from fastspeech2_amd.parallel import shard_indices, gather_packed
+    mine = shard_indices(il.tolist(), world)[rank]
+    sel = torch.as_tensor(mine)
+    m_loc, ol_loc = _fake_run_local(xs[sel][:, : int(il[sel].max())], il[sel])
+    packed = torch.cat([m_loc[i, : int(ol_loc[i])] for i in range(len(mine))])
+    mel2, ol2 = gather_packed(packed, ol_loc, mine, xs.shape[0])
+    assert torch.equal(ol2, ol) and torch.equal(mel2, mel[:, : mel2.shape[1]])
     q.put((rank, mel, ol))
     dist.barrier()
     dist.destroy_process_group()
