@@ -66,11 +66,12 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-// Elementwise epilogue of a 64 x 64 wave tile held as acc[4][4] (16 x 16 MFMA tiles, C layout col = l&15,
+// Elementwise epilogue of a (16 MT) x 64 wave tile held as acc[MT][4] (16 x 16 MFMA tiles, C layout col = l&15,
 // row = 4*(l>>4) + reg).  All loads of a 16-row slab (row flags, residual) are issued before its stores and the
 // pointers are __restrict__, so the compiler does not serialise a memory round trip per element behind
 // possibly-aliasing stores (that cost ~25 us per workgroup before).
-__device__ __forceinline__ void tile_epilogue_64x64(const GemmArgs& a, f32x4 (&acc)[4][4], int row_base, int col_base, int lr, int lg,
+template <int MT>
+__device__ __forceinline__ void tile_epilogue_64x64(const GemmArgs& a, f32x4 (&acc)[MT][4], int row_base, int col_base, int lr, int lg,
                                                     bool relu_first) {
     const float* __restrict__ biasp = a.bias;
     const float* __restrict__ residp = a.resid;
@@ -83,7 +84,7 @@ __device__ __forceinline__ void tile_epilogue_64x64(const GemmArgs& a, f32x4 (&a
         bv[nt] = (biasp && col < a.N) ? biasp[col] : 0.f;
     }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         bool inb[4], valid[4];
         float rv[4][4];
 #pragma unroll

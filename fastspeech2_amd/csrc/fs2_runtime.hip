@@ -162,39 +162,58 @@ hipError_t launch_tile(hipStream_t s, const GemmArgs& a) {
 
 bool rows_supported(int N) { return N == 80 || N == 256 || N == 384; }
 
-template <int NSPLIT, bool K1>
+template <int NSPLIT, bool K1, int BM>
 hipError_t launch_glds_bf16_t(hipStream_t s, const GemmArgs& a) {
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_bf16<NSPLIT, K1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds_lds_bytes<K1>());
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_bf16<NSPLIT, K1, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds_lds_bytes<K1, BM>());
         attr = true;
     }
-    const int nN = (a.N + kB16BN - 1) / kB16BN, nM = ((a.qk_hi ? a.Rvt : a.R) + kB16BM - 1) / kB16BM;
-    hipLaunchKernelGGL((gemm_glds_bf16<NSPLIT, K1>), dim3(nN * nM), dim3(256), glds_lds_bytes<K1>(), s, a);
+    const int nN = (a.N + kB16BN - 1) / kB16BN, nM = ((a.qk_hi ? a.Rvt : a.R) + BM - 1) / BM;
+    const size_t lds = glds_lds_bytes<K1, BM>();
+    hipLaunchKernelGGL((gemm_glds_bf16<NSPLIT, K1, BM>), dim3(nN * nM), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
-// Kernel choice per shape (measured on MI355X, c3): the 9-tap FFN conv is ~10 % faster register-staged
+// Kernel choice per shape (measured on MI355X, c3): the 9-tap FFN conv is ~10 % faster with the A tile register-staged
 // (gemm_tile_bf16: the fp32->bf16 split happens once per chunk, not once per tap); k = 1 GEMMs are ~5-15 % faster
-// with LDS-DMA staging (gemm_glds_bf16: A and B double-buffered, no staging registers).  FS2_GEMM=regs|glds forces one.
-int gemm_choice() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FS2_GEMM"); v = !e ? 0 : (!strcmp(e, "glds") ? 1 : (!strcmp(e, "regs") ? 2 : 0)); }
-    return v;
+// with all-DMA staging (gemm_glds_bf16: A and B double-buffered, no staging registers).  FS2_GEMM=regs|glds forces one.
+int gemm_choice() {     // read per launch (a getenv is nanoseconds) so that tests can switch kernels inside one process
+    const char* e = getenv("FS2_GEMM");
+    return !e ? 0 : (!strcmp(e, "glds") ? 1 : (!strcmp(e, "regs") ? 2 : 0));
 }
 bool use_glds(int ktaps) { const int c = gemm_choice(); return c == 1 || (c == 0 && ktaps == 1); }
 
-template <int NSPLIT>
-hipError_t launch_tile_bf16(hipStream_t s, const GemmArgs& a) {
-    if (use_glds(a.ktaps) || a.qk_hi) return a.ktaps == 1 ? launch_glds_bf16_t<NSPLIT, true>(s, a) : launch_glds_bf16_t<NSPLIT, false>(s, a);
+// 64-row tiles when 128-row tiles would leave most of the 256 CUs (x 2-3 workgroups) without work (encoder, small batches)
+bool small_grid(const GemmArgs& a) {
+    const char* e = getenv("FS2_BM");
+    const int force = !e ? 0 : atoi(e);
+    if (force == 64) return true;
+    if (force == 128) return false;
+    const long nN = (a.N + kB16BN - 1) / kB16BN, nM = (a.R + 127) / 128;
+    return nN * nM < 512;
+}
+
+template <int NSPLIT, int BM>
+hipError_t launch_tile_bf16_t(hipStream_t s, const GemmArgs& a) {
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_bf16<NSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kB16Lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_bf16<NSPLIT, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b16_lds<BM>());
         attr = true;
     }
-    dim3 grid((a.N + kB16BN - 1) / kB16BN, (a.R + kB16BM - 1) / kB16BM);
-    hipLaunchKernelGGL(gemm_tile_bf16<NSPLIT>, grid, dim3(256), kB16Lds, s, a);
+    dim3 grid((a.N + kB16BN - 1) / kB16BN, (a.R + BM - 1) / BM);
+    hipLaunchKernelGGL((gemm_tile_bf16<NSPLIT, BM>), grid, dim3(256), b16_lds<BM>(), s, a);
     return hipGetLastError();
+}
+
+template <int NSPLIT>
+hipError_t launch_tile_bf16(hipStream_t s, const GemmArgs& a) {
+    const bool sm = small_grid(a);
+    if (use_glds(a.ktaps) || a.qk_hi) {
+        if (a.ktaps == 1) return sm ? launch_glds_bf16_t<NSPLIT, true, 64>(s, a) : launch_glds_bf16_t<NSPLIT, true, 128>(s, a);
+        return sm ? launch_glds_bf16_t<NSPLIT, false, 64>(s, a) : launch_glds_bf16_t<NSPLIT, false, 128>(s, a);
+    }
+    return sm ? launch_tile_bf16_t<NSPLIT, 64>(s, a) : launch_tile_bf16_t<NSPLIT, 128>(s, a);
 }
 
 // Picks the kernel.  fp32: row-complete tiles when the epilogue needs whole rows, 128x128 tiles otherwise.

@@ -33,9 +33,9 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 #ifndef FS2_SETPRIO
 #define FS2_SETPRIO 1
 #endif
-constexpr int kB16BM = 128, kB16BN = 128;
-constexpr int kB16ARows = kB16BM + kMaxHalo;
-constexpr size_t kB16Lds = (size_t)kB16ARows * 128 + 2 * (size_t)kB16BN * 128;   // A + double-buffered B = 50 KB
+constexpr int kB16BM = 128, kB16BN = 128;     // BM is a template parameter of the kernels: 128, or 64 for small grids
+template <int BM> constexpr int b16_arows() { return BM + kMaxHalo; }
+template <int BM> constexpr size_t b16_lds() { return (size_t)b16_arows<BM>() * 128 + 2 * (size_t)kB16BN * 128; }   // A + double-buffered B
 
 struct SplitPair { uint4 hi, lo; };
 
@@ -63,30 +63,30 @@ __device__ __forceinline__ int swz(int row, int slot) { return (row << 7) + ((sl
 // in natural fp32 order in LDS (gemm_glds_bf16), the same conflict-free slot pattern as the split hi/lo image.
 __device__ __host__ __forceinline__ int kperm(int p) { const int slot = p >> 3, j = p & 7; return (j < 4) ? 4 * slot + j : 16 + 4 * slot + (j - 4); }
 
-template <int NSPLIT>
+template <int NSPLIT, int BM>
 __global__ __launch_bounds__(256, 3) void gemm_tile_bf16(GemmArgs a) {
+    constexpr int MT = BM / 32;          // 16-row MFMA tiles per wave (wave tile = BM/2 x 64)
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     char* As = smem_b;
-    char* Bs0 = smem_b + kB16ARows * 128;
+    char* Bs0 = smem_b + b16_arows<BM>() * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * kB16BN, m0 = blockIdx.y * kB16BM;
+    const int n0 = blockIdx.x * kB16BN, m0 = blockIdx.y * BM;
     const int P = (a.ktaps - 1) >> 1;
     const int lr = lane & 15, lg = lane >> 4;
     const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = a.Cpad / 32;
     const int niter = nchunks * a.ktaps;
-    const int a_items = (kB16BM + 2 * P) * 4;     // (row, k-group of 8) pairs of the A tile
-    // Staging registers are named scalars (an indexed array here ends up in scratch memory).
+    const int a_items = (BM + 2 * P) * 4;     // (row, k-group of 8) pairs of the A tile
+    // Staging registers are named scalars (an indexed array of float4 here ends up in scratch memory).
     float4 ap0, aq0, ap1, aq1, ap2, aq2;
-    uint4 b0, b1, b2, b3;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
 #define FS2_GLOAD_A1(i, P_, Q_)                                                                   \
@@ -113,10 +113,6 @@ __global__ __launch_bounds__(256, 3) void gemm_tile_bf16(GemmArgs a) {
         }                                                                                         \
     }
 #define FS2_STORE_A() { FS2_STORE_A1(0, ap0, aq0) FS2_STORE_A1(1, ap1, aq1) FS2_STORE_A1(2, ap2, aq2) }
-#define FS2_GLOAD_B1(i, V_) { V_ = *reinterpret_cast<const uint4*>(wp + (size_t)(i) * wstride); }
-#define FS2_GLOAD_B() { FS2_GLOAD_B1(0, b0) FS2_GLOAD_B1(1, b1) FS2_GLOAD_B1(2, b2) FS2_GLOAD_B1(3, b3) wp += 64; }
-#define FS2_STORE_B1(i, V_) { const int idx = tid + (i) * 256; *reinterpret_cast<uint4*>(bs_ + swz(idx >> 3, idx & 7)) = V_; }
-#define FS2_STORE_B(buf_) { char* bs_ = Bs0 + (buf_) * (kB16BN * 128); FS2_STORE_B1(0, b0) FS2_STORE_B1(1, b1) FS2_STORE_B1(2, b2) FS2_STORE_B1(3, b3) }
 
     // B tiles go global -> LDS by DMA (no staging registers, no ds_write): wave w issues 1-KB instructions w, w+4, ...;
     // lane j of an instruction fills (row 8q + (j>>3), physical slot j&7), i.e. fetches the logical slot (j&7)^swizzle.
@@ -144,10 +140,10 @@ __global__ __launch_bounds__(256, 3) void gemm_tile_bf16(GemmArgs a) {
             if (it + 1 < niter) FS2_DMA_B(it + 1, (it + 1) & 1)      // buffer last read in step it-1
             if (last_tap) FS2_GLOAD_A(chunk + 1)       // lands while this step's MFMAs run
             const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
-            bf16x8_t ah[4], al[4];
+            bf16x8_t ah[MT], al[MT];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int r = wm * 64 + mt * 16 + lr + tap;
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = wm * (BM / 2) + mt * 16 + lr + tap;
                 ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
                 if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
             }
@@ -158,15 +154,15 @@ __global__ __launch_bounds__(256, 3) void gemm_tile_bf16(GemmArgs a) {
                 const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
                 bf16x8_t bl;
                 if (NSPLIT == 3) bl = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
-                // consecutive MFMAs hit different accumulators (dependency distance 4)
+                // consecutive MFMAs hit different accumulators (dependency distance MT)
                 if (NSPLIT == 3) {
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt][nt], 0, 0, 0);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
                 }
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
             }
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
             if (last_tap) {
@@ -180,12 +176,8 @@ __global__ __launch_bounds__(256, 3) void gemm_tile_bf16(GemmArgs a) {
 #undef FS2_GLOAD_A
 #undef FS2_STORE_A1
 #undef FS2_STORE_A
-#undef FS2_GLOAD_B1
-#undef FS2_GLOAD_B
-#undef FS2_STORE_B1
-#undef FS2_STORE_B
     // epilogue (elementwise): bias, residual, activation, gap rows -> 0
-    tile_epilogue_64x64(a, acc, m0 + wm * 64, n0 + wn * 64, lr, lg, a.relu_pre != 0);
+    tile_epilogue_64x64<MT>(a, acc, m0 + wm * (BM / 2), n0 + wn * 64, lr, lg, a.relu_pre != 0);
 }
 
 // Fused QKV epilogue: the 128 x 128 fp32 tile (+bias) goes through LDS once and leaves as the split-bf16 attention
@@ -193,8 +185,10 @@ __global__ __launch_bounds__(256, 3) void gemm_tile_bf16(GemmArgs a) {
 // transposed (8 consecutive rows of one column per lane -> V^T [D][Rvt], key index contiguous).  Rows that are gaps
 // or beyond R are written as zeros (P = 0 times a non-finite V would poison the P.V sum).
 constexpr int kQkvLd = kB16BN + 4;      // fp32 tile row stride in LDS (floats)
-__device__ __forceinline__ void qkv_split_epilogue(const GemmArgs& a, f32x4 (&acc)[4][4], float* tile, int m0, int n0, int wm, int wn,
+template <int BM>
+__device__ __forceinline__ void qkv_split_epilogue(const GemmArgs& a, f32x4 (&acc)[BM / 32][4], float* tile, int m0, int n0, int wm, int wn,
                                                    int lr, int lg, int tid) {
+    constexpr int MT = BM / 32;
     const float* __restrict__ biasp = a.bias;
     const int* __restrict__ rpos = a.row_pos;
     __syncthreads();                      // the operand buffers are dead: reuse them for the output tile
@@ -203,9 +197,9 @@ __device__ __forceinline__ void qkv_split_epilogue(const GemmArgs& a, f32x4 (&ac
         const int cl = wn * 64 + nt * 16 + lr;
         const float bv = (biasp && n0 + cl < a.N) ? biasp[n0 + cl] : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tile[(wm * 64 + mt * 16 + lg * 4 + r) * kQkvLd + cl] = acc[mt][nt][r] + bv;
+            for (int r = 0; r < 4; ++r) tile[(wm * (BM / 2) + mt * 16 + lg * 4 + r) * kQkvLd + cl] = acc[mt][nt][r] + bv;
     }
     __syncthreads();
     const int D = a.att_D;
@@ -216,7 +210,7 @@ __device__ __forceinline__ void qkv_split_epilogue(const GemmArgs& a, f32x4 (&ac
     if (n0 < 2 * D) {                     // Q | K tile (tiles never straddle 2D: D is a multiple of 128)
         const float sc = (n0 < D) ? a.q_scale : 1.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < BM / 16; ++u) {
             const int idx = tid + u * 256;
             const int r = idx >> 4, c = (idx & 15) * 8;
             const int row = m0 + r;
@@ -233,7 +227,7 @@ __device__ __forceinline__ void qkv_split_epilogue(const GemmArgs& a, f32x4 (&ac
         }
     } else {                              // V tile -> V^T
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < BM / 16; ++u) {
             const int idx = tid + u * 256;
             // column c, rows 8j .. 8j+7 of the tile; 4 consecutive lanes share a column (64-byte V^T segments),
             // consecutive lane quads take consecutive columns (different LDS banks)
@@ -269,11 +263,17 @@ __device__ __forceinline__ void qkv_split_epilogue(const GemmArgs& a, f32x4 (&ac
 //     conv form: one A buffer, refilled behind an extra barrier once per 32-channel chunk (every ktaps steps).
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // DMA source for out-of-range pieces
 
-template <bool K1>
-constexpr size_t glds_lds_bytes() { return (size_t)(K1 ? 2 : 1) * kB16ARows * 128 + 2 * (size_t)kB16BN * 128; }
+template <bool K1, int BM>
+constexpr size_t glds_lds_bytes() {
+    const size_t ops = (size_t)(K1 ? 2 : 1) * b16_arows<BM>() * 128 + 2 * (size_t)kB16BN * 128;
+    const size_t out = K1 ? (size_t)BM * (kB16BN + 4) * 4 : 0;       // fused QKV epilogue stages the fp32 tile here
+    return ops > out ? ops : out;
+}
 
-template <int NSPLIT, bool K1>
+template <int NSPLIT, bool K1, int BM>
 __global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
+    constexpr int MT = BM / 32;
+    constexpr int kB16ARows = b16_arows<BM>();
     extern __shared__ __attribute__((aligned(16))) char smem_g[];
     char* As0 = smem_g;
     char* Bs0 = smem_g + (K1 ? 2 : 1) * kB16ARows * 128;
@@ -281,20 +281,20 @@ __global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int nN = (a.N + kB16BN - 1) / kB16BN;
     const int tn = blockIdx.x % nN, tm = blockIdx.x / nN;
-    const int n0 = tn * kB16BN, m0 = tm * kB16BM;
+    const int n0 = tn * kB16BN, m0 = tm * BM;
     const int P = (a.ktaps - 1) >> 1;
     const int lr = lane & 15, lg = lane >> 4;
     const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = a.Cpad / 32;
     const int niter = nchunks * a.ktaps;
-    const int a_instr = (kB16BM + 2 * P + 7) >> 3;       // 1-KB DMA instructions (8 rows each) of one A tile
+    const int a_instr = (BM + 2 * P + 7) >> 3;       // 1-KB DMA instructions (8 rows each) of one A tile
     const int jrow = lane >> 3, jslot = lane & 7;        // this lane's (row, physical slot) inside a DMA instruction
 
     // A tile of 32-channel chunk `ch` -> buffer `buf`; wave w issues instructions w, w+4, ...
@@ -333,10 +333,10 @@ __global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
             }
             const char* As = As0 + (K1 ? (it & 1) : 0) * (kB16ARows * 128);
             const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
-            bf16x8_t ah[4], al[4];
+            bf16x8_t ah[MT], al[MT];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int r = wm * 64 + mt * 16 + lr + tap;
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = wm * (BM / 2) + mt * 16 + lr + tap;
                 const f32x4 x0 = *reinterpret_cast<const f32x4*>(As + swz(r, lg));
                 const f32x4 x1 = *reinterpret_cast<const f32x4*>(As + swz(r, 4 + lg));
 #pragma unroll
@@ -358,12 +358,12 @@ __global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
                 if (NSPLIT == 3) bl = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
                 if (NSPLIT == 3) {
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt][nt], 0, 0, 0);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
                 }
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
             }
             if (!K1 && tap == a.ktaps - 1 && chunk + 1 < nchunks) {
                 __syncthreads();              // every wave has read its last fragments of this chunk's A tile
@@ -371,8 +371,8 @@ __global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
             }
         }
     }
-    if (K1 && a.qk_hi != nullptr) qkv_split_epilogue(a, acc, reinterpret_cast<float*>(smem_g), m0, n0, wm, wn, lr, lg, tid);
-    else tile_epilogue_64x64(a, acc, m0 + wm * 64, n0 + wn * 64, lr, lg, a.relu_pre != 0);
+    if (K1 && a.qk_hi != nullptr) qkv_split_epilogue<BM>(a, acc, reinterpret_cast<float*>(smem_g), m0, n0, wm, wn, lr, lg, tid);
+    else tile_epilogue_64x64<MT>(a, acc, m0 + wm * (BM / 2), n0 + wn * 64, lr, lg, a.relu_pre != 0);
 }
 
 // Row epilogue as its own HBM-bound kernel (used after gemm_tile_bf16 when the op ends in a LayerNorm, a

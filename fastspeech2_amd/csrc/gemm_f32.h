@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm_tile_f32(GemmArgs a) {
     }
 #undef FS2_GLOAD_B
     // epilogue: row = 4*lg + reg, col = lr inside each 16x16 tile
-    tile_epilogue_64x64(a, acc, m0 + wm * 64, n0 + wn * 64, lr, lg, a.relu_pre != 0);
+    tile_epilogue_64x64<4>(a, acc, m0 + wm * 64, n0 + wn * 64, lr, lg, a.relu_pre != 0);
 }
 
 // ---------------------------------------------------------------------------------------------------

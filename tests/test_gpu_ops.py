@@ -94,6 +94,17 @@ def test_conv_gemm_fp32_row_complete_kernel(case, monkeypatch):
     test_conv_gemm(case, "fp32")
 
 
+@pytest.mark.parametrize("bm", ["64", "128"])
+@pytest.mark.parametrize("gemm", ["regs", "glds"])
+@pytest.mark.parametrize("case", CASES[:6], ids=[c[-1] for c in CASES[:6]])
+def test_conv_gemm_bf16x3_kernel_variants(case, gemm, bm, monkeypatch):
+    """Both split-bf16 GEMM kernels (register-staged A / all LDS-DMA) at both tile heights (FS2_GEMM, FS2_BM pin the
+    choice the runtime otherwise makes per shape)."""
+    monkeypatch.setenv("FS2_GEMM", gemm)
+    monkeypatch.setenv("FS2_BM", bm)
+    test_conv_gemm(case, "bf16x3")
+
+
 def test_conv_gemm_transpose_detecting():
     """A = identity-like with an ASYMMETRIC weight: catches a swapped C/D row<->col mapping."""
     from tests import ops_binding as ops
