@@ -190,6 +190,7 @@ bool small_grid(const GemmArgs& a) {
     const int force = !e ? 0 : atoi(e);
     if (force == 64) return true;
     if (force == 128) return false;
+    if (a.ktaps == 1) return true;     // k = 1 GEMMs measure 8-20 % faster with 64-row tiles at every size (3-4 workgroups/CU)
     const long nN = (a.N + kB16BN - 1) / kB16BN, nM = (a.R + 127) / 128;
     return nN * nM < 512;
 }
