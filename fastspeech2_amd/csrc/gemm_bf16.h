@@ -30,6 +30,15 @@ namespace fs2 {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
+// Barrier that also covers this wave's outstanding LDS-DMA (global_load_lds counts on vmcnt).  hipcc normally emits the
+// vmcnt(0) itself in front of __syncthreads(), but in one kernel of this project (an LDS-DMA variant of the attention
+// loop) it hoisted that wait out of the loop and the loop-top barrier raced with the DMA issued in the previous
+// iteration; the explicit wait makes the ordering independent of that heuristic (a duplicate s_waitcnt is free).
+__device__ __forceinline__ void dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 #ifndef FS2_SETPRIO
 #define FS2_SETPRIO 1
 #endif
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tile_bf16(GemmArgs a) {
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         for (int tap = 0; tap < a.ktaps; ++tap, ++it) {     // no integer division on the critical path
             const bool last_tap = (tap == a.ktaps - 1) && (chunk + 1 < nchunks);
-            __syncthreads();   // DMA of B(it) landed (drained at the barrier), A(chunk) visible; step it-1 is finished
+            dma_barrier();     // DMA of B(it) landed, A(chunk) visible; step it-1 is finished
             if (it + 1 < niter) FS2_DMA_B(it + 1, (it + 1) & 1)      // buffer last read in step it-1
             if (last_tap) FS2_GLOAD_A(chunk + 1)       // lands while this step's MFMAs run
             const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
     int it = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         for (int tap = 0; tap < a.ktaps; ++tap, ++it) {
-            __syncthreads();   // DMA of step `it` landed (hipcc waits vmcnt(0) here); every wave is done with step it-1
+            dma_barrier();     // DMA of step `it` landed; every wave is done with step it-1
             if (it + 1 < niter) {
                 dma_B(it + 1, (it + 1) & 1);
                 if (K1) dma_A(it + 1, (it + 1) & 1);
