@@ -192,7 +192,7 @@ bool small_grid(const GemmArgs& a) {
     if (force == 128) return false;
     if (a.ktaps == 1) return true;     // k = 1 GEMMs measure 8-20 % faster with 64-row tiles at every size (3-4 workgroups/CU)
     const long nN = (a.N + kB16BN - 1) / kB16BN, nM = (a.R + 127) / 128;
-    return nN * nM < 512;
+    return nN * nM < 400;     // measured: 296 workgroups of 128 rows (enc.ffn1) prefer 64-row tiles, 458 (Postnet, predictors) do not
 }
 
 template <int NSPLIT, int BM>
