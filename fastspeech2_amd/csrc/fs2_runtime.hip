@@ -379,6 +379,9 @@ void build_layout(HostLayout& L, int B, const std::vector<int>& len, const std::
     }
     L.R = row;
     L.Rpad = round_up(row, 128);
+    // attention work list: longest key ranges first, so that the few long utterances do not form the tail of the launch
+    // (a workgroup's run time is proportional to klen; dispatch follows the list order)
+    std::stable_sort(L.work.begin(), L.work.end(), [&](const int2& x, const int2& y) { return klen[x.x] > klen[y.x]; });
 }
 
 size_t layout_dev_ints(const HostLayout& L) { return (size_t)4 * L.B + 2 * (size_t)L.Rpad + 2 * L.work.size() + 64; }
