@@ -30,7 +30,7 @@ class Config(C.Structure):
         "idim", "odim", "adim", "aheads", "elayers", "eunits", "ddim", "dlayers", "dunits", "ffn_kernel",
         "dur_layers", "dur_chans", "dur_kernel", "var_layers", "var_chans", "var_kernel", "n_bins",
         "postnet_layers", "postnet_chans", "postnet_filts", "use_batch_norm", "use_scaled_pos_enc",
-        "reduction_factor", "device")]
+        "reduction_factor", "device", "decoder_input_layer")]
 
 
 class TensorDesc(C.Structure):

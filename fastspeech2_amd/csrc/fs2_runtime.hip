@@ -716,6 +716,7 @@ int fs2_create(const fs2_config* cfg, fs2_handle** out) {
     *out = nullptr;
     if (cfg->reduction_factor != 1) return fail(nullptr, FS2_ERR_UNSUPPORTED, "reduction_factor %d (only 1 is implemented)", cfg->reduction_factor);
     if (cfg->adim % cfg->aheads || cfg->ddim % cfg->aheads) return fail(nullptr, FS2_ERR_ARG, "adim/ddim not divisible by aheads");
+    if (!cfg->decoder_input_layer && cfg->ddim != cfg->adim) return fail(nullptr, FS2_ERR_ARG, "decoder_input_layer = 0 needs ddim == adim");
     if (cfg->n_bins != cfg->adim) return fail(nullptr, FS2_ERR_ARG, "n_bins (%d) must equal adim (%d): the reference feeds one_hot(256) into Linear(adim, adim)", cfg->n_bins, cfg->adim);
     if (cfg->ffn_kernel % 2 == 0 || cfg->dur_kernel % 2 == 0 || cfg->var_kernel % 2 == 0 || (cfg->postnet_layers > 0 && cfg->postnet_filts % 2 == 0))
         return fail(nullptr, FS2_ERR_UNSUPPORTED, "even convolution kernel sizes are not supported");
@@ -753,7 +754,8 @@ int fs2_load_weights(fs2_handle* h, const fs2_tensor_desc* t, int32_t n, void* s
 
     h->enc_embed = L.copy("encoder.embed.0.weight", {c.idim, c.adim});
     load_stack(L, h->enc, "encoder", c.elayers, c.adim, c.eunits, c.ffn_kernel, "encoder.embed.1", c.use_scaled_pos_enc);
-    load_stack(L, h->dec, "decoder", c.dlayers, c.ddim, c.dunits, c.ffn_kernel, "decoder.embed.4", c.use_scaled_pos_enc);
+    load_stack(L, h->dec, "decoder", c.dlayers, c.ddim, c.dunits, c.ffn_kernel, c.decoder_input_layer ? "decoder.embed.4" : "decoder.embed.0",
+               c.use_scaled_pos_enc);
     load_predictor(L, h->dur, "duration_predictor", c.dur_layers, c.adim, c.dur_chans, c.dur_kernel);
     load_predictor(L, h->energy, "energy_predictor.predictor", c.var_layers, c.adim, c.var_chans, c.var_kernel);
     load_predictor(L, h->pitch, "pitch_predictor.predictor", c.var_layers, c.adim, c.var_chans, c.var_kernel);
@@ -770,9 +772,11 @@ int fs2_load_weights(fs2_handle* h, const fs2_tensor_desc* t, int32_t n, void* s
             hipLaunchKernelGGL(onehot_table, dim3((tot + 255) / 256), dim3(256), 0, s, (const float*)wp->data, (const float*)bp->data, c.adim, c.n_bins, h->Tp);
         }
     }
-    h->dec_in = L.gemm({"decoder.embed.0.weight"}, {"decoder.embed.0.bias"}, c.ddim, c.adim, 1, true);
-    h->dec_in_lng = L.copy("decoder.embed.1.weight", {c.ddim});
-    h->dec_in_lnb = L.copy("decoder.embed.1.bias", {c.ddim});
+    if (c.decoder_input_layer) {
+        h->dec_in = L.gemm({"decoder.embed.0.weight"}, {"decoder.embed.0.bias"}, c.ddim, c.adim, 1, true);
+        h->dec_in_lng = L.copy("decoder.embed.1.weight", {c.ddim});
+        h->dec_in_lnb = L.copy("decoder.embed.1.bias", {c.ddim});
+    }
     h->feat = L.gemm({"feat_out.weight"}, {"feat_out.bias"}, c.odim, c.ddim, 1, true);
     h->post.clear();
     for (int l = 0; l < c.postnet_layers; ++l) {
@@ -921,11 +925,20 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
                            io->ps, io->ps_stride, f.e_rows, f.p_rows, h->ebins, h->pbins, c.n_bins - 1, h->Te, h->Tp, f.qe, f.qp);
         HIP_TRY(h, hipGetLastError());
     }
-    {   // decoder input layer: Linear -> LN -> ReLU -> + alpha * pe   (reference encoder.py:118-125)
+    if (c.decoder_input_layer) {   // decoder input layer: Linear -> LN -> ReLU -> + alpha * pe   (reference encoder.py:118-125)
         GemmArgs a = gemm_args(h->dec_in, f.hfr, c.adim, R, dl.row_pos, f.sb.x0, c.ddim);
         a.ln_g = h->dec_in_lng; a.ln_b = h->dec_in_lnb; a.ln_eps = 1e-5f; a.act_post = 1;
         a.pe = h->dec.pe; a.pe_ld = c.ddim; a.pe_alpha = h->dec.alpha; a.x_scale = c.use_scaled_pos_enc ? 1.f : sqrtf((float)c.ddim);
         if ((rc = launch_gemm(h, s, "dec.in", a, b.precision))) return rc;
+    } else {                       // TorchScript twin: the decoder input is just x (* sqrt(d)) + alpha * pe   (encoder.py:138-141)
+        Scope sc(h, s, "dec.in.pe", 0.0, 8.0 * R * c.ddim);
+        HIP_TRY(h, hipMemcpyAsync(f.sb.x0, f.hfr, (size_t)R * c.ddim * sizeof(float), hipMemcpyDeviceToDevice, s));
+        GemmArgs a;
+        memset(&a, 0, sizeof a);
+        a.N = c.ddim; a.R = R; a.row_pos = dl.row_pos; a.Y = f.sb.x0; a.ldy = c.ddim;
+        a.pe = h->dec.pe; a.pe_ld = c.ddim; a.pe_alpha = h->dec.alpha; a.x_scale = c.use_scaled_pos_enc ? 1.f : sqrtf((float)c.ddim);
+        hipLaunchKernelGGL(ln_rows, dim3((R + 3) / 4), dim3(256), 0, s, a);
+        HIP_TRY(h, hipGetLastError());
     }
     const int mask_q = (b.compat_padded && io->masked) ? 1 : 0;
     if ((rc = run_stack(h, s, "dec", h->dec, c.ddim, c.aheads, R, L, dl, mask_q, f.sb, b.precision))) return rc;

@@ -39,7 +39,8 @@ def sinusoid_table(n, d):
 
 
 class _Holder(nn.Module):
-    def forward(self, *a, **k):  # pragma: no cover
+    @torch.jit.unused          # keeps the containers (and the nn.Sequential wrappers around them) scriptable
+    def forward(self, x: torch.Tensor) -> torch.Tensor:  # pragma: no cover
         raise RuntimeError("parameter container: the forward pass runs in libfs2_hip.so")
 
 
@@ -178,9 +179,12 @@ class FeedForwardTransformer(nn.Module):
         see pad rows).  ``forward()`` (the loss path) always uses "padded_compat".
     """
 
-    def __init__(self, idim: int, odim: int, hp):
+    def __init__(self, idim: int, odim: int, hp, _script_twin: bool = False):
         super().__init__()
         m = hp.model
+        # _script_twin: the architecture of reference utils/fastspeech2_script.py (decoder dim = adim, positional
+        # encoding as the only decoder input layer, feat_out Linear(adim, odim)); see fastspeech2_script.py here
+        ddim = m.adim if _script_twin else m.ddim
         self.idim, self.odim = idim, odim
         self.use_scaled_pos_enc = bool(m.use_scaled_pos_enc)
         self.use_masking = bool(m.use_masking)
@@ -194,13 +198,13 @@ class FeedForwardTransformer(nn.Module):
         conv = m.positionwise_layer_type == "conv1d"
         kernel = m.positionwise_conv_kernel_size if conv else 1
         self._cfg = dict(
-            idim=idim, odim=odim, adim=m.adim, aheads=m.aheads, elayers=m.elayers, eunits=m.eunits, ddim=m.ddim,
+            idim=idim, odim=odim, adim=m.adim, aheads=m.aheads, elayers=m.elayers, eunits=m.eunits, ddim=ddim,
             dlayers=m.dlayers, dunits=m.dunits, ffn_kernel=kernel,
             dur_layers=m.duration_predictor_layers, dur_chans=m.duration_predictor_chans,
             dur_kernel=m.duration_predictor_kernel_size, var_layers=2, var_chans=256, var_kernel=3, n_bins=256,
             postnet_layers=m.postnet_layers, postnet_chans=m.postnet_chans, postnet_filts=m.postnet_filts,
             use_batch_norm=int(bool(m.use_batch_norm)), use_scaled_pos_enc=int(self.use_scaled_pos_enc),
-            reduction_factor=m.reduction_factor)
+            reduction_factor=m.reduction_factor, decoder_input_layer=0 if _script_twin else 1)
 
         enc_embed = nn.Sequential(nn.Embedding(idim, m.adim, padding_idx=0), _PositionalTable(m.adim, self.use_scaled_pos_enc))
         self.encoder = _FFTStack(enc_embed, m.adim, m.eunits, m.elayers, kernel, conv)
@@ -214,12 +218,15 @@ class FeedForwardTransformer(nn.Module):
             torch.exp(torch.linspace(torch.log(torch.tensor(float(hp.data.p_min))),
                                      torch.log(torch.tensor(float(hp.data.p_max))), 255)))
         self.pitch_embed = nn.Linear(m.adim, m.adim)
-        dec_embed = nn.Sequential(nn.Linear(m.adim, m.ddim), nn.LayerNorm(m.ddim), nn.Dropout(0.2), nn.ReLU(),
-                                  _PositionalTable(m.ddim, self.use_scaled_pos_enc))
-        self.decoder = _FFTStack(dec_embed, m.ddim, m.dunits, m.dlayers, kernel, conv)
+        if _script_twin:
+            dec_embed = nn.Sequential(_PositionalTable(ddim, self.use_scaled_pos_enc))
+        else:
+            dec_embed = nn.Sequential(nn.Linear(m.adim, ddim), nn.LayerNorm(ddim), nn.Dropout(0.2), nn.ReLU(),
+                                      _PositionalTable(ddim, self.use_scaled_pos_enc))
+        self.decoder = _FFTStack(dec_embed, ddim, m.dunits, m.dlayers, kernel, conv)
         self.postnet = None if m.postnet_layers == 0 else _Postnet(odim, m.postnet_layers, m.postnet_chans,
                                                                    m.postnet_filts, bool(m.use_batch_norm))
-        self.feat_out = nn.Linear(m.ddim, odim * m.reduction_factor)
+        self.feat_out = nn.Linear(ddim, odim * m.reduction_factor)
         self._reset_parameters(m.transformer_init, m.initial_encoder_alpha, m.initial_decoder_alpha)
 
         self.precision = "fp32"
@@ -276,7 +283,9 @@ class FeedForwardTransformer(nn.Module):
         self.decoder.embed[-1].ensure(max(need_frames, 1))
         if self._handle is None or self._handle_device != device:
             self._drop_handle()
-            cfg = _lib.Config(**self._cfg, device=device.index if device.index is not None else torch.cuda.current_device())
+            cfg = _lib.Config(**{k: v for k, v in self._cfg.items() if k != 'decoder_input_layer'},
+                              device=device.index if device.index is not None else torch.cuda.current_device(),
+                              decoder_input_layer=self._cfg['decoder_input_layer'])
             h = C.c_void_p()
             _lib.check(L.fs2_create(C.byref(cfg), C.byref(h)))
             self._handle, self._handle_device, self._fingerprint = h, device, None

@@ -61,6 +61,9 @@ typedef struct fs2_config {
     int32_t use_scaled_pos_enc;
     int32_t reduction_factor;           /* only 1 is implemented                              */
     int32_t device;                     /* HIP device ordinal                                 */
+    int32_t decoder_input_layer;        /* 1: Linear -> LN -> ReLU -> +pe (fastspeech.py:120-135, encoder.py:118-125);
+                                           0: +pe only (the TorchScript twin, utils/fastspeech2_script.py:112-127;
+                                           needs ddim == adim)                                */
 } fs2_config;
 
 /* One reference-layout tensor (state_dict entry), fp32, resident on the device. */

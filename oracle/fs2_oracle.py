@@ -21,10 +21,11 @@ import torch
 import torch.nn.functional as F
 
 
-def config_from_hp(hp, idim, odim):
-    """Collect the fields the path reads (reference fastspeech.py:53-160)."""
+def config_from_hp(hp, idim, odim, script_twin=False):
+    """Collect the fields the path reads (reference fastspeech.py:53-160).  script_twin: the architecture of
+    reference utils/fastspeech2_script.py:112-145 (decoder dim = adim, PE-only decoder input layer)."""
     m = hp.model
-    return dict(
+    return dict(dec_input_linear=not script_twin,
         idim=idim, odim=odim, adim=m.adim, aheads=m.aheads, elayers=m.elayers, eunits=m.eunits,
         ddim=m.ddim, dlayers=m.dlayers, dunits=m.dunits,
         ffn_kernel=(m.positionwise_conv_kernel_size if m.positionwise_layer_type == "conv1d" else 1),
@@ -217,9 +218,12 @@ def padded_forward(sd, cfg, xs, ilens, olens=None, ds=None, es=None, ps=None, is
         h_mask = ov.unsqueeze(-2) & ov.unsqueeze(-1)
     else:
         h_mask = None
-    z = F.linear(hs_f, sd["decoder.embed.0.weight"], sd["decoder.embed.0.bias"])
-    z = F.layer_norm(z, (z.shape[-1],), sd["decoder.embed.1.weight"], sd["decoder.embed.1.bias"], 1e-5)
-    z = _add_pos(sd, "decoder.embed.4", torch.relu(z), cfg)
+    if cfg.get("dec_input_linear", True):
+        z = F.linear(hs_f, sd["decoder.embed.0.weight"], sd["decoder.embed.0.bias"])
+        z = F.layer_norm(z, (z.shape[-1],), sd["decoder.embed.1.weight"], sd["decoder.embed.1.bias"], 1e-5)
+        z = _add_pos(sd, "decoder.embed.4", torch.relu(z), cfg)
+    else:   # utils/fastspeech2_script.py:112-127: input_layer=None -> embed = Sequential(pos_enc)
+        z = _add_pos(sd, "decoder.embed.0", hs_f, cfg)
     z = _fft_stack(sd, "decoder", z, h_mask, cfg["dlayers"], heads, cfg)
     out["decoder_out"] = z
     before = F.linear(z, sd["feat_out.weight"], sd["feat_out.bias"]).view(B, -1, cfg["odim"])

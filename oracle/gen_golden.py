@@ -188,6 +188,21 @@ def main():
                             lr_hs=np_(hs), lr_ds=np_(dsl), lr_ilens=np_(ill), lr_out=np_(lro),
                             pad_mask_5_3_2=np_(make_pad_mask([5, 3, 2])), attn_x=np_(xa), attn_out=np_(ao),
                             pe_rows=np.array([0, 1, 4999]), pe256=np_(pe256[[0, 1, 4999]]), pe384=np_(pe384[[0, 1, 4999]]))
+        # ---- G5: the TorchScript twin (utils/fastspeech2_script.py): different architecture, forward(x) ----
+        from utils import fastspeech2_script as ref_script
+        twin = ref_script.FeedForwardTransformer(idim, odim, hp).eval()
+        sd5 = bias_durations(portable_state_dict(twin.state_dict(), seed=5), 4.0)
+        twin.load_state_dict(sd5)
+        x5 = torch.from_numpy(np.random.RandomState(16).randint(1, 68, size=30).astype(np.int64))
+        mel5 = twin(x5)
+        keys5 = sorted(sd5.keys())
+        np.savez_compressed(os.path.join(out_dir, "g5_script_twin_t30.npz"), x=np_(x5), mel=np_(mel5),
+                            keys=np.array(keys5), shapes=np.array([str(tuple(sd5[k].shape)) for k in keys5]))
+        cfg5 = O.config_from_hp(hp, idim, odim, script_twin=True)
+        o5 = O.padded_forward(sd5, cfg5, x5.unsqueeze(0), torch.tensor([30]), is_inference=True)
+        print("G5 twin (L=%d, %d state-dict keys, %d params)" % (mel5.shape[0], len(keys5), sum(p.numel() for p in twin.parameters())))
+        cmp("twin mel", o5["after"][0], mel5)
+
     print("worst oracle-vs-reference max-abs: %.3e" % worst)
     assert worst < 2e-5, "oracle restatement drifted from the reference"
     print("fixtures written to", out_dir)

@@ -43,7 +43,7 @@ def test_create_without_gpu_fails_loudly(libpath):
         pytest.skip("GPU present")
     from fastspeech2_amd import _lib
     L = _lib.lib()
-    cfg = _lib.Config(68, 80, 256, 2, 4, 1024, 384, 4, 1024, 9, 2, 256, 3, 2, 256, 3, 256, 5, 256, 5, 1, 1, 1, 0)
+    cfg = _lib.Config(68, 80, 256, 2, 4, 1024, 384, 4, 1024, 9, 2, 256, 3, 2, 256, 3, 256, 5, 256, 5, 1, 1, 1, 0, 1)
     h = ctypes.c_void_p()
     rc = L.fs2_create(ctypes.byref(cfg), ctypes.byref(h))
     assert rc != 0 and b"no HIP device" in L.fs2_last_error(None)
@@ -113,3 +113,19 @@ def test_portable_weights_are_deterministic():
     c3 = make_batch("c3")
     assert c3["xs"].shape[0] == 64 and int(c3["olens"].sum()) > 30000
     assert torch.equal(c3["ds"].sum(1), c3["olens"])
+
+
+def test_script_twin_is_scriptable_without_a_gpu(tmp_path):
+    """export_torchscript.py's flow (reference export_torchscript.py:46-49): torch.jit.script(model) + save; running the
+    archive needs the GPU (tests/test_gpu_parity.py)."""
+    from fastspeech2_amd import default_hparams, N_PHONEME_SYMBOLS
+    from fastspeech2_amd.fastspeech2_script import FeedForwardTransformer as Twin
+    twin = Twin(N_PHONEME_SYMBOLS, 80, default_hparams()).eval()
+    scripted = torch.jit.script(twin)
+    assert "fs2::twin_inference" in str(scripted.graph)
+    path = str(tmp_path / "fs2_twin.pt")
+    scripted.save(path)
+    again = torch.jit.load(path)
+    assert again.flat_weights.numel() == twin.flat_weights.numel() > 26e6
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        again(torch.ones(5, dtype=torch.int64))

@@ -313,3 +313,31 @@ def test_packed_output_and_unpack_kernel(env):
         assert torch.equal(r["after_packed"][s0:s0 + L], r["after"][i, :L])
     back = unpack_rows(r["after_packed"], starts, ol, r["after"].shape[1])
     assert torch.equal(back, r["after"])
+
+
+def test_g5_script_twin_eager_scripted_and_reloaded(golden_dir, tmp_path):
+    """The TorchScript twin (reference utils/fastspeech2_script.py, export_torchscript.py:46-58) on the HIP path:
+    eager forward, scripted forward, traced forward and a save/load round trip all reproduce the reference's mel."""
+    from fastspeech2_amd import default_hparams, N_PHONEME_SYMBOLS
+    from fastspeech2_amd.fastspeech2_script import FeedForwardTransformer as Twin
+    from fastspeech2_amd.synthetic import portable_state_dict, bias_durations
+    g = np.load(golden_dir + "/g5_script_twin_t30.npz")
+    twin = Twin(N_PHONEME_SYMBOLS, 80, default_hparams()).eval()
+    twin.load_state_dict(bias_durations(portable_state_dict(twin.state_dict(), seed=5), 4.0))
+    twin = twin.to("cuda:0")
+    x = _t(g["x"])
+    with torch.no_grad():
+        eager = twin(x)
+        direct = twin.inference(x)
+        scripted = torch.jit.script(twin)
+        s_out = scripted(x)
+        traced = torch.jit.trace(twin, torch.ones(50, dtype=torch.int64, device="cuda:0"))
+        t_out = traced(x)
+        path = str(tmp_path / "twin.pt")
+        scripted.save(path)
+        r_out = torch.jit.load(path)(x)
+    d = _maxabs(eager, g["mel"])
+    print("G5 twin mel max-abs %.2e (L=%d)" % (d, eager.shape[0]))
+    assert eager.shape == tuple(g["mel"].shape) and d <= MEL_TOL
+    for o in (direct, s_out, t_out, r_out):
+        assert torch.equal(o, eager)
