@@ -5,3 +5,4 @@
 """
 from .hparams import default_hparams, load_hparams, N_PHONEME_SYMBOLS  # noqa: F401
 from .fastspeech import FeedForwardTransformer  # noqa: F401
+from .io import load_checkpoint, vocoder_input, hparams_from_str  # noqa: F401

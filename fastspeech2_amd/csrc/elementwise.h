@@ -228,6 +228,23 @@ __global__ void pack_rows(const float* src, int W, const int* row_pos, const int
     *reinterpret_cast<float4*>(dst + (size_t)(cum[b] + j) * W + c) = *reinterpret_cast<const float4*>(src + (size_t)row * W + c);
 }
 
+// [N, W] -> [W, N] through a 32 x 33 LDS tile (coalesced on both sides)
+__global__ __launch_bounds__(256) void transpose_rows(const float* src, int64_t N, int W, float* dst) {
+    __shared__ float t[32][33];
+    const int64_t n0 = (int64_t)blockIdx.x * 32;
+    const int w0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t n = n0 + r; const int w = w0 + tx;
+        t[r][tx] = (n < N && w < W) ? src[n * W + w] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int w = w0 + r; const int64_t n = n0 + tx;
+        if (w < W && n < N) dst[(int64_t)w * N + n] = t[tx][r];
+    }
+}
+
 // ---- weight repacking (run once per load_state_dict) ----
 // conv / linear weight [N][C][k] -> [Npad][k][Cpad], zero padded, optionally scaled per output channel by
 // gamma / sqrt(var + eps) (eval-mode BatchNorm folded into the Postnet convs, reference modules.py:285-348).

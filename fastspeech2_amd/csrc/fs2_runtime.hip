@@ -1115,6 +1115,15 @@ int fs2_op_unpack_rows(void* stream, const float* src, int32_t W, int32_t B, con
     return FS2_OK;
 }
 
+int fs2_op_transpose(void* stream, const float* src, int64_t N, int32_t W, float* dst) {
+    if (!src || !dst || N < 0 || W <= 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_transpose: bad arguments");
+    if (N == 0) return FS2_OK;
+    hipLaunchKernelGGL(transpose_rows, dim3((unsigned)((N + 31) / 32), (W + 31) / 32), dim3(256), 0, (hipStream_t)stream, src, N, W, dst);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "transpose: %s", hipGetErrorString(e));
+    return FS2_OK;
+}
+
 int fs2_op_bucketize(void* stream, const float* x, int64_t n, const float* bins, int32_t nb, int32_t* idx) {
     if (!x || !bins || !idx || n < 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_bucketize: bad arguments");
     if (n == 0) return FS2_OK;

@@ -184,6 +184,10 @@ int fs2_op_length_regulate(void *stream, const float *hs, const int64_t *ds, con
 int fs2_op_unpack_rows(void *stream, const float *src, int32_t W, int32_t B, const int32_t *starts, const int32_t *lens,
                        int32_t Lout, float *dst);
 
+/* dst [W, N] <- src [N, W]^T : packed mel frames [sum L, 80] -> vocoder layout [80, sum L] (the reference does
+ * mel.transpose + np.concatenate on the host, inference.py:173-178; MelGAN takes [1, 80, L], utils/plot.py:96-105) */
+int fs2_op_transpose(void *stream, const float *src, int64_t N, int32_t W, float *dst);
+
 /* idx[i] = bucketize(x[i], bins[nb]) (right=False, NaN -> nb)  (variance_predictor.py:158,231) */
 int fs2_op_bucketize(void *stream, const float *x, int64_t n, const float *bins, int32_t nb, int32_t *idx);
 

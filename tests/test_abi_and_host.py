@@ -129,3 +129,22 @@ def test_script_twin_is_scriptable_without_a_gpu(tmp_path):
     assert again.flat_weights.numel() == twin.flat_weights.numel() > 26e6
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         again(torch.ones(5, dtype=torch.int64))
+
+
+def test_load_checkpoint_forms(tmp_path):
+    """inference.py:161-166 / train_fastspeech.py:235-244: {"model": ...} checkpoints, bare --old_model state dicts
+    (strict=False), DataParallel prefixes, embedded hp_str."""
+    from fastspeech2_amd import load_checkpoint, hparams_from_str
+    from fastspeech2_amd.synthetic import portable_state_dict
+    model, hp = _model()
+    sd = portable_state_dict(model.state_dict(), 7)
+    path = str(tmp_path / "chk.pt")
+    torch.save({"model": sd, "optim": {}, "step": 58000, "hp_str": open(os.path.join(ROOT, "configs", "default.yaml")).read(), "githash": "abc"}, path)
+    extras = load_checkpoint(model, path)
+    assert extras["step"] == 58000 and torch.equal(model.state_dict()["feat_out.weight"], sd["feat_out.weight"])
+    assert hparams_from_str(extras["hp_str"]).model.adim == 256
+    bare = {("module." + k): v for k, v in sd.items() if "concat_linear" not in k}          # old checkpoint without unused keys
+    with pytest.raises(RuntimeError):
+        load_checkpoint(model, dict(bare))
+    extras = load_checkpoint(model, dict(bare), old_model=True)
+    assert any("concat_linear" in k for k in extras["missing_keys"]) and not extras["unexpected_keys"]

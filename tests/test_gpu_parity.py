@@ -341,3 +341,15 @@ def test_g5_script_twin_eager_scripted_and_reloaded(golden_dir, tmp_path):
     assert eager.shape == tuple(g["mel"].shape) and d <= MEL_TOL
     for o in (direct, s_out, t_out, r_out):
         assert torch.equal(o, eager)
+
+
+def test_vocoder_hand_off(env):
+    """inference.py:173-178 on the device: packed mels -> [1, 80, sum L]."""
+    model, sd, cfg, O = env
+    from fastspeech2_amd import vocoder_input
+    from fastspeech2_amd.synthetic import make_batch
+    b = make_batch("c3", B=5)
+    with torch.no_grad():
+        packed, ol = model.inference_batch(b["xs"].cuda(), b["ilens"], d_override=b["ds"].cuda(), packed=True)
+    v = vocoder_input(packed)
+    assert v.shape == (1, 80, int(ol.sum())) and torch.equal(v[0], packed.t())
