@@ -66,21 +66,30 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// MFMA lane -> tile-row permutation of the bf16 kernels.  ds_read_b128 serves a wave in four 16-lane groups
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...), each mixing two k-slot columns; with tile row = lane&15 the XOR-swizzled
+// 128-byte-row layout has 2-way bank conflicts in most groups (brute-forced over all tap offsets: 2/3 of the reads).  Giving
+// lanes 4-11 the even rows and lanes 0-3,12-15 the odd rows makes every group hit 16 distinct 16-byte bank slots for EVERY
+// row offset (tap), because the two slot columns of a group then differ by the XOR of row bit 1 within closed row pairs.
+// The same permutation applies to the B operand (output column) and therefore to the C/D element -> (row, col) map.
+__device__ __forceinline__ int rperm(int i) { return i < 4 ? 2 * i + 1 : (i < 12 ? 2 * (i - 4) : 2 * (i - 12) + 9); }
+
 // Elementwise epilogue of a (16 MT) x 64 wave tile held as acc[MT][4] (16 x 16 MFMA tiles, C layout col = l&15,
 // row = 4*(l>>4) + reg).  All loads of a 16-row slab (row flags, residual) are issued before its stores and the
 // pointers are __restrict__, so the compiler does not serialise a memory round trip per element behind
 // possibly-aliasing stores (that cost ~25 us per workgroup before).
-template <int MT>
+template <int MT, bool PERM = false>
 __device__ __forceinline__ void tile_epilogue_64x64(const GemmArgs& a, f32x4 (&acc)[MT][4], int row_base, int col_base, int lr, int lg,
                                                     bool relu_first) {
     const float* __restrict__ biasp = a.bias;
     const float* __restrict__ residp = a.resid;
     const int* __restrict__ rpos = a.row_pos;
     float* __restrict__ Y = a.Y;
+    const int lc = PERM ? rperm(lr) : lr;                 // column of this lane inside a 16-wide tile
     float bv[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int col = col_base + nt * 16 + lr;
+        const int col = col_base + nt * 16 + lc;
         bv[nt] = (biasp && col < a.N) ? biasp[col] : 0.f;
     }
 #pragma unroll
@@ -89,25 +98,25 @@ __device__ __forceinline__ void tile_epilogue_64x64(const GemmArgs& a, f32x4 (&a
         float rv[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = row_base + mt * 16 + lg * 4 + r;
+            const int row = row_base + mt * 16 + (PERM ? rperm(lg * 4 + r) : lg * 4 + r);
             inb[r] = row < a.R;
             valid[r] = inb[r] && (rpos == nullptr || rpos[row] >= 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = row_base + mt * 16 + lg * 4 + r;
+            const int row = row_base + mt * 16 + (PERM ? rperm(lg * 4 + r) : lg * 4 + r);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int col = col_base + nt * 16 + lr;
+                const int col = col_base + nt * 16 + lc;
                 rv[r][nt] = (residp && inb[r] && col < a.N) ? residp[(size_t)row * a.ldr + col] : 0.f;
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = row_base + mt * 16 + lg * 4 + r;
+            const int row = row_base + mt * 16 + (PERM ? rperm(lg * 4 + r) : lg * 4 + r);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int col = col_base + nt * 16 + lr;
+                const int col = col_base + nt * 16 + lc;
                 float v = acc[mt][nt][r] + bv[nt] + rv[r][nt];
                 if (relu_first) v = fmaxf(v, 0.f);
                 v = apply_act(v, a.act_post);

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tile_bf16(GemmArgs a) {
     const int n0 = blockIdx.x * kB16BN, m0 = blockIdx.y * BM;
     const int P = (a.ktaps - 1) >> 1;
     const int lr = lane & 15, lg = lane >> 4;
+    const int lp = rperm(lr);            // tile row / column this lane feeds to the MFMA (conflict-free LDS reads, common.h)
     const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
 
     f32x4 acc[MT][4];
@@ -152,14 +153,14 @@ __global__ __launch_bounds__(256, 3) void gemm_tile_bf16(GemmArgs a) {
             bf16x8_t ah[MT], al[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int r = wm * (BM / 2) + mt * 16 + lr + tap;
+                const int r = wm * (BM / 2) + mt * 16 + lp + tap;
                 ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
                 if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
             }
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);     // favour the wave that is feeding the matrix pipe
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int n = wn * 64 + nt * 16 + lr;
+                const int n = wn * 64 + nt * 16 + lp;
                 const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
                 bf16x8_t bl;
                 if (NSPLIT == 3) bl = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tile_bf16(GemmArgs a) {
 #undef FS2_STORE_A1
 #undef FS2_STORE_A
     // epilogue (elementwise): bias, residual, activation, gap rows -> 0
-    tile_epilogue_64x64<MT>(a, acc, m0 + wm * (BM / 2), n0 + wn * 64, lr, lg, a.relu_pre != 0);
+    tile_epilogue_64x64<MT, true>(a, acc, m0 + wm * (BM / 2), n0 + wn * 64, lr, lg, a.relu_pre != 0);
 }
 
 // Fused QKV epilogue: the 128 x 128 fp32 tile (+bias) goes through LDS once and leaves as the split-bf16 attention
@@ -203,12 +204,12 @@ __device__ __forceinline__ void qkv_split_epilogue(const GemmArgs& a, f32x4 (&ac
     __syncthreads();                      // the operand buffers are dead: reuse them for the output tile
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int cl = wn * 64 + nt * 16 + lr;
+        const int cl = wn * 64 + nt * 16 + rperm(lr);
         const float bv = (biasp && n0 + cl < a.N) ? biasp[n0 + cl] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tile[(wm * (BM / 2) + mt * 16 + lg * 4 + r) * kQkvLd + cl] = acc[mt][nt][r] + bv;
+            for (int r = 0; r < 4; ++r) tile[(wm * (BM / 2) + mt * 16 + rperm(lg * 4 + r)) * kQkvLd + cl] = acc[mt][nt][r] + bv;
     }
     __syncthreads();
     const int D = a.att_D;
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
     const int n0 = tn * kB16BN, m0 = tm * BM;
     const int P = (a.ktaps - 1) >> 1;
     const int lr = lane & 15, lg = lane >> 4;
+    const int lp = rperm(lr);            // tile row / column this lane feeds to the MFMA (conflict-free LDS reads, common.h)
     const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
 
     f32x4 acc[MT][4];
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
             bf16x8_t ah[MT], al[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int r = wm * (BM / 2) + mt * 16 + lr + tap;
+                const int r = wm * (BM / 2) + mt * 16 + lp + tap;
                 const f32x4 x0 = *reinterpret_cast<const f32x4*>(As + swz(r, lg));
                 const f32x4 x1 = *reinterpret_cast<const f32x4*>(As + swz(r, 4 + lg));
 #pragma unroll
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int n = wn * 64 + nt * 16 + lr;
+                const int n = wn * 64 + nt * 16 + lp;
                 const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
                 bf16x8_t bl;
                 if (NSPLIT == 3) bl = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
         }
     }
     if (K1 && a.qk_hi != nullptr) qkv_split_epilogue<BM>(a, acc, reinterpret_cast<float*>(smem_g), m0, n0, wm, wn, lr, lg, tid);
-    else tile_epilogue_64x64<MT>(a, acc, m0 + wm * (BM / 2), n0 + wn * 64, lr, lg, a.relu_pre != 0);
+    else tile_epilogue_64x64<MT, true>(a, acc, m0 + wm * (BM / 2), n0 + wn * 64, lr, lg, a.relu_pre != 0);
 }
 
 // Row epilogue as its own HBM-bound kernel (used after gemm_tile_bf16 when the op ends in a LayerNorm, a
