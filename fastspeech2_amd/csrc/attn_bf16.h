@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void qkv_split(QkvSplitArgs a) {
 struct AttnB16Args {
     const __bf16 *qk_hi, *qk_lo; int ldqk;     // [R][2D]
     const __bf16 *vt_hi, *vt_lo; int Rvt;      // [D][Rvt]
-    float* ctx; int ldc;
+    float* ctx; int ldc;                       // fp32 context [R][ldc] (or nullptr) ...
+    void* ctxp; int ctxp_chunks;               // ... and / or split-bf16 planes, the A operand of the output projection (gemm_planes.h)
     const int* start; const int* len; const int* klen;
     const int2* work;
     int D; int mask_q;
@@ -163,7 +164,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
 #define FS2_STORE_V()                                                                                       \
     _Pragma("unroll") for (int u = 0; u < NLD; ++u) {                                                       \
         const int idx = tid + u * 256;                                                                      \
-        *reinterpret_cast<u32x4*>(Vs + swz(idx >> 3, idx & 7)) = stg[u];                                    \
+        const int d = idx >> 3;     /* head channel d -> LDS row 16 (4 (d >> 6) + (d & 3)) + ((d & 63) >> 2) */ \
+        *reinterpret_cast<u32x4*>(Vs + swz((((d >> 6) << 2) | (d & 3)) * 16 + ((d & 63) >> 2), idx & 7)) = stg[u]; \
     }
     if (ntiles > 0) {
         FS2_LOAD_K(0)
@@ -269,6 +271,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
 #undef FS2_STORE_K
 #undef FS2_LOAD_V
 #undef FS2_STORE_V
+    // V^T rows sit in LDS so that n-tile n of lane lr is head channel 64 (n >> 2) + 4 lr + (n & 3): a lane's accumulators
+    // o[4g .. 4g+3][r] are four consecutive channels of query row 4 lg + r -> 16-byte stores (or 8 + 8 bytes of planes).
     const float linv = (l_run > 0.f) ? 1.f / l_run : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -276,9 +280,15 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
         const int qrow = q0 + lg * 4 + r;
         if (qrow >= len) continue;
         const bool dead = a.mask_q && qrow >= klen;
-        float* dst = a.ctx + (size_t)(s0 + qrow) * a.ldc + (size_t)h * DK + lr;
+        const size_t row = (size_t)(s0 + qrow);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) dst[n * 16] = dead ? 0.f : o[n][r] * li;
+        for (int g = 0; g < NT / 4; ++g) {
+            const int col = h * DK + 64 * g + 4 * lr;
+            f32x4 v = f32x4{o[4 * g][r], o[4 * g + 1][r], o[4 * g + 2][r], o[4 * g + 3][r]} * li;
+            if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.ctx) *reinterpret_cast<f32x4*>(a.ctx + row * a.ldc + col) = v;
+            if (a.ctxp) store_planes4(a.ctxp, row, a.ctxp_chunks, col, v);
+        }
     }
 }
 

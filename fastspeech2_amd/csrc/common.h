@@ -49,6 +49,12 @@ struct GemmArgs {
     // but split into bf16 hi/lo planes: columns [0,2D) -> qk_hi/lo [Rvt][2D] (Q scaled by q_scale), [2D,3D) -> V^T [D][Rvt]
     void *qk_hi, *qk_lo, *vt_hi, *vt_lo; int att_D; int Rvt; float q_scale;
     float* scratch;                        // [R, N] scratch for two-pass epilogues when Y == nullptr
+    // split-bf16 activation planes (gemm_planes.h): [rows][Cpad/32][hi 32 | lo 32] bf16, 128 B per (row, chunk), the
+    // exact LDS row image of the MFMA kernels.  Xp: input planes (same rows as X); xp_scratch: where launch_gemm may
+    // build them from X when the producer did not; Yp: output planes (yp_chunks 32-channel chunks per row), written
+    // by the epilogue next to / instead of Y.
+    const void* Xp; void* xp_scratch; void* Yp; int yp_chunks;
+    int probe;                             // FS2_PROBE (performance experiments only): 1 no A refills, 2 no B refills, 4 no MFMA, 8 no epilogue, 16 XCD-aware tile order
 };
 
 __device__ __forceinline__ float wave16_sum(float v) {
@@ -73,6 +79,32 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // row offset (tap), because the two slot columns of a group then differ by the XOR of row bit 1 within closed row pairs.
 // The same permutation applies to the B operand (output column) and therefore to the C/D element -> (row, col) map.
 __device__ __forceinline__ int rperm(int i) { return i < 4 ? 2 * i + 1 : (i < 12 ? 2 * (i - 4) : 2 * (i - 12) + 9); }
+__device__ __forceinline__ int rperm_inv(int x) { return (x & 1) ? (x < 8 ? (x - 1) >> 1 : ((x - 9) >> 1) + 12) : (x >> 1) + 4; }
+
+// Split-bf16 activation planes: element (row, c) lives in chunk c>>5 at k-position p with kperm(p) == c&31 (gemm_bf16.h):
+// 4 consecutive channels c..c+3 (c % 4 == 0) are 8 contiguous bytes of the hi half and 8 of the lo half (+64 B).
+__device__ __host__ __forceinline__ size_t plane_byte(size_t row, int nchunks, int c) {
+    return (row * nchunks + (c >> 5)) * 128 + (((c & 15) >> 2) << 4) + (((c >> 4) & 1) << 3);
+}
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4(const f32x4 v, uint2& hi, uint2& lo) {
+    bf16x4_t h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 hb = (__bf16)v[j];
+        h[j] = hb;
+        l[j] = (__bf16)(v[j] - (float)hb);
+    }
+    hi = *reinterpret_cast<uint2*>(&h);
+    lo = *reinterpret_cast<uint2*>(&l);
+}
+__device__ __forceinline__ void store_planes4(void* planes, size_t row, int nchunks, int c, const f32x4 v) {
+    uint2 hi, lo;
+    split4(v, hi, lo);
+    char* p = reinterpret_cast<char*>(planes) + plane_byte(row, nchunks, c);
+    *reinterpret_cast<uint2*>(p) = hi;
+    *reinterpret_cast<uint2*>(p + 64) = lo;
+}
 
 // Elementwise epilogue of a (16 MT) x 64 wave tile held as acc[MT][4] (16 x 16 MFMA tiles, C layout col = l&15,
 // row = 4*(l>>4) + reg).  All loads of a 16-row slab (row flags, residual) are issued before its stores and the

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "elementwise.h"
 #include "gemm_bf16.h"
+#include "gemm_planes.h"
 #include "gemm_f32.h"
 
 using namespace fs2;
@@ -217,6 +218,42 @@ hipError_t launch_tile_bf16(hipStream_t s, const GemmArgs& a) {
     return sm ? launch_tile_bf16_t<NSPLIT, 64>(s, a) : launch_tile_bf16_t<NSPLIT, 128>(s, a);
 }
 
+template <int NSPLIT, int BM, bool K1>
+hipError_t launch_pl_t(hipStream_t s, const GemmArgs& a) {
+    static bool attr = false;
+    constexpr size_t lds = pl_lds_bytes<BM, K1>();
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pl_bf16<NSPLIT, BM, K1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    GemmArgs b = a;
+    const char* pe = getenv("FS2_PROBE");
+    b.probe = pe ? atoi(pe) : 0;
+    int nM = ((a.qk_hi ? a.Rvt : a.R) + BM - 1) / BM;
+    if (b.probe & 16) nM = round_up(nM, 8);
+    dim3 grid((a.N + kB16BN - 1) / kB16BN, nM);
+    hipLaunchKernelGGL((gemm_pl_bf16<NSPLIT, BM, K1>), grid, dim3(256), lds, s, b);
+    return hipGetLastError();
+}
+
+// Tile height of the planes kernel: the largest one that still gives every CU its 2-3 resident workgroups
+// (FS2_BM=64|128|256 forces one; k = 1 GEMMs have no 256-row form: two 256-row A buffers would not fit two workgroups per CU).
+template <int NSPLIT>
+hipError_t launch_pl(hipStream_t s, const GemmArgs& a) {
+    const char* e = getenv("FS2_BM");
+    const int force = !e ? 0 : atoi(e);
+    const long rows = a.qk_hi ? a.Rvt : a.R;
+    const long nN = (a.N + kB16BN - 1) / kB16BN;
+    int bm;
+    if (a.ktaps == 1) {
+        bm = (force == 64 || force == 128) ? force : 64;     // measured (c3): 64-row tiles win for every k = 1 GEMM (3 workgroups/CU hide the DMA round trips)
+        return bm == 128 ? launch_pl_t<NSPLIT, 128, true>(s, a) : launch_pl_t<NSPLIT, 64, true>(s, a);
+    }
+    bm = force ? force : (nN * ((rows + 255) / 256) >= 512 ? 256 : (nN * ((rows + 127) / 128) >= 400 ? 128 : 64));
+    if (bm == 256) return launch_pl_t<NSPLIT, 256, false>(s, a);
+    return bm == 128 ? launch_pl_t<NSPLIT, 128, false>(s, a) : launch_pl_t<NSPLIT, 64, false>(s, a);
+}
+
 // Picks the kernel.  fp32: row-complete tiles when the epilogue needs whole rows, 128x128 tiles otherwise.
 // bf16 / bf16x3: one 256x128 MFMA tile kernel (+ elementwise epilogue), followed by the HBM-bound row kernel
 // when the op ends in LayerNorm / positional encoding / scalar head.
@@ -232,13 +269,27 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         if (a.C % 8 != 0 || a.N % 4 != 0 || (need_rows && a.N > 1024)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: bf16 path needs C %% 8 == 0, N %% 4 == 0 (N <= 1024 with a row epilogue)", name);
         GemmArgs t = a;
         t.W = reinterpret_cast<const float*>(a.Wb);
-        if (!t.Y && !t.qk_hi) { t.Y = a.scratch; t.ldy = a.N; }
-        if (!t.Y && !t.qk_hi) return fail(h, FS2_ERR_ARG, "%s: no output or scratch buffer", name);
+        // planes kernel (gemm_planes.h) whenever the A operand exists as split-bf16 planes or may be built in xp_scratch
+        const bool planes = (a.Xp || a.xp_scratch) && gemm_choice() == 0 && a.ldy % 4 == 0 && (!a.resid || a.ldr % 4 == 0) &&
+                            (!a.qk_hi || a.att_D % kB16BN == 0);
+        const bool y_needed = need_rows || (!a.Yp && !a.qk_hi);
+        if (!t.Y && y_needed) { t.Y = a.scratch; t.ldy = a.N; }
+        if (!t.Y && y_needed) return fail(h, FS2_ERR_ARG, "%s: no output or scratch buffer", name);
         if (t.qk_hi && (a.ktaps != 1 || a.att_D % kB16BN != 0 || a.N != 3 * a.att_D)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: fused QKV split needs D %% 128 == 0", name);
-        if (need_rows) t.act_post = 0;
+        if (a.Yp && !planes) return fail(h, FS2_ERR_STATE, "%s: plane output requested on the fp32-input kernels", name);
+        if (need_rows) { t.act_post = 0; t.Yp = nullptr; }      // the row kernel writes the planes
+        if (planes && !a.Xp) {
+            char nm[112];
+            snprintf(nm, sizeof nm, "%s.planes", name);
+            Scope sc(h, s, nm, 0.0, 8.0 * a.R * a.Cpad);
+            const int64_t n = (int64_t)a.R * (a.Cpad / 4);
+            hipLaunchKernelGGL(to_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.X, a.ldx, a.C, a.R, a.Cpad / 32, a.xp_scratch);
+            t.Xp = a.xp_scratch;
+        }
         {
             Scope sc(h, s, name, flops, bytes);
-            e = (precision == FS2_PREC_BF16X3) ? launch_tile_bf16<3>(s, t) : launch_tile_bf16<1>(s, t);
+            if (planes) e = (precision == FS2_PREC_BF16X3) ? launch_pl<3>(s, t) : launch_pl<1>(s, t);
+            else e = (precision == FS2_PREC_BF16X3) ? launch_tile_bf16<3>(s, t) : launch_tile_bf16<1>(s, t);
         }
         if (e == hipSuccess && need_rows) {
             char nm[112];
@@ -334,7 +385,7 @@ hipError_t launch_attn_b16_t(hipStream_t s, dim3 grid, const AttnB16Args& a) {
 // qkv fp32 [R,3D] -> split planes -> attention.  planes: qk_hi/lo [Rvt][2D], vt_hi/lo [D][Rvt] (Rvt % 32 == 0)
 int launch_attention_b16(fs2_handle* h, hipStream_t s, const char* name, const float* qkv, float* ctx, int D, int heads, int R, int Rvt,
                          const DevLayout& dl, int nwork, int mask_q, double flops, int precision, __bf16* qkh, __bf16* qkl, __bf16* vth,
-                         __bf16* vtl) {
+                         __bf16* vtl, void* ctxp = nullptr) {
     const int dk = D / heads;
     if (nwork == 0) return FS2_OK;
     if (qkv != nullptr) {
@@ -353,6 +404,7 @@ int launch_attention_b16(fs2_handle* h, hipStream_t s, const char* name, const f
     }
     AttnB16Args a;
     a.qk_hi = qkh; a.qk_lo = qkl; a.ldqk = 2 * D; a.vt_hi = vth; a.vt_lo = vtl; a.Rvt = Rvt; a.ctx = ctx; a.ldc = D;
+    a.ctxp = ctxp; a.ctxp_chunks = D / 32;
     a.start = dl.start; a.len = dl.len; a.klen = dl.klen; a.work = dl.work; a.D = D; a.mask_q = mask_q;
     Scope sc(h, s, name, flops, 0.0);
     dim3 grid(nwork, heads);
@@ -407,19 +459,33 @@ int upload_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, D
 }
 
 // ------------------------------------------------------------------ FFT block stack
-struct StackBufs { float *x0, *x1, *qkv, *ctx, *hid; __bf16 *qkh, *qkl, *vth, *vtl; };
+// x0p / x1p: split-bf16 planes of x0 / x1 (gemm_planes.h); xps: planes scratch for activations produced without planes.
+// In the bf16 modes the attention context and the FFN hidden layer exist ONLY as planes, in the ctx / hid storage.
+struct StackBufs { float *x0, *x1, *qkv, *ctx, *hid; __bf16 *qkh, *qkl, *vth, *vtl; void *x0p, *x1p, *xps; };
 
 // x0 holds the input; returns the buffer holding the output (x0 again).
 int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, int D, int heads, int R,
-              const HostLayout& L, const DevLayout& dl, int mask_q, const StackBufs& b, int prec) {
+              const HostLayout& L, const DevLayout& dl, int mask_q, const StackBufs& b, int prec, bool x0p_ready = false) {
     char nm[96];
     double att_flops = 0;
     for (int i = 0; i < L.B; ++i) att_flops += 4.0 * D * (double)L.klen[i] * std::min(L.len[i], mask_q ? L.klen[i] : L.len[i]);
+    // bf16 modes: activations travel between the GEMMs as split-bf16 planes (no conversion work inside the MFMA loops)
+    const int hidden = st.layers.empty() ? 0 : st.layers[0].w1.N;
+    const bool pl = prec != FS2_PREC_FP32 && gemm_choice() == 0 && D % 32 == 0 && hidden % 32 == 0 && b.x0p && b.x1p;
+    void* ctxp = pl ? (void*)b.ctx : nullptr;
+    void* hidp = pl ? (void*)b.hid : nullptr;
+    if (pl && !x0p_ready) {
+        snprintf(nm, sizeof nm, "%s.in.planes", tag);
+        Scope sc(h, s, nm, 0.0, 8.0 * R * D);
+        const int64_t n = (int64_t)R * (D / 4);
+        hipLaunchKernelGGL(to_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, b.x0, D, D, R, D / 32, b.x0p);
+    }
     for (size_t li = 0; li < st.layers.size(); ++li) {
         const Layer& ly = st.layers[li];
         int rc;
         snprintf(nm, sizeof nm, "%s.qkv", tag);
         GemmArgs a = gemm_args(ly.qkv, b.x0, D, R, dl.row_pos, b.qkv, 3 * D);
+        if (pl) a.Xp = b.x0p;
         const bool fused_split = prec != FS2_PREC_FP32 && D % kB16BN == 0 && gemm_choice() != 2;
         if (fused_split) {   // bf16 attention operands straight from the GEMM epilogue (no fp32 QKV round trip)
             a.Y = nullptr; a.qk_hi = b.qkh; a.qk_lo = b.qkl; a.vt_hi = b.vth; a.vt_lo = b.vtl; a.att_D = D; a.Rvt = L.Rpad;
@@ -428,19 +494,22 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.attn", tag);
         if (prec == FS2_PREC_FP32) rc = launch_attention(h, s, nm, b.qkv, b.ctx, D, heads, dl, (int)L.work.size(), mask_q, att_flops);
-        else rc = launch_attention_b16(h, s, nm, fused_split ? nullptr : b.qkv, b.ctx, D, heads, R, L.Rpad, dl, (int)L.work.size(), mask_q, att_flops, prec, b.qkh, b.qkl, b.vth, b.vtl);
+        else rc = launch_attention_b16(h, s, nm, fused_split ? nullptr : b.qkv, pl ? nullptr : b.ctx, D, heads, R, L.Rpad, dl, (int)L.work.size(), mask_q, att_flops, prec, b.qkh, b.qkl, b.vth, b.vtl, ctxp);
         if (rc) return rc;
         snprintf(nm, sizeof nm, "%s.out_ln", tag);
         a = gemm_args(ly.out, b.ctx, D, R, dl.row_pos, b.x1, D);
         a.resid = b.x0; a.ldr = D; a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
+        if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.ffn1", tag);
-        a = gemm_args(ly.w1, b.x1, D, R, dl.row_pos, b.hid, ly.w1.N);
+        a = gemm_args(ly.w1, b.x1, D, R, dl.row_pos, pl ? nullptr : b.hid, ly.w1.N);
         a.act_post = 1;
+        if (pl) { a.Xp = b.x1p; a.Yp = hidp; a.yp_chunks = ly.w1.N / 32; }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.ffn2_ln", tag);
         a = gemm_args(ly.w2, b.hid, ly.w1.N, R, dl.row_pos, b.x0, D);
         a.resid = b.x1; a.ldr = D; a.ln_g = ly.ln2g; a.ln_b = ly.ln2b; a.ln_eps = 1e-5f;
+        if (pl) { a.Xp = hidp; a.Yp = b.x0p; a.yp_chunks = D / 32; }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
     }
     return FS2_OK;
@@ -449,7 +518,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
 // conv stack + scalar head (reference variance_predictor.py:46-51 / duration_predictor.py:70-75);
 // tmp0/tmp1: [R, chans] scratch; out_rows: [R]
 int run_predictor(fs2_handle* h, hipStream_t s, const char* tag, const Predictor& p, const float* X, int ldx, int R,
-                  const int* row_pos, float* tmp0, float* tmp1, float* out_rows, int prec) {
+                  const int* row_pos, float* tmp0, float* tmp1, float* out_rows, int prec, const void* Xp = nullptr, void* xps = nullptr) {
     char nm[96];
     const float* in = X; int ld = ldx;
     float* bufs[2] = {tmp0, tmp1};
@@ -460,6 +529,11 @@ int run_predictor(fs2_handle* h, hipStream_t s, const char* tag, const Predictor
         a.relu_pre = 1; a.ln_g = p.lng[l]; a.ln_b = p.lnb[l]; a.ln_eps = 1e-12f;
         if (last) { a.dot_w = p.lin_w; a.dot_b = p.lin_b; a.dot_out = out_rows; }
         a.scratch = out;
+        // planes: the first layer's input from the caller (or built in xps), later layers' from the row kernel of the
+        // previous one (it runs after the GEMM that read xps, so the buffer can be reused in place)
+        a.Xp = Xp; a.xp_scratch = xps;
+        if (xps && !last) { a.Yp = xps; a.yp_chunks = round_up(p.conv[l].N, 32) / 32; }
+        if (xps && !last) Xp = xps; else Xp = nullptr;
         snprintf(nm, sizeof nm, "%s.conv%d", tag, (int)l);
         int rc = launch_gemm(h, s, nm, a, prec);
         if (rc) return rc;
@@ -634,6 +708,10 @@ size_t carve_tokens(const fs2_config& c, const fs2_batch& b, const HostLayout& L
     __bf16* qkl = bp.take<__bf16>(R * 2 * c.adim);
     __bf16* vth = bp.take<__bf16>(R * c.adim);
     __bf16* vtl = bp.take<__bf16>(R * c.adim);
+    const size_t pw = round_up(c.adim, 32);
+    float* x0p = bp.take<float>(R * pw);
+    float* x1p = bp.take<float>(R * pw);
+    float* xps = bp.take<float>(R * (size_t)round_up(std::max(c.adim, c.dur_chans), 32));
     float* q0 = bp.take<float>(R * c.dur_chans);
     float* q1 = bp.take<float>(R * c.dur_chans);
     float* dl = bp.take<float>(R);
@@ -641,7 +719,7 @@ size_t carve_tokens(const fs2_config& c, const fs2_batch& b, const HostLayout& L
     int* cu = bp.take<int>((size_t)b.B * b.Tmax);
     int* o32 = bp.take<int>(b.B);
     if (meta) *meta = m;
-    if (sb) { sb->x0 = x0; sb->x1 = x1; sb->qkv = qkv; sb->ctx = ctx; sb->hid = hid; sb->qkh = qkh; sb->qkl = qkl; sb->vth = vth; sb->vtl = vtl; }
+    if (sb) { sb->x0 = x0; sb->x1 = x1; sb->qkv = qkv; sb->ctx = ctx; sb->hid = hid; sb->qkh = qkh; sb->qkl = qkl; sb->vth = vth; sb->vtl = vtl; sb->x0p = x0p; sb->x1p = x1p; sb->xps = xps; }
     if (p0) *p0 = q0;
     if (p1) *p1 = q1;
     if (dlog_rows) *dlog_rows = dl;
@@ -675,6 +753,9 @@ size_t carve_frames(const fs2_config& c, const HostLayout& L, void* ws, size_t c
     f.sb.qkl = bp.take<__bf16>(R * 2 * c.ddim);
     f.sb.vth = bp.take<__bf16>(R * c.ddim);
     f.sb.vtl = bp.take<__bf16>(R * c.ddim);
+    f.sb.x0p = bp.take<float>(R * (size_t)round_up(std::max(c.ddim, c.postnet_chans), 32));
+    f.sb.x1p = bp.take<float>(R * (size_t)round_up(std::max(c.ddim, c.postnet_chans), 32));
+    f.sb.xps = bp.take<float>(R * (size_t)round_up(std::max(std::max(c.adim, c.ddim), std::max(std::max(c.var_chans, c.postnet_chans), c.odim)), 32));
     f.before = bp.take<float>(R * c.odim);
     f.after = bp.take<float>(R * c.odim);
     f.qe = bp.take<int>(R);
@@ -857,7 +938,8 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
         HIP_TRY(h, hipGetLastError());
     }
     if ((rc = run_stack(h, s, "enc", h->enc, c.adim, c.aheads, L.R, L, dl, /*mask_q=*/1, sb, b.precision))) return rc;
-    if ((rc = run_predictor(h, s, "dur", h->dur, sb.x0, c.adim, L.R, dl.row_pos, p0, p1, dlog_rows, b.precision))) return rc;
+    const bool enc_pl = b.precision != FS2_PREC_FP32 && gemm_choice() == 0 && c.adim % 32 == 0 && c.eunits % 32 == 0;   // run_stack left planes of x0 in x0p
+    if ((rc = run_predictor(h, s, "dur", h->dur, sb.x0, c.adim, L.R, dl.row_pos, p0, p1, dlog_rows, b.precision, enc_pl ? sb.x0p : nullptr, sb.xps))) return rc;
     {
         Scope sc(h, s, "dur.post", 0, 0);
         const int n = b.B * b.Tmax;
@@ -917,18 +999,21 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         HIP_TRY(h, hipGetLastError());
     }
     const bool need_e = (io->es == nullptr) || io->e_out, need_p = (io->ps == nullptr) || io->p_out;
-    if (need_e && (rc = run_predictor(h, s, "energy", h->energy, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.e_rows, b.precision))) return rc;
-    if (need_p && (rc = run_predictor(h, s, "pitch", h->pitch, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.p_rows, b.precision))) return rc;
+    if (need_e && (rc = run_predictor(h, s, "energy", h->energy, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.e_rows, b.precision, nullptr, f.sb.xps))) return rc;
+    if (need_p && (rc = run_predictor(h, s, "pitch", h->pitch, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.p_rows, b.precision, nullptr, f.sb.xps))) return rc;
     {
         Scope sc(h, s, "var.embed", 0, 4.0 * R * c.adim * 4);
         hipLaunchKernelGGL(bucket_embed, dim3((R + 3) / 4), dim3(256), 0, s, f.hfr, c.adim, dl.row_pos, dl.row_seq, R, io->es, io->es_stride,
                            io->ps, io->ps_stride, f.e_rows, f.p_rows, h->ebins, h->pbins, c.n_bins - 1, h->Te, h->Tp, f.qe, f.qp);
         HIP_TRY(h, hipGetLastError());
     }
+    const bool dec_pl = b.precision != FS2_PREC_FP32 && gemm_choice() == 0 && c.ddim % 32 == 0 && c.dunits % 32 == 0;
     if (c.decoder_input_layer) {   // decoder input layer: Linear -> LN -> ReLU -> + alpha * pe   (reference encoder.py:118-125)
         GemmArgs a = gemm_args(h->dec_in, f.hfr, c.adim, R, dl.row_pos, f.sb.x0, c.ddim);
         a.ln_g = h->dec_in_lng; a.ln_b = h->dec_in_lnb; a.ln_eps = 1e-5f; a.act_post = 1;
         a.pe = h->dec.pe; a.pe_ld = c.ddim; a.pe_alpha = h->dec.alpha; a.x_scale = c.use_scaled_pos_enc ? 1.f : sqrtf((float)c.ddim);
+        a.xp_scratch = f.sb.xps;
+        if (dec_pl) { a.Yp = f.sb.x0p; a.yp_chunks = c.ddim / 32; }
         if ((rc = launch_gemm(h, s, "dec.in", a, b.precision))) return rc;
     } else {                       // TorchScript twin: the decoder input is just x (* sqrt(d)) + alpha * pe   (encoder.py:138-141)
         Scope sc(h, s, "dec.in.pe", 0.0, 8.0 * R * c.ddim);
@@ -937,13 +1022,18 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         memset(&a, 0, sizeof a);
         a.N = c.ddim; a.R = R; a.row_pos = dl.row_pos; a.Y = f.sb.x0; a.ldy = c.ddim;
         a.pe = h->dec.pe; a.pe_ld = c.ddim; a.pe_alpha = h->dec.alpha; a.x_scale = c.use_scaled_pos_enc ? 1.f : sqrtf((float)c.ddim);
+        if (dec_pl) { a.Yp = f.sb.x0p; a.yp_chunks = c.ddim / 32; }
         hipLaunchKernelGGL(ln_rows, dim3((R + 3) / 4), dim3(256), 0, s, a);
         HIP_TRY(h, hipGetLastError());
     }
     const int mask_q = (b.compat_padded && io->masked) ? 1 : 0;
-    if ((rc = run_stack(h, s, "dec", h->dec, c.ddim, c.aheads, R, L, dl, mask_q, f.sb, b.precision))) return rc;
+    if ((rc = run_stack(h, s, "dec", h->dec, c.ddim, c.aheads, R, L, dl, mask_q, f.sb, b.precision, /*x0p_ready=*/dec_pl))) return rc;
+    // planes hand-off through the tail: decoder -> feat_out (fp32 mel + planes of it) -> Postnet convs ping-pong x0p / x1p
+    const bool post_pl = dec_pl && c.postnet_layers > 1;
     {
         GemmArgs a = gemm_args(h->feat, f.sb.x0, c.ddim, R, dl.row_pos, f.before, c.odim);
+        if (dec_pl) a.Xp = f.sb.x0p;
+        if (post_pl) { a.Yp = f.sb.xps; a.yp_chunks = round_up(c.odim, 32) / 32; }
         if ((rc = launch_gemm(h, s, "feat_out", a, b.precision))) return rc;
     }
     const float* mel_after = f.before;
@@ -956,6 +1046,12 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
             float* out = last ? f.after : ((l & 1) ? pb : pa);
             GemmArgs a = gemm_args(h->post[l], in, ld, R, dl.row_pos, out, h->post[l].N);
             if (!last) a.act_post = 2; else { a.resid = f.before; a.ldr = c.odim; }
+            if (post_pl) {
+                a.Xp = (l == 0) ? f.sb.xps : ((l & 1) ? f.sb.x0p : f.sb.x1p);
+                if (!last) { a.Y = nullptr; a.Yp = (l & 1) ? f.sb.x1p : f.sb.x0p; a.yp_chunks = round_up(h->post[l].N, 32) / 32; }
+            } else {
+                a.xp_scratch = f.sb.xps;
+            }
             char nm[32]; snprintf(nm, sizeof nm, "postnet.%d", l);
             if ((rc = launch_gemm(h, s, nm, a, b.precision))) return rc;
             in = out; ld = h->post[l].N;
@@ -1004,6 +1100,8 @@ int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
     OP_TRY(hipMalloc((void**)&g.wb, wn * 4));
     float* scratch = nullptr;
     OP_TRY(hipMalloc((void**)&scratch, (size_t)o->R * o->N * sizeof(float)));
+    void* xps = nullptr;          // planes of x for the bf16 modes (gemm_planes.h); FS2_GEMM=regs|glds selects the fp32-input kernels
+    if (o->precision != FS2_PREC_FP32) OP_TRY(hipMalloc(&xps, (size_t)o->R * g.Cpad * sizeof(float)));
     int* rp = nullptr;
     hipMemsetAsync(g.w, 0, wn * sizeof(float), s);
     hipMemsetAsync(g.wb, 0, wn * 4, s);
@@ -1027,9 +1125,11 @@ int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
     }
     a.resid = o->resid; a.ldr = o->N; a.relu_pre = o->relu_pre; a.ln_g = o->ln_gamma; a.ln_b = o->ln_beta; a.ln_eps = o->ln_eps;
     a.act_post = o->act_post; a.dot_w = o->dot_w; a.dot_b = o->dot_b; a.dot_out = o->dot_out;
+    a.xp_scratch = xps;
     int rc = launch_gemm(nullptr, s, "op.conv_gemm", a, o->precision);
     hipStreamSynchronize(s);
     hipFree(g.w); hipFree(g.wb); hipFree(scratch);
+    if (xps) hipFree(xps);
     if (rp) hipFree(rp);
     return rc;
 }

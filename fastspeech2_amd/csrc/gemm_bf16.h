@@ -195,12 +195,15 @@ __global__ __launch_bounds__(256, 3) void gemm_tile_bf16(GemmArgs a) {
 // transposed (8 consecutive rows of one column per lane -> V^T [D][Rvt], key index contiguous).  Rows that are gaps
 // or beyond R are written as zeros (P = 0 times a non-finite V would poison the P.V sum).
 constexpr int kQkvLd = kB16BN + 4;      // fp32 tile row stride in LDS (floats)
+// second half of the fused QKV epilogue: fp32 tile (bias already added) in LDS -> split-bf16 attention operands in HBM
+template <int BM>
+__device__ __forceinline__ void qkv_tile_store(const GemmArgs& a, const float* tile, int m0, int n0, int tid);
+
 template <int BM>
 __device__ __forceinline__ void qkv_split_epilogue(const GemmArgs& a, f32x4 (&acc)[BM / 32][4], float* tile, int m0, int n0, int wm, int wn,
                                                    int lr, int lg, int tid) {
     constexpr int MT = BM / 32;
     const float* __restrict__ biasp = a.bias;
-    const int* __restrict__ rpos = a.row_pos;
     __syncthreads();                      // the operand buffers are dead: reuse them for the output tile
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -212,6 +215,12 @@ __device__ __forceinline__ void qkv_split_epilogue(const GemmArgs& a, f32x4 (&ac
             for (int r = 0; r < 4; ++r) tile[(wm * (BM / 2) + mt * 16 + rperm(lg * 4 + r)) * kQkvLd + cl] = acc[mt][nt][r] + bv;
     }
     __syncthreads();
+    qkv_tile_store<BM>(a, tile, m0, n0, tid);
+}
+
+template <int BM>
+__device__ __forceinline__ void qkv_tile_store(const GemmArgs& a, const float* tile, int m0, int n0, int tid) {
+    const int* __restrict__ rpos = a.row_pos;
     const int D = a.att_D;
     __bf16* qkh = reinterpret_cast<__bf16*>(a.qk_hi);
     __bf16* qkl = reinterpret_cast<__bf16*>(a.qk_lo);
@@ -389,14 +398,17 @@ __global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
 // Row epilogue as its own HBM-bound kernel (used after gemm_tile_bf16 when the op ends in a LayerNorm, a
 // positional-encoding add or the scalar head): in place on Y [R, N], one wavefront per row, N <= 1024.
 //   v = LN(y) (if ln_g) -> act_post -> v*x_scale + alpha*pe[pos] -> store; dot_out[row] = v . dot_w + dot_b
+// With Yp the result is also written as split-bf16 planes, the A operand of the next GEMM (gemm_planes.h).
 __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= a.R) return;
     const int pos = a.row_pos ? a.row_pos[row] : 0;
     float* y = a.Y + (size_t)row * a.ldy;
+    const int pc = a.Yp ? a.yp_chunks * 32 : 0;      // channels of the output planes (>= N, zero padded)
     if (pos < 0) {
         for (int c = lane * 4; c < a.N; c += 256) *reinterpret_cast<float4*>(y + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = lane * 4; c < pc; c += 256) store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{0.f, 0.f, 0.f, 0.f});
         if (a.dot_w && lane == 0) a.dot_out[row] = 0.f;
         return;
     }
@@ -454,6 +466,9 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
                 d += (t.x * w.x + t.y * w.y) + (t.z * w.z + t.w * w.w);
             }
             *reinterpret_cast<float4*>(y + c) = t;
+            if (a.Yp) store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{t.x, t.y, t.z, t.w});
+        } else if (c < pc) {
+            store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{0.f, 0.f, 0.f, 0.f});
         }
     }
     if (a.dot_w) {

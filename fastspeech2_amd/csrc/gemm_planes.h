@@ -1,0 +1,221 @@
+// gemm_pl_bf16: the split-bf16 conv-as-GEMM with BOTH operands streamed by LDS-DMA and no conversion work in the loop.
+//
+// gemm_tile_bf16 / gemm_glds_bf16 (gemm_bf16.h) read fp32 activations and split them into bf16 hi/lo in the kernel;
+// PMC showed what that costs: 0.9 (9-tap conv) to 8 (k = 1 GEMMs) VALU instructions per MFMA, i.e. the k = 1 GEMMs
+// were VALU-bound at ~25 % of the MFMA rate.  Here the PRODUCER of an activation writes it once as "planes",
+//     Xp[row][chunk] = 128 B = [hi: 32 bf16 in kperm order | lo: 32 bf16],      (common.h: plane_byte / store_planes4)
+// which is byte-for-byte the LDS row image of the MFMA loop, so the A tile is a plain 1-KB-per-instruction DMA
+// (8 rows x 128 B) exactly like the weight image.  Same HBM bytes as the fp32 tensor it replaces.
+//   * tile BM x 128, 4 waves as 2(M) x 2(N), wave tile (BM/2) x 64; BM = 64 / 128 (3 or 2 workgroups per CU) or,
+//     conv form only, 256 (2 per CU, 128 accumulator registers per lane): per MFMA a 256-row tile reads 25 % less
+//     LDS and half the weight bytes of the 128-row one and meets half as many barriers.
+//   * conv form (ktaps > 1): one A buffer (BM + halo rows) shared by the taps, refilled once per 32-channel chunk;
+//     k = 1 form: A double-buffered like B.  One barrier per k-step.
+//   * B rows are DMA'd in a permuted order: the LDS row that lane lr reads for n-tile nt holds output channel
+//     64 wn + 4 lr + nt, so the four accumulators acc[mt][0..3][r] of a lane are FOUR CONSECUTIVE CHANNELS of one
+//     row: the epilogue moves 16-byte pieces (float4 bias / residual / store, or 8 + 8 bytes of hi / lo planes)
+//     instead of 4-byte ones, without any shuffle.
+//   * A rows keep the conflict-free lane -> row permutation rperm (common.h).
+#pragma once
+#include "gemm_bf16.h"
+
+namespace fs2 {
+
+template <int BM, bool K1> constexpr int pl_arows() { return K1 ? BM : BM + kMaxHalo; }
+template <int BM, bool K1>
+constexpr size_t pl_lds_bytes() {
+    const size_t ops = (size_t)(K1 ? 2 : 1) * pl_arows<BM, K1>() * 128 + 2 * (size_t)kB16BN * 128;
+    const size_t out = (K1 && BM <= 128) ? (size_t)BM * kQkvLd * 4 : 0;       // fused QKV epilogue stages the fp32 tile here
+    return ops > out ? ops : out;
+}
+template <int BM, bool K1> constexpr int pl_occ() { return pl_lds_bytes<BM, K1>() > 53 * 1024 ? 2 : 3; }
+
+// fp32 [R, ldx] -> planes (for activations whose producer is not plane-aware); channels >= C are zero
+__global__ void to_planes(const float* __restrict__ X, int ldx, int C, int R, int nchunks, void* __restrict__ Xp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_row = nchunks * 8;
+    if (i >= (int64_t)R * per_row) return;
+    const int row = (int)(i / per_row), c = (int)(i - (int64_t)row * per_row) * 4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < C) v = *reinterpret_cast<const f32x4*>(X + (size_t)row * ldx + c);
+    store_planes4(Xp, row, nchunks, c, v);
+}
+
+// Elementwise epilogue on 4-channel pieces: bias, ReLU, residual, activation, gap rows -> 0; fp32 and / or planes out.
+template <int MT>
+__device__ __forceinline__ void pl_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][4], int row_base, int col, int lg) {
+    const float* __restrict__ biasp = a.bias;
+    const float* __restrict__ residp = a.resid;
+    const int* __restrict__ rpos = a.row_pos;
+    float* __restrict__ Y = a.Y;
+    void* __restrict__ Yp = a.Yp;
+    const bool colok = col < a.N;
+    const bool pcol = Yp != nullptr && col < a.yp_chunks * 32;
+    const bool relu_first = a.relu_pre != 0;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (biasp && colok) bv = *reinterpret_cast<const f32x4*>(biasp + col);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        bool inb[4], valid[4];
+        f32x4 rv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row_base + mt * 16 + rperm(lg * 4 + r);
+            inb[r] = row < a.R;
+            valid[r] = inb[r] && (rpos == nullptr || rpos[row] >= 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row_base + mt * 16 + rperm(lg * 4 + r);
+            rv[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (residp && inb[r] && colok) rv[r] = *reinterpret_cast<const f32x4*>(residp + (size_t)row * a.ldr + col);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row_base + mt * 16 + rperm(lg * 4 + r);
+            f32x4 v = f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]} + bv + rv[r];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = v[j];
+                if (relu_first) t = fmaxf(t, 0.f);
+                t = apply_act(t, a.act_post);
+                v[j] = (valid[r] && colok) ? t : 0.f;
+            }
+            if (Y && inb[r] && colok) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
+            if (pcol && inb[r]) store_planes4(Yp, row, a.yp_chunks, col, v);
+        }
+    }
+}
+
+template <int NSPLIT, int BM, bool K1>
+__global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs a) {
+    constexpr int MT = BM / 32;               // 16-row MFMA tiles per wave (wave tile = BM/2 x 64)
+    constexpr int AROWS = pl_arows<BM, K1>();
+    extern __shared__ __attribute__((aligned(16))) char smem_p[];
+    char* As0 = smem_p;
+    char* Bs0 = smem_p + (K1 ? 2 : 1) * AROWS * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int tn = blockIdx.x, tm = blockIdx.y;
+    if (a.probe & 16) {      // workgroup L runs on XCD L % 8: give one XCD all N tiles of an M tile (A tile fetched into one L2 only)
+        const int L = blockIdx.y * gridDim.x + blockIdx.x, k = L >> 3;
+        tn = k % (int)gridDim.x;
+        tm = (k / (int)gridDim.x) * 8 + (L & 7);
+        if (tm * BM >= (a.qk_hi ? a.Rvt : a.R)) return;
+    }
+    const int n0 = tn * kB16BN, m0 = tm * BM;
+    const int ktaps = K1 ? 1 : a.ktaps;
+    const int P = (ktaps - 1) >> 1;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int lp = rperm(lr);
+    const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
+    const __bf16* Xp = reinterpret_cast<const __bf16*>(a.Xp);
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = a.Cpad / 32;
+    const int niter = nchunks * ktaps;
+    const int jrow = lane >> 3, jslot = lane & 7;        // this lane's (row, physical slot) inside a 1-KB DMA instruction
+
+    // A: wave w issues instructions q = w, w+4, ... (8 tile rows each).  The swizzle term ((r >> 1) & 7) of tile row
+    // r = 8q + jrow is 4 (q & 1) + (jrow >> 1) and q & 1 == w & 1, so the logical slot this lane fetches is a constant.
+    const int a_instr = K1 ? BM / 8 : (BM + 2 * P + 7) >> 3;
+    const int sA = jslot ^ (jrow >> 1) ^ ((wave & 1) << 2);
+    const int arow0 = m0 - P + wave * 8 + jrow;
+    const __bf16* a_src0 = Xp + (ptrdiff_t)arow0 * nchunks * 64 + sA * 8;      // dereferenced only when the row is in [0, R)
+    const size_t a_qstride = (size_t)32 * nchunks * 64;
+    auto dma_A = [&](int ch, int buf) {
+        char* dst = As0 + buf * (AROWS * 128) + wave * 1024;
+        const __bf16* src = a_src0 + (size_t)ch * 64;
+        int row = arow0;
+        for (int q = wave; q < a_instr; q += 4) {
+            const bool ok = row >= 0 && row < a.R;
+            const void* sp = ok ? static_cast<const void*>(src) : static_cast<const void*>(g_zero16);
+            __builtin_amdgcn_global_load_lds(sp, (lds_void_t*)dst, 16, 0, 0);
+            dst += 4096; src += a_qstride; row += 32;
+        }
+    };
+    // B: instruction q = w + 4u fills LDS rows 8q + jrow = 64 (u >> 1) + 16 ((w >> 1) + 2 (u & 1)) + (8 (w & 1) + jrow),
+    // i.e. n-tile nt = (w >> 1) + 2 (u & 1) of column half u >> 1, tile row jB; it receives weight row
+    // 64 (u >> 1) + 4 rperm_inv(jB) + nt (see the header): one per-lane pointer + three uniform offsets.
+    const int jB = (wave & 1) * 8 + jrow;
+    const int sB = jslot ^ ((jB >> 1) & 7);
+    const __bf16* b_src0 = Wb + ((size_t)(n0 + 4 * rperm_inv(jB) + (wave >> 1)) * niter) * 64 + sB * 8;
+    const size_t b_o1 = (size_t)2 * niter * 64, b_o2 = (size_t)64 * niter * 64;
+    auto dma_B = [&](int it, int buf) {
+        char* dst = Bs0 + buf * (kB16BN * 128) + wave * 1024;
+        const __bf16* src = b_src0 + (size_t)it * 64;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            __builtin_amdgcn_global_load_lds(src + (u & 1) * b_o1 + (u >> 1) * b_o2, (lds_void_t*)(dst + u * 4096), 16, 0, 0);
+    };
+
+    dma_A(0, 0);
+    dma_B(0, 0);
+    int it = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        for (int tap = 0; tap < ktaps; ++tap, ++it) {
+            dma_barrier();     // DMA of step `it` landed; every wave is done with step it-1
+            if (it + 1 < niter) {
+                if (!(a.probe & 2)) dma_B(it + 1, (it + 1) & 1);
+                if (K1 && !(a.probe & 1)) dma_A(it + 1, (it + 1) & 1);
+            }
+            const char* As = As0 + (K1 ? (it & 1) : 0) * (AROWS * 128);
+            const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
+            bf16x8_t bh[4], bl[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = wn * 64 + nt * 16 + lp;
+                bh[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
+                if (NSPLIT == 3) bl[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
+            }
+            if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
+            if (!(a.probe & 4))
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = wm * (BM / 2) + mt * 16 + lp + tap;
+                const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
+                if (NSPLIT == 3) {
+                    const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], acc[mt][nt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+            }
+            if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
+            if (!K1 && tap == ktaps - 1 && chunk + 1 < nchunks) {
+                __syncthreads();              // every wave has read its last fragments of this chunk's A tile
+                if (!(a.probe & 1)) dma_A(chunk + 1, 0);
+            }
+        }
+    }
+    const int col = n0 + wn * 64 + 4 * lr;    // this lane's four consecutive output channels
+    if (a.probe & 8) { if (acc[0][0][0] == 123.456f) a.Y[0] = 1.f; return; }
+    if constexpr (K1 && BM <= 128) {
+        if (a.qk_hi != nullptr) {             // fused QKV epilogue: tile (+bias) -> LDS -> split-bf16 attention operands
+            float* tile = reinterpret_cast<float*>(smem_p);
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias && col < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+            __syncthreads();                  // the operand buffers are dead: reuse them for the output tile
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<f32x4*>(tile + (wm * (BM / 2) + mt * 16 + rperm(lg * 4 + r)) * kQkvLd + wn * 64 + 4 * lr) =
+                        f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]} + bv;
+            __syncthreads();
+            qkv_tile_store<BM>(a, tile, m0, n0, tid);
+            return;
+        }
+    }
+    pl_epilogue<MT>(a, acc, m0 + wm * (BM / 2), col, lg);
+}
+
+}  // namespace fs2

@@ -105,6 +105,17 @@ def test_conv_gemm_bf16x3_kernel_variants(case, gemm, bm, monkeypatch):
     test_conv_gemm(case, "bf16x3")
 
 
+@pytest.mark.parametrize("bm", ["64", "128", "256"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=[c[-1] for c in CASES])
+def test_conv_gemm_planes_kernel_tile_heights(case, precision, bm, monkeypatch):
+    """The default bf16 path (activations as split-bf16 planes, both operands by LDS-DMA: gemm_planes.h) at every
+    tile height (256 rows exists for the conv form only; k = 1 GEMMs fall back to their own choice)."""
+    monkeypatch.delenv("FS2_GEMM", raising=False)
+    monkeypatch.setenv("FS2_BM", bm)
+    test_conv_gemm(case, precision)
+
+
 def test_conv_gemm_transpose_detecting():
     """A = identity-like with an ASYMMETRIC weight: catches a swapped C/D row<->col mapping."""
     from tests import ops_binding as ops
