@@ -236,6 +236,27 @@ hipError_t launch_pl_t(hipStream_t s, const GemmArgs& a) {
     return hipGetLastError();
 }
 
+template <int NSPLIT, int NB>
+hipError_t launch_row8_t(hipStream_t s, const GemmArgs& a) {
+    static bool attr = false;
+    constexpr size_t lds = row8_lds_bytes<NB>();
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_row8_bf16<NSPLIT, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_row8_bf16<NSPLIT, NB>), dim3((a.R + 127) / 128), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+// Row-complete LN-fused kernel (gemm_row8_bf16) for k = 1 GEMMs that end in a row epilogue: one workgroup per CU, so it
+// needs about a CU's worth of 128-row tiles to pay (FS2_ROW8=0|1 forces the choice).
+bool use_row8(const GemmArgs& a) {
+    if (a.ktaps != 1 || a.dot_w || a.qk_hi || (a.N != 256 && a.N != 384) || !(a.ln_g || a.pe)) return false;
+    const char* e = getenv("FS2_ROW8");
+    if (e) return atoi(e) != 0;
+    return (a.R + 127) / 128 >= 128;
+}
+
 // Tile height of the planes kernel: the largest one that still gives every CU its 2-3 resident workgroups
 // (FS2_BM=64|128|256 forces one; k = 1 GEMMs have no 256-row form: two 256-row A buffers would not fit two workgroups per CU).
 template <int NSPLIT>
@@ -272,12 +293,13 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         // planes kernel (gemm_planes.h) whenever the A operand exists as split-bf16 planes or may be built in xp_scratch
         const bool planes = (a.Xp || a.xp_scratch) && gemm_choice() == 0 && a.ldy % 4 == 0 && (!a.resid || a.ldr % 4 == 0) &&
                             (!a.qk_hi || a.att_D % kB16BN == 0);
-        const bool y_needed = need_rows || (!a.Yp && !a.qk_hi);
+        const bool row8 = planes && use_row8(a);
+        const bool y_needed = (need_rows && !row8) || (!a.Yp && !a.qk_hi);
         if (!t.Y && y_needed) { t.Y = a.scratch; t.ldy = a.N; }
         if (!t.Y && y_needed) return fail(h, FS2_ERR_ARG, "%s: no output or scratch buffer", name);
         if (t.qk_hi && (a.ktaps != 1 || a.att_D % kB16BN != 0 || a.N != 3 * a.att_D)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: fused QKV split needs D %% 128 == 0", name);
         if (a.Yp && !planes) return fail(h, FS2_ERR_STATE, "%s: plane output requested on the fp32-input kernels", name);
-        if (need_rows) { t.act_post = 0; t.Yp = nullptr; }      // the row kernel writes the planes
+        if (need_rows && !row8) { t.act_post = 0; t.Yp = nullptr; }      // the row kernel writes the planes
         if (planes && !a.Xp) {
             char nm[112];
             snprintf(nm, sizeof nm, "%s.planes", name);
@@ -288,10 +310,13 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         }
         {
             Scope sc(h, s, name, flops, bytes);
-            if (planes) e = (precision == FS2_PREC_BF16X3) ? launch_pl<3>(s, t) : launch_pl<1>(s, t);
+            if (row8) {
+                if (a.N == 384) e = (precision == FS2_PREC_BF16X3) ? launch_row8_t<3, 3>(s, t) : launch_row8_t<1, 3>(s, t);
+                else e = (precision == FS2_PREC_BF16X3) ? launch_row8_t<3, 2>(s, t) : launch_row8_t<1, 2>(s, t);
+            } else if (planes) e = (precision == FS2_PREC_BF16X3) ? launch_pl<3>(s, t) : launch_pl<1>(s, t);
             else e = (precision == FS2_PREC_BF16X3) ? launch_tile_bf16<3>(s, t) : launch_tile_bf16<1>(s, t);
         }
-        if (e == hipSuccess && need_rows) {
+        if (e == hipSuccess && need_rows && !row8) {
             char nm[112];
             snprintf(nm, sizeof nm, "%s.rows", name);
             Scope sc(h, s, nm, 0.0, 8.0 * a.R * a.N);

@@ -41,23 +41,19 @@ __global__ void to_planes(const float* __restrict__ X, int ldx, int C, int R, in
     store_planes4(Xp, row, nchunks, c, v);
 }
 
-// Elementwise epilogue on 4-channel pieces: bias, ReLU, residual, activation, gap rows -> 0; fp32 and / or planes out.
+// Elementwise epilogue on 4-channel pieces (bias and residual are already in the accumulators): ReLU, activation,
+// gap rows -> 0; fp32 and / or planes out.
 template <int MT>
 __device__ __forceinline__ void pl_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][4], int row_base, int col, int lg) {
-    const float* __restrict__ biasp = a.bias;
-    const float* __restrict__ residp = a.resid;
     const int* __restrict__ rpos = a.row_pos;
     float* __restrict__ Y = a.Y;
     void* __restrict__ Yp = a.Yp;
     const bool colok = col < a.N;
     const bool pcol = Yp != nullptr && col < a.yp_chunks * 32;
     const bool relu_first = a.relu_pre != 0;
-    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (biasp && colok) bv = *reinterpret_cast<const f32x4*>(biasp + col);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         bool inb[4], valid[4];
-        f32x4 rv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = row_base + mt * 16 + rperm(lg * 4 + r);
@@ -67,16 +63,10 @@ __device__ __forceinline__ void pl_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = row_base + mt * 16 + rperm(lg * 4 + r);
-            rv[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (residp && inb[r] && colok) rv[r] = *reinterpret_cast<const f32x4*>(residp + (size_t)row * a.ldr + col);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row_base + mt * 16 + rperm(lg * 4 + r);
-            f32x4 v = f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]} + bv + rv[r];
+            f32x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float t = v[j];
+                float t = acc[mt][j][r];
                 if (relu_first) t = fmaxf(t, 0.f);
                 t = apply_act(t, a.act_post);
                 v[j] = (valid[r] && colok) ? t : 0.f;
@@ -110,12 +100,6 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     const int lp = rperm(lr);
     const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
     const __bf16* Xp = reinterpret_cast<const __bf16*>(a.Xp);
-
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = a.Cpad / 32;
     const int niter = nchunks * ktaps;
@@ -156,6 +140,24 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
 
     dma_A(0, 0);
     dma_B(0, 0);
+    // The accumulators start at bias + residual (loaded while the first tiles are in flight), so the epilogue has no
+    // loads on its critical path: acc[mt][nt][r] belongs to row (mt, r), channel col + nt.
+    const int col = n0 + wn * 64 + 4 * lr;    // this lane's four consecutive output channels
+    f32x4 acc[MT][4];
+    {
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias && col < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * (BM / 2) + mt * 16 + rperm(lg * 4 + r);
+                f32x4 v = bv;
+                if (a.resid && row < a.R && col < a.N) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt][r] = v[nt];
+            }
+    }
     int it = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         for (int tap = 0; tap < ktaps; ++tap, ++it) {
@@ -196,26 +198,254 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
             }
         }
     }
-    const int col = n0 + wn * 64 + 4 * lr;    // this lane's four consecutive output channels
     if (a.probe & 8) { if (acc[0][0][0] == 123.456f) a.Y[0] = 1.f; return; }
     if constexpr (K1 && BM <= 128) {
-        if (a.qk_hi != nullptr) {             // fused QKV epilogue: tile (+bias) -> LDS -> split-bf16 attention operands
+        if (a.qk_hi != nullptr && n0 < 2 * a.att_D) {
+            // fused QKV epilogue, Q | K tiles: row-major split-bf16 operands straight from the registers (8 + 8 bytes per
+            // 4 channels, 128 contiguous bytes per row and plane); gap rows and rows beyond R are written as zeros
+            const float sc = (n0 < a.att_D) ? a.q_scale : 1.f;
+            const int* __restrict__ rpos = a.row_pos;
+            __bf16* qkh = reinterpret_cast<__bf16*>(a.qk_hi);
+            __bf16* qkl = reinterpret_cast<__bf16*>(a.qk_lo);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm * (BM / 2) + mt * 16 + rperm(lg * 4 + r);
+                    if (row >= a.Rvt) continue;
+                    const bool ok = row < a.R && (rpos == nullptr || rpos[row] >= 0);
+                    const float f = ok ? sc : 0.f;
+                    uint2 hi, lo;
+                    split4(f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]} * f, hi, lo);
+                    const size_t off = (size_t)row * 2 * a.att_D + col;
+                    *reinterpret_cast<uint2*>(qkh + off) = hi;
+                    *reinterpret_cast<uint2*>(qkl + off) = lo;
+                }
+            return;
+        }
+        if (a.qk_hi != nullptr) {             // V tile: (+bias) -> LDS -> V^T planes (8 consecutive keys per 16-byte store)
             float* tile = reinterpret_cast<float*>(smem_p);
-            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (a.bias && col < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + col);
             __syncthreads();                  // the operand buffers are dead: reuse them for the output tile
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     *reinterpret_cast<f32x4*>(tile + (wm * (BM / 2) + mt * 16 + rperm(lg * 4 + r)) * kQkvLd + wn * 64 + 4 * lr) =
-                        f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]} + bv;
+                        f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
             __syncthreads();
             qkv_tile_store<BM>(a, tile, m0, n0, tid);
             return;
         }
     }
     pl_epilogue<MT>(a, acc, m0 + wm * (BM / 2), col, lg);
+}
+
+}  // namespace fs2
+
+namespace fs2 {
+
+// ---------------------------------------------------------------------------------------------------------------
+// gemm_row8_bf16: row-complete k = 1 GEMM (N = 128 NB = 256 or 384 outputs per row) with the LayerNorm epilogue fused.
+//
+// Measured on MI355X (FS2_PROBE experiments): an LDS-DMA round trip under load takes ~1.2 us, so a
+// double-buffered k = 1 GEMM moves (bytes in flight per CU) / 1.2 us no matter how fast its MFMAs are, and the 64/128-row
+// x 128-column tiles above spend 25-50 % of their time in the epilogue plus a second HBM-bound pass (ln_rows).  This
+// kernel takes 128 rows x ALL N columns per workgroup: 2/3 of the operand bytes per flop of a 128 x 128 tile, the whole
+// row in registers at the end, so bias + residual + LayerNorm + activation + positional encoding happen in the epilogue
+// and the result leaves once, as fp32 and as planes (no fp32 round trip of the pre-LN tensor, no second launch).
+//   * 8 waves as 4(M) x 2(N); wave tile 32 rows x 64 NB columns (MT = 2, NT = 4 NB); 16 NB accumulator registers x 2.
+//   * one workgroup per CU (2 x (16 + 16 NB) KB of LDS), 2 waves per SIMD.
+//   * B rows are DMA'd permuted as in gemm_pl_bf16: n-tile nt of lane lr is channel 64 NB wn + 64 (nt >> 2) + 4 lr + (nt & 3).
+//   * LayerNorm statistics: two passes (mean, then centred sum of squares) over the 64 NB values a wave holds per row
+//     (16-lane reduction), completed across the two N-waves through 2 KB of LDS.
+template <int NB> constexpr size_t row8_lds_bytes() { return 2 * (size_t)(128 + 128 * NB) * 128; }
+
+template <int NSPLIT, int NB>
+__global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
+    constexpr int MT = 2, NT = 4 * NB, BM = 128, BN = 128 * NB;
+    constexpr int STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem_r[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int lp = rperm(lr);
+    const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
+    const __bf16* Xp = reinterpret_cast<const __bf16*>(a.Xp);
+
+    const int niter = a.Cpad / 32;
+    const int jrow = lane >> 3, jslot = lane & 7;
+    // A: 16 one-KB instructions per stage, wave w issues q = w and w + 8 (tile rows 8q + jrow)
+    const int sA = jslot ^ (jrow >> 1) ^ ((wave & 1) << 2);
+    const int arow0 = m0 + wave * 8 + jrow;
+    const __bf16* a_src0 = Xp + (size_t)arow0 * niter * 64 + sA * 8;
+    const size_t a_qstride = (size_t)64 * niter * 64;
+    // B: 16 NB instructions per stage, wave w issues q = w + 8u (u < 2 NB): LDS rows 8q + jrow = 16 ((w >> 1) + 4u) + jB,
+    // i.e. 64-column group u, n-tile (w >> 1) of it, tile row jB -> weight row 64u + 4 rperm_inv(jB) + (w >> 1)
+    const int jB = (wave & 1) * 8 + jrow;
+    const int sB = jslot ^ ((jB >> 1) & 7);
+    const __bf16* b_src0 = Wb + ((size_t)(4 * rperm_inv(jB) + (wave >> 1)) * niter) * 64 + sB * 8;
+    const size_t b_ustride = (size_t)64 * niter * 64;
+    auto dma_stage = [&](int it, int buf) {
+        char* as = smem_r + buf * STAGE + wave * 1024;
+        const __bf16* asrc = a_src0 + (size_t)it * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = arow0 + 64 * i < a.R;
+            const void* sp = ok ? static_cast<const void*>(asrc + i * a_qstride) : static_cast<const void*>(g_zero16);
+            __builtin_amdgcn_global_load_lds(sp, (lds_void_t*)(as + i * 8192), 16, 0, 0);
+        }
+        char* bs = smem_r + buf * STAGE + BM * 128 + wave * 1024;
+        const __bf16* bsrc = b_src0 + (size_t)it * 64;
+#pragma unroll
+        for (int u = 0; u < 2 * NB; ++u)
+            __builtin_amdgcn_global_load_lds(bsrc + u * b_ustride, (lds_void_t*)(bs + u * 8192), 16, 0, 0);
+    };
+
+    dma_stage(0, 0);
+    // accumulators start at bias + residual (loaded under the first DMA round trip): acc[mt][4g + j][r] is channel
+    // col0 + 64 g + j of tile row (mt, r)
+    const int col0 = wn * (64 * NB) + 4 * lr;
+    int rowi[MT][4];
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowi[mt][r] = m0 + wm * 32 + mt * 16 + rperm(lg * 4 + r);
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + col0 + 64 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4 v = bv;
+                if (a.resid && rowi[mt][r] < a.R) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)rowi[mt][r] * a.ldr + col0 + 64 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mt][4 * g + j][r] = v[j];
+            }
+    }
+    for (int it = 0; it < niter; ++it) {
+        dma_barrier();
+        if (it + 1 < niter) dma_stage(it + 1, (it + 1) & 1);
+        const char* As = smem_r + (it & 1) * STAGE;
+        const char* Bs = As + BM * 128;
+        bf16x8_t ah[MT], al[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int r = wm * 32 + mt * 16 + lp;
+            ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
+            if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
+        }
+        if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int n2 = 0; n2 < NT; n2 += 2) {
+            bf16x8_t bh[2], bl[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = wn * (64 * NB) + (n2 + u) * 16 + lp;
+                bh[u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
+                if (NSPLIT == 3) bl[u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
+            }
+            if (NSPLIT == 3) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[u], acc[mt][n2 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[u], acc[mt][n2 + u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[u], acc[mt][n2 + u], 0, 0, 0);
+        }
+        if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
+    }
+
+    // ---- epilogue: rows stay in registers
+    const int* __restrict__ rpos = a.row_pos;
+    float* __restrict__ Y = a.Y;
+    void* __restrict__ Yp = a.Yp;
+    const bool relu_first = a.relu_pre != 0;
+    int pos[MT][4];
+    float rsum[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pos[mt][r] = rowi[mt][r] < a.R ? (rpos ? rpos[rowi[mt][r]] : 0) : -1;
+            float s = 0.f;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                if (relu_first) acc[mt][n][r] = fmaxf(acc[mt][n][r], 0.f);
+                s += acc[mt][n][r];
+            }
+            rsum[mt][r] = wave16_sum(s);
+        }
+    float* red = reinterpret_cast<float*>(smem_r);      // [2 passes][8 waves][32 rows]
+    float mean[MT][4], rstd[MT][4];
+    if (a.ln_g) {
+        __syncthreads();                                // operand buffers are dead
+        if (lr == 0)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * 32 + mt * 16 + lg * 4 + r] = rsum[mt][r];
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mean[mt][r] = (rsum[mt][r] + red[(wave ^ 1) * 32 + mt * 16 + lg * 4 + r]) / (float)a.N;
+                float q = 0.f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) { const float d = acc[mt][n][r] - mean[mt][r]; q += d * d; }
+                rsum[mt][r] = wave16_sum(q);
+            }
+        if (lr == 0)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[256 + wave * 32 + mt * 16 + lg * 4 + r] = rsum[mt][r];
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                rstd[mt][r] = 1.f / sqrtf((rsum[mt][r] + red[256 + (wave ^ 1) * 32 + mt * 16 + lg * 4 + r]) / (float)a.N + a.ln_eps);
+    }
+    const float alpha = (a.pe && a.pe_alpha) ? a.pe_alpha[0] : 1.f;
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        const int col = col0 + 64 * g;
+        f32x4 gam = f32x4{1.f, 1.f, 1.f, 1.f}, bet = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.ln_g) { gam = *reinterpret_cast<const f32x4*>(a.ln_g + col); bet = *reinterpret_cast<const f32x4*>(a.ln_b + col); }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rowi[mt][r];
+                if (row >= a.R) continue;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (pos[mt][r] >= 0) {
+                    f32x4 pe4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (a.pe) pe4 = *reinterpret_cast<const f32x4*>(a.pe + (size_t)pos[mt][r] * a.pe_ld + col);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = acc[mt][4 * g + j][r];
+                        if (a.ln_g) t = (t - mean[mt][r]) * rstd[mt][r] * gam[j] + bet[j];
+                        t = apply_act(t, a.act_post);
+                        if (a.pe) t = t * a.x_scale + alpha * pe4[j];
+                        v[j] = t;
+                    }
+                }
+                if (Y) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
+                if (Yp) store_planes4(Yp, row, a.yp_chunks, col, v);
+            }
+    }
 }
 
 }  // namespace fs2

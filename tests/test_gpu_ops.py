@@ -116,6 +116,19 @@ def test_conv_gemm_planes_kernel_tile_heights(case, precision, bm, monkeypatch):
     test_conv_gemm(case, precision)
 
 
+ROW8_CASES = [c for c in CASES if c[3] == 1 and c[7] is not None and c[2] in (256, 384)]
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("case", ROW8_CASES, ids=[c[-1] for c in ROW8_CASES])
+def test_conv_gemm_row_complete_ln_fused_kernel(case, precision, monkeypatch):
+    """gemm_row8_bf16 (128 rows x all N columns per workgroup, LayerNorm in the epilogue) is chosen by size in the
+    model path; force it here on the small op cases (several row tiles, ragged last tile, gap rows)."""
+    monkeypatch.delenv("FS2_GEMM", raising=False)
+    monkeypatch.setenv("FS2_ROW8", "1")
+    test_conv_gemm(case, precision)
+
+
 def test_conv_gemm_transpose_detecting():
     """A = identity-like with an ASYMMETRIC weight: catches a swapped C/D row<->col mapping."""
     from tests import ops_binding as ops

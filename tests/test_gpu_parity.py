@@ -118,6 +118,20 @@ def test_c2_batch_vs_oracle(env, precision):
         model.precision = "fp32"
 
 
+@pytest.mark.parametrize("row8", ["0", "1"])
+def test_c2_row_complete_kernel_choice(env, row8, monkeypatch):
+    """The LN-terminated k = 1 GEMMs have two bf16 implementations (128-column tiles + row kernel / row-complete tile with
+    the LayerNorm fused, chosen by size): c2 in the parity mode with each one forced."""
+    model, sd, cfg, O = env
+    from fastspeech2_amd.synthetic import make_batch
+    monkeypatch.setenv("FS2_ROW8", row8)
+    model.precision = "bf16x3"
+    try:
+        _c2_body(model, sd, cfg, O, make_batch("c2"), "bf16x3")
+    finally:
+        model.precision = "fp32"
+
+
 def _c2_body(model, sd, cfg, O, b, precision):
     with torch.no_grad():
         r = model._run(b["xs"].cuda(), b["ilens"], b["olens"], b["ds"].cuda(), b["es"].cuda(), b["ps"].cuda(),
