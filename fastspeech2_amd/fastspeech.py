@@ -258,7 +258,10 @@ class FeedForwardTransformer(nn.Module):
 
     # ------------------------------------------------------------------ library handle / weights
     def __del__(self):
-        self._drop_handle()
+        try:
+            self._drop_handle()
+        except Exception:       # interpreter shutdown: torch's own module machinery may already be torn down
+            pass
 
     def _drop_handle(self):
         h = getattr(self, "_handle", None)
@@ -267,7 +270,7 @@ class FeedForwardTransformer(nn.Module):
                 _lib.lib().fs2_destroy(h)
             except Exception:   # interpreter shutdown
                 pass
-            self._handle = None
+            self.__dict__["_handle"] = None
 
     def _weights_fingerprint(self):
         sd = self.state_dict(keep_vars=True)
