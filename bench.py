@@ -120,13 +120,17 @@ def main():
 
     def step():
         if not use_dist:
-            return model.inference_batch(xs, il)
+            # nothing on the host waits for the GPU: the frame layout is built on the device (fs2_decode's device-driven
+            # mode); the very first call is synchronous and teaches the capacity predictor the frames-per-phoneme ratio
+            return model.inference_batch(xs, il, sync=False)
         packed, olens = model.inference_batch(xs, il, packed=True)          # valid frames only travel over xGMI
         return gather_packed(packed, olens, index, B * world)
 
     with torch.no_grad():
         for _ in range(max(args.warmup, 1)):
             mel, olens_all = step()
+        if not use_dist:
+            assert model.async_ok(), "capacities of the asynchronous path were exceeded during warm-up"
         local_frames = int(model.last_olens.sum())
         total_frames = int(olens_all.sum())
         # find the dominant launch site with one fully bracketed (untimed) step, then bracket only that site
@@ -150,6 +154,8 @@ def main():
         if use_dist:
             dist.barrier()
         dt = time.perf_counter() - t0
+        if not use_dist:
+            assert model.async_ok(), "capacities of the asynchronous path were exceeded in the timed region"
         prof = model.get_profile()
         model.set_profiling(False)
     if use_dist:

@@ -54,7 +54,7 @@ class DecodeIO(C.Structure):
                 ("before", C.c_void_p), ("after", C.c_void_p), ("e_out", C.c_void_p), ("p_out", C.c_void_p),
                 ("qe", C.c_void_p), ("qp", C.c_void_p), ("lr_index", C.c_void_p), ("dec_out", C.c_void_p),
                 ("token_workspace", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("after_packed", C.c_void_p)]
+                ("after_packed", C.c_void_p), ("row_capacity", C.c_int64), ("status", C.c_void_p)]
 
 
 class OpGemmArgs(C.Structure):
@@ -67,7 +67,7 @@ class OpGemmArgs(C.Structure):
 
 # every symbol include/fs2.h declares (tests check the library exports all of them)
 EXPORTS = ["fs2_create", "fs2_destroy", "fs2_last_error", "fs2_load_weights", "fs2_token_workspace_bytes",
-           "fs2_encode", "fs2_frame_workspace_bytes", "fs2_decode", "fs2_set_profiling", "fs2_set_profile_filter", "fs2_get_profile",
+           "fs2_encode", "fs2_frame_workspace_bytes", "fs2_row_capacity", "fs2_frame_workspace_bytes_cap", "fs2_decode", "fs2_set_profiling", "fs2_set_profile_filter", "fs2_get_profile",
            "fs2_op_conv_gemm", "fs2_op_attention", "fs2_op_length_regulate", "fs2_op_unpack_rows", "fs2_op_transpose", "fs2_op_bucketize"]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
@@ -120,6 +120,10 @@ def lib():
     L.fs2_encode.restype = C.c_int
     L.fs2_frame_workspace_bytes.argtypes = [vp, C.POINTER(Batch), i64p]
     L.fs2_frame_workspace_bytes.restype = C.c_size_t
+    L.fs2_row_capacity.argtypes = [C.POINTER(Batch), C.c_int64]
+    L.fs2_row_capacity.restype = C.c_int64
+    L.fs2_frame_workspace_bytes_cap.argtypes = [vp, C.POINTER(Batch), C.c_int64]
+    L.fs2_frame_workspace_bytes_cap.restype = C.c_size_t
     L.fs2_decode.argtypes = [vp, vp, C.POINTER(DecodeIO)]
     L.fs2_decode.restype = C.c_int
     L.fs2_set_profiling.argtypes = [vp, i32]

@@ -86,6 +86,7 @@ struct AttnB16Args {
     void* ctxp; int ctxp_chunks;               // ... and / or split-bf16 planes, the A operand of the output projection (gemm_planes.h)
     const int* start; const int* len; const int* klen;
     const int2* work;
+    const int* nwork;                          // device-driven layout: number of valid work items (grid.x is a capacity), or nullptr
     int D; int mask_q;
 };
 
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
     char* Vs = smem_a + 32 * KROW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
+    if (a.nwork != nullptr && (int)blockIdx.x >= *a.nwork) return;
     const int2 wk = a.work[blockIdx.x];
     const int b = wk.x, h = blockIdx.y;
     const int s0 = a.start[b], len = a.len[b], klen = a.klen[b];

@@ -26,6 +26,7 @@ struct AttnArgs {
     float* ctx; int ldc;             // [R, D]
     const int* start; const int* len; const int* klen;   // per utterance
     const int2* work;                // (utterance, query tile)
+    const int* nwork;                // device-driven layout: number of valid work items (grid.x is a capacity), or nullptr
     int D; int mask_q;               // mask_q: query rows >= klen yield zeros (reference masked_fill(0))
     float scale;                     // 1/sqrt(dk)
 };
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(256) void attn_f32(AttnArgs a) {
     float* Vs = smem + kAttKT * LDK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
+    if (a.nwork != nullptr && (int)blockIdx.x >= *a.nwork) return;
     const int2 wk = a.work[blockIdx.x];
     const int b = wk.x, h = blockIdx.y;
     const int s0 = a.start[b], len = a.len[b], klen = a.klen[b];

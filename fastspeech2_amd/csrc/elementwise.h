@@ -22,6 +22,65 @@ __global__ void build_row_meta(const int* start, const int* len, int B, int rpad
     row_seq[row] = seq;
 }
 
+// Frame-side layout built on the device from the frame counts the duration scan left there (device-driven mode of
+// fs2_decode: no host read-back).  Mirrors build_layout() in fs2_runtime.hip exactly: 32-row aligned starts, kGap zero rows
+// between utterances, attention work list = (utterance, 64-query block) ordered by key length descending (stable).
+// One workgroup.  dims = {rows used, work items, overflow flags, longest utterance}; 8 = kGap, 32 = kAttAlign, 64 = kAttBQ.
+__global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B, int compat, int masked, int row_cap, int work_cap,
+                                                         int lmax_cap, int pe_rows, int* start, int* len, int* klen, int* vlen,
+                                                         int* rank_tmp, int* woff_tmp, int2* work, int* dims) {
+    __shared__ int s_max, s_min;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_max = 0; s_min = 0x7fffffff; }
+    __syncthreads();
+    int mx = 0, mn = 0x7fffffff;
+    for (int b = tid; b < B; b += 1024) { mx = max(mx, olens[b]); mn = min(mn, olens[b]); }
+    atomicMax(&s_max, mx);
+    atomicMin(&s_min, mn);
+    __syncthreads();
+    mx = s_max;
+    for (int b = tid; b < B; b += 1024) {
+        const int v = max(olens[b], 0);
+        vlen[b] = v;
+        len[b] = compat ? mx : v;
+        klen[b] = compat ? (masked ? v : mx) : v;
+    }
+    __syncthreads();
+    // position of utterance b in the work order: longer key ranges first, ties in batch order
+    for (int b = tid; b < B; b += 1024) {
+        const int k = klen[b];
+        int r = 0;
+        for (int j = 0; j < B; ++j) { const int kj = klen[j]; r += (kj > k) || (kj == k && j < b); }
+        rank_tmp[r] = b;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int row = 8;      // kGap
+        for (int b = 0; b < B; ++b) {
+            row = (row + 31) & ~31;
+            start[b] = row;
+            row += len[b] + 8;
+        }
+        int w = 0;
+        for (int r = 0; r < B; ++r) { const int b = rank_tmp[r]; woff_tmp[b] = w; w += (len[b] + 63) >> 6; }
+        int ovf = 0;
+        if (row > row_cap || w > work_cap) ovf |= 1;
+        if (mx > lmax_cap) ovf |= 2;
+        if (mx > pe_rows) ovf |= 4;
+        if (s_min <= 0) ovf |= 8;
+        dims[0] = row; dims[1] = ovf ? 0 : w; dims[2] = ovf; dims[3] = mx;
+    }
+    __syncthreads();
+    if (dims[2] != 0) {           // a capacity is too small: leave an empty layout (all rows are gap rows, no work) so that
+        for (int b = tid; b < B; b += 1024) { start[b] = 8; len[b] = 0; klen[b] = 0; vlen[b] = 0; }    // nothing indexes out of range
+        return;
+    }
+    for (int b = tid; b < B; b += 1024) {
+        const int nq = (len[b] + 63) >> 6, o = woff_tmp[b];
+        for (int q = 0; q < nq; ++q) work[o + q] = make_int2(b, q);
+    }
+}
+
 // h[row] = E[xs[b, t]] * xscale + alpha * pe[t]      (reference encoder.py:196, embedding.py:77-80,105-120)
 __global__ __launch_bounds__(256) void embed_pe(const int64_t* xs, int Tmax, const float* E, int idim, int D,
                                                 const float* pe, const float* alpha_p, float xscale,

@@ -52,10 +52,13 @@ struct HostLayout {
     int B = 0, R = 0, Rpad = 0;
     std::vector<int> start, len, klen, vlen;
     std::vector<int2> work;
+    int work_cap = -1;      // device-driven layout: R / Rpad / work_cap are capacities, the vectors stay empty
+    int nwork() const { return work_cap >= 0 ? work_cap : (int)work.size(); }
 };
 struct DevLayout {
     int *start = nullptr, *len = nullptr, *klen = nullptr, *vlen = nullptr, *row_pos = nullptr, *row_seq = nullptr;
     int2* work = nullptr;
+    int* dims = nullptr;    // device-driven layout: {rows used, work items, overflow flags, longest utterance}
 };
 
 struct ProfRec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
@@ -81,6 +84,7 @@ struct fs2_handle {
     DevLayout dtok;
     float* enc_final = nullptr;
     int* cum = nullptr;
+    int* o32 = nullptr;        // device frame counts (int32) left by the duration scan
     int enc_B = 0, enc_Tmax = 0, enc_compat = 0;
     void* enc_ws = nullptr;
     // profiling
@@ -372,7 +376,7 @@ int launch_attention(fs2_handle* h, hipStream_t s, const char* name, const float
     const int dk = D / heads;
     AttnArgs a;
     a.qkv = qkv; a.ld = 3 * D; a.ctx = ctx; a.ldc = D; a.start = dl.start; a.len = dl.len; a.klen = dl.klen;
-    a.work = dl.work; a.D = D; a.mask_q = mask_q; a.scale = 1.0f / sqrtf((float)dk);
+    a.work = dl.work; a.nwork = dl.dims ? dl.dims + 1 : nullptr; a.D = D; a.mask_q = mask_q; a.scale = 1.0f / sqrtf((float)dk);
     if (nwork == 0) return FS2_OK;
     Scope sc(h, s, name, flops, 0.0);
     dim3 grid(nwork, heads);
@@ -430,7 +434,7 @@ int launch_attention_b16(fs2_handle* h, hipStream_t s, const char* name, const f
     AttnB16Args a;
     a.qk_hi = qkh; a.qk_lo = qkl; a.ldqk = 2 * D; a.vt_hi = vth; a.vt_lo = vtl; a.Rvt = Rvt; a.ctx = ctx; a.ldc = D;
     a.ctxp = ctxp; a.ctxp_chunks = D / 32;
-    a.start = dl.start; a.len = dl.len; a.klen = dl.klen; a.work = dl.work; a.D = D; a.mask_q = mask_q;
+    a.start = dl.start; a.len = dl.len; a.klen = dl.klen; a.work = dl.work; a.nwork = dl.dims ? dl.dims + 1 : nullptr; a.D = D; a.mask_q = mask_q;
     Scope sc(h, s, name, flops, 0.0);
     dim3 grid(nwork, heads);
     hipError_t e;
@@ -461,7 +465,7 @@ void build_layout(HostLayout& L, int B, const std::vector<int>& len, const std::
     std::stable_sort(L.work.begin(), L.work.end(), [&](const int2& x, const int2& y) { return klen[x.x] > klen[y.x]; });
 }
 
-size_t layout_dev_ints(const HostLayout& L) { return (size_t)4 * L.B + 2 * (size_t)L.Rpad + 2 * L.work.size() + 64; }
+size_t layout_dev_ints(const HostLayout& L) { return (size_t)6 * L.B + 2 * (size_t)L.Rpad + 2 * (size_t)L.nwork() + 64 + 16; }
 
 // uploads start/len/klen/vlen/work, then derives row_pos/row_seq on the device
 int upload_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, DevLayout& D) {
@@ -483,6 +487,25 @@ int upload_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, D
     return FS2_OK;
 }
 
+// device-driven variant: the layout arrays are produced by frame_layout_dev from the device frame counts
+int device_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, DevLayout& D, const int* olens32, int compat, int masked,
+                  int lmax_cap, int pe_rows) {
+    D.start = dev; D.len = dev + L.B; D.klen = dev + 2 * L.B; D.vlen = dev + 3 * L.B;
+    int* rank_tmp = dev + 4 * L.B;
+    int* woff_tmp = dev + 5 * L.B;
+    int* rest = reinterpret_cast<int*>(align_up(reinterpret_cast<size_t>(dev + 6 * L.B), 16));
+    D.dims = rest; rest += 16;
+    D.work = reinterpret_cast<int2*>(rest);
+    rest += 2 * (size_t)L.nwork();
+    rest = reinterpret_cast<int*>(align_up(reinterpret_cast<size_t>(rest), 16));
+    D.row_pos = rest; D.row_seq = rest + L.Rpad;
+    hipLaunchKernelGGL(frame_layout_dev, dim3(1), dim3(1024), 0, s, olens32, L.B, compat, masked, L.R, L.nwork(), lmax_cap, pe_rows,
+                       D.start, D.len, D.klen, D.vlen, rank_tmp, woff_tmp, D.work, D.dims);
+    hipLaunchKernelGGL(build_row_meta, dim3((L.Rpad + 255) / 256), dim3(256), 0, s, D.start, D.len, L.B, L.Rpad, D.row_pos, D.row_seq);
+    HIP_TRY(h, hipGetLastError());
+    return FS2_OK;
+}
+
 // ------------------------------------------------------------------ FFT block stack
 // x0p / x1p: split-bf16 planes of x0 / x1 (gemm_planes.h); xps: planes scratch for activations produced without planes.
 // In the bf16 modes the attention context and the FFN hidden layer exist ONLY as planes, in the ctx / hid storage.
@@ -493,7 +516,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
               const HostLayout& L, const DevLayout& dl, int mask_q, const StackBufs& b, int prec, bool x0p_ready = false) {
     char nm[96];
     double att_flops = 0;
-    for (int i = 0; i < L.B; ++i) att_flops += 4.0 * D * (double)L.klen[i] * std::min(L.len[i], mask_q ? L.klen[i] : L.len[i]);
+    for (size_t i = 0; i < L.klen.size(); ++i) att_flops += 4.0 * D * (double)L.klen[i] * std::min(L.len[i], mask_q ? L.klen[i] : L.len[i]);
     // bf16 modes: activations travel between the GEMMs as split-bf16 planes (no conversion work inside the MFMA loops)
     const int hidden = st.layers.empty() ? 0 : st.layers[0].w1.N;
     const bool pl = prec != FS2_PREC_FP32 && gemm_choice() == 0 && D % 32 == 0 && hidden % 32 == 0 && b.x0p && b.x1p;
@@ -510,6 +533,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         int rc;
         snprintf(nm, sizeof nm, "%s.qkv", tag);
         GemmArgs a = gemm_args(ly.qkv, b.x0, D, R, dl.row_pos, b.qkv, 3 * D);
+        a.Rp = dl.dims;
         if (pl) a.Xp = b.x0p;
         const bool fused_split = prec != FS2_PREC_FP32 && D % kB16BN == 0 && gemm_choice() != 2;
         if (fused_split) {   // bf16 attention operands straight from the GEMM epilogue (no fp32 QKV round trip)
@@ -518,21 +542,24 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.attn", tag);
-        if (prec == FS2_PREC_FP32) rc = launch_attention(h, s, nm, b.qkv, b.ctx, D, heads, dl, (int)L.work.size(), mask_q, att_flops);
-        else rc = launch_attention_b16(h, s, nm, fused_split ? nullptr : b.qkv, pl ? nullptr : b.ctx, D, heads, R, L.Rpad, dl, (int)L.work.size(), mask_q, att_flops, prec, b.qkh, b.qkl, b.vth, b.vtl, ctxp);
+        if (prec == FS2_PREC_FP32) rc = launch_attention(h, s, nm, b.qkv, b.ctx, D, heads, dl, L.nwork(), mask_q, att_flops);
+        else rc = launch_attention_b16(h, s, nm, fused_split ? nullptr : b.qkv, pl ? nullptr : b.ctx, D, heads, R, L.Rpad, dl, L.nwork(), mask_q, att_flops, prec, b.qkh, b.qkl, b.vth, b.vtl, ctxp);
         if (rc) return rc;
         snprintf(nm, sizeof nm, "%s.out_ln", tag);
         a = gemm_args(ly.out, b.ctx, D, R, dl.row_pos, b.x1, D);
+        a.Rp = dl.dims;
         a.resid = b.x0; a.ldr = D; a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
         if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.ffn1", tag);
         a = gemm_args(ly.w1, b.x1, D, R, dl.row_pos, pl ? nullptr : b.hid, ly.w1.N);
+        a.Rp = dl.dims;
         a.act_post = 1;
         if (pl) { a.Xp = b.x1p; a.Yp = hidp; a.yp_chunks = ly.w1.N / 32; }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.ffn2_ln", tag);
         a = gemm_args(ly.w2, b.hid, ly.w1.N, R, dl.row_pos, b.x0, D);
+        a.Rp = dl.dims;
         a.resid = b.x1; a.ldr = D; a.ln_g = ly.ln2g; a.ln_b = ly.ln2b; a.ln_eps = 1e-5f;
         if (pl) { a.Xp = hidp; a.Yp = b.x0p; a.yp_chunks = D / 32; }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
@@ -543,7 +570,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
 // conv stack + scalar head (reference variance_predictor.py:46-51 / duration_predictor.py:70-75);
 // tmp0/tmp1: [R, chans] scratch; out_rows: [R]
 int run_predictor(fs2_handle* h, hipStream_t s, const char* tag, const Predictor& p, const float* X, int ldx, int R,
-                  const int* row_pos, float* tmp0, float* tmp1, float* out_rows, int prec, const void* Xp = nullptr, void* xps = nullptr) {
+                  const int* row_pos, float* tmp0, float* tmp1, float* out_rows, int prec, const void* Xp = nullptr, void* xps = nullptr, const int* Rp = nullptr) {
     char nm[96];
     const float* in = X; int ld = ldx;
     float* bufs[2] = {tmp0, tmp1};
@@ -551,6 +578,7 @@ int run_predictor(fs2_handle* h, hipStream_t s, const char* tag, const Predictor
         const bool last = (l + 1 == p.conv.size());
         float* out = bufs[l & 1];
         GemmArgs a = gemm_args(p.conv[l], in, ld, R, row_pos, last ? nullptr : out, p.conv[l].N);
+        a.Rp = Rp;
         a.relu_pre = 1; a.ln_g = p.lng[l]; a.ln_b = p.lnb[l]; a.ln_eps = 1e-12f;
         if (last) { a.dot_w = p.lin_w; a.dot_b = p.lin_b; a.dot_out = out_rows; }
         a.scratch = out;
@@ -977,7 +1005,7 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
     if (io->enc_out) {
         if ((rc = unpack<float>(h, s, sb.x0, c.adim, dl.start, dl.vlen, b.B, b.Tmax, io->enc_out, 0.f))) return rc;
     }
-    h->enc_final = sb.x0; h->cum = cum; h->enc_B = b.B; h->enc_Tmax = b.Tmax; h->enc_compat = b.compat_padded;
+    h->enc_final = sb.x0; h->cum = cum; h->o32 = o32; h->enc_B = b.B; h->enc_Tmax = b.Tmax; h->enc_compat = b.compat_padded;
     h->enc_ws = io->workspace;
     h->encoded = true;
     return FS2_OK;
@@ -990,6 +1018,25 @@ size_t fs2_frame_workspace_bytes(const fs2_handle* h, const fs2_batch* b, const 
     return carve_frames(h->cfg, L, nullptr, 0, nullptr, nullptr);
 }
 
+// device-driven layout: every utterance start is rounded up to kAttAlign rows and followed by kGap zero rows
+int64_t fs2_row_capacity(const fs2_batch* b, int64_t total_frames_bound) {
+    if (!b || b->B <= 0 || total_frames_bound <= 0) return 0;
+    return round_up((int)std::min<int64_t>(total_frames_bound + (int64_t)b->B * (kGap + kAttAlign) + kGap, INT32_MAX - 256), 128);
+}
+
+void capacity_layout(const fs2_batch& b, int64_t row_capacity, HostLayout& L) {
+    L.B = b.B; L.R = (int)row_capacity; L.Rpad = round_up((int)row_capacity, 128);
+    L.work_cap = (int)(row_capacity / kAttBQ) + b.B;
+    L.start.clear(); L.len.clear(); L.klen.clear(); L.vlen.clear(); L.work.clear();
+}
+
+size_t fs2_frame_workspace_bytes_cap(const fs2_handle* h, const fs2_batch* b, int64_t row_capacity) {
+    if (!h || !b || b->B <= 0 || row_capacity <= 0 || row_capacity > INT32_MAX - 256) return 0;
+    HostLayout L;
+    capacity_layout(*b, row_capacity, L);
+    return carve_frames(h->cfg, L, nullptr, 0, nullptr, nullptr);
+}
+
 int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     if (!h || !io) return fail(h, FS2_ERR_ARG, "fs2_decode: null argument");
     if (!h->encoded) return fail(h, FS2_ERR_STATE, "fs2_decode called without a preceding fs2_encode");
@@ -998,24 +1045,35 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     if (rc) return rc;
     if (b.B != h->enc_B || b.Tmax != h->enc_Tmax || b.compat_padded != h->enc_compat || io->token_workspace != h->enc_ws)
         return fail(h, FS2_ERR_STATE, "fs2_decode: batch does not match the preceding fs2_encode");
-    if (!io->olens || !io->workspace || !io->after) return fail(h, FS2_ERR_ARG, "fs2_decode: olens/workspace/after must be given");
+    const bool devlay = io->olens == nullptr && io->row_capacity > 0;
+    if ((!io->olens && !devlay) || !io->workspace || !io->after) return fail(h, FS2_ERR_ARG, "fs2_decode: olens (or row_capacity) / workspace / after must be given");
     const fs2_config& c = h->cfg;
-    int mx = 0;
-    for (int i = 0; i < b.B; ++i) {
-        if (io->olens[i] <= 0) return fail(h, FS2_ERR_ARG, "olens[%d]=%lld", i, (long long)io->olens[i]);
-        mx = std::max(mx, (int)io->olens[i]);
+    if (devlay) {
+        if (!io->status) return fail(h, FS2_ERR_ARG, "fs2_decode: the device-driven layout needs a status buffer");
+        if (io->after_packed) return fail(h, FS2_ERR_UNSUPPORTED, "after_packed needs host frame counts");
+        if (io->row_capacity > INT32_MAX - 256 || io->Lmax <= 0) return fail(h, FS2_ERR_ARG, "row_capacity %lld / Lmax %d", (long long)io->row_capacity, io->Lmax);
+    } else {
+        int mx = 0;
+        for (int i = 0; i < b.B; ++i) {
+            if (io->olens[i] <= 0) return fail(h, FS2_ERR_ARG, "olens[%d]=%lld", i, (long long)io->olens[i]);
+            mx = std::max(mx, (int)io->olens[i]);
+        }
+        if (io->Lmax < mx) return fail(h, FS2_ERR_ARG, "Lmax %d < longest utterance %d", io->Lmax, mx);
+        if (mx > h->dec.pe_rows) return fail(h, FS2_ERR_ARG, "utterance of %d frames exceeds the positional table (%d rows): extend `pe` and reload", mx, h->dec.pe_rows);
     }
-    if (io->Lmax < mx) return fail(h, FS2_ERR_ARG, "Lmax %d < longest utterance %d", io->Lmax, mx);
-    if (mx > h->dec.pe_rows) return fail(h, FS2_ERR_ARG, "utterance of %d frames exceeds the positional table (%d rows): extend `pe` and reload", mx, h->dec.pe_rows);
     HIP_TRY(h, hipSetDevice(c.device));
     hipStream_t s = (hipStream_t)stream;
     HostLayout L;
-    frame_layout(b, io->olens, io->masked, L);
+    if (devlay) capacity_layout(b, io->row_capacity, L);
+    else frame_layout(b, io->olens, io->masked, L);
     FrameBufs f; bool ok;
     carve_frames(c, L, io->workspace, io->workspace_bytes, &f, &ok);
     if (!ok) return fail(h, FS2_ERR_WORKSPACE, "fs2_decode: workspace too small");
     DevLayout dl;
-    if ((rc = upload_layout(h, s, L, f.meta, dl))) return rc;
+    if (devlay) {
+        if ((rc = device_layout(h, s, L, f.meta, dl, h->o32, b.compat_padded, io->masked, io->Lmax, h->dec.pe_rows))) return rc;
+        HIP_TRY(h, hipMemcpyAsync(io->status, dl.dims, 4 * sizeof(int), hipMemcpyDeviceToDevice, s));
+    } else if ((rc = upload_layout(h, s, L, f.meta, dl))) return rc;
     const int R = L.R;
     {   // length regulator
         Scope sc(h, s, "lr.expand", 0, 4.0 * R * c.adim * 2);
@@ -1024,8 +1082,8 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         HIP_TRY(h, hipGetLastError());
     }
     const bool need_e = (io->es == nullptr) || io->e_out, need_p = (io->ps == nullptr) || io->p_out;
-    if (need_e && (rc = run_predictor(h, s, "energy", h->energy, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.e_rows, b.precision, nullptr, f.sb.xps))) return rc;
-    if (need_p && (rc = run_predictor(h, s, "pitch", h->pitch, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.p_rows, b.precision, nullptr, f.sb.xps))) return rc;
+    if (need_e && (rc = run_predictor(h, s, "energy", h->energy, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.e_rows, b.precision, nullptr, f.sb.xps, dl.dims))) return rc;
+    if (need_p && (rc = run_predictor(h, s, "pitch", h->pitch, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.p_rows, b.precision, nullptr, f.sb.xps, dl.dims))) return rc;
     {
         Scope sc(h, s, "var.embed", 0, 4.0 * R * c.adim * 4);
         hipLaunchKernelGGL(bucket_embed, dim3((R + 3) / 4), dim3(256), 0, s, f.hfr, c.adim, dl.row_pos, dl.row_seq, R, io->es, io->es_stride,
@@ -1035,6 +1093,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     const bool dec_pl = b.precision != FS2_PREC_FP32 && gemm_choice() == 0 && c.ddim % 32 == 0 && c.dunits % 32 == 0;
     if (c.decoder_input_layer) {   // decoder input layer: Linear -> LN -> ReLU -> + alpha * pe   (reference encoder.py:118-125)
         GemmArgs a = gemm_args(h->dec_in, f.hfr, c.adim, R, dl.row_pos, f.sb.x0, c.ddim);
+        a.Rp = dl.dims;
         a.ln_g = h->dec_in_lng; a.ln_b = h->dec_in_lnb; a.ln_eps = 1e-5f; a.act_post = 1;
         a.pe = h->dec.pe; a.pe_ld = c.ddim; a.pe_alpha = h->dec.alpha; a.x_scale = c.use_scaled_pos_enc ? 1.f : sqrtf((float)c.ddim);
         a.xp_scratch = f.sb.xps;
@@ -1057,6 +1116,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     const bool post_pl = dec_pl && c.postnet_layers > 1;
     {
         GemmArgs a = gemm_args(h->feat, f.sb.x0, c.ddim, R, dl.row_pos, f.before, c.odim);
+        a.Rp = dl.dims;
         if (dec_pl) a.Xp = f.sb.x0p;
         if (post_pl) { a.Yp = f.sb.xps; a.yp_chunks = round_up(c.odim, 32) / 32; }
         if ((rc = launch_gemm(h, s, "feat_out", a, b.precision))) return rc;
@@ -1070,6 +1130,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
             const bool last = (l == c.postnet_layers - 1);
             float* out = last ? f.after : ((l & 1) ? pb : pa);
             GemmArgs a = gemm_args(h->post[l], in, ld, R, dl.row_pos, out, h->post[l].N);
+            a.Rp = dl.dims;
             if (!last) a.act_post = 2; else { a.resid = f.before; a.ldr = c.odim; }
             if (post_pl) {
                 a.Xp = (l == 0) ? f.sb.xps : ((l & 1) ? f.sb.x0p : f.sb.x1p);

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tile_bf16(GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int n0 = blockIdx.x * kB16BN, m0 = blockIdx.y * BM;
+    if (a.Rp != nullptr && m0 >= ((*a.Rp + 127) & ~127)) return;      // device-driven layout: tile beyond the rows in use
     const int P = (a.ktaps - 1) >> 1;
     const int lr = lane & 15, lg = lane >> 4;
     const int lp = rperm(lr);            // tile row / column this lane feeds to the MFMA (conflict-free LDS reads, common.h)
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
     const int nN = (a.N + kB16BN - 1) / kB16BN;
     const int tn = blockIdx.x % nN, tm = blockIdx.x / nN;
     const int n0 = tn * kB16BN, m0 = tm * BM;
+    if (a.Rp != nullptr && m0 >= ((*a.Rp + 127) & ~127)) return;      // device-driven layout: tile beyond the rows in use
     const int P = (a.ktaps - 1) >> 1;
     const int lr = lane & 15, lg = lane >> 4;
     const int lp = rperm(lr);            // tile row / column this lane feeds to the MFMA (conflict-free LDS reads, common.h)

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void gemm_tile_f32(GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * kTileBM, n0 = blockIdx.y * kTileBN;
+    if (a.Rp != nullptr && m0 >= ((*a.Rp + 127) & ~127)) return;      // device-driven layout: tile beyond the rows in use
     const int P = (a.ktaps - 1) >> 1;
     const int lr = lane & 15, lg = lane >> 4;
 
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void gemm_rows_f32(GemmArgs a) {
     float* Bs = smem + (kRowsBM + kMaxHalo) * kLd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * kRowsBM;
+    if (a.Rp != nullptr && m0 >= ((*a.Rp + 127) & ~127)) return;      // device-driven layout: tile beyond the rows in use
     const int P = (a.ktaps - 1) >> 1;
     const int lr = lane & 15, lg = lane >> 4;
 

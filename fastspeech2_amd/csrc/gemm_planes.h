@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
         if (tm * BM >= (a.qk_hi ? a.Rvt : a.R)) return;
     }
     const int n0 = tn * kB16BN, m0 = tm * BM;
+    if (a.Rp != nullptr && m0 >= ((*a.Rp + 127) & ~127)) return;      // device-driven layout: tile beyond the rows in use
     const int ktaps = K1 ? 1 : a.ktaps;
     const int P = (ktaps - 1) >> 1;
     const int lr = lane & 15, lg = lane >> 4;
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * BM;
+    if (a.Rp != nullptr && m0 >= ((*a.Rp + 127) & ~127)) return;      // device-driven layout: tile beyond the rows in use
     const int lr = lane & 15, lg = lane >> 4;
     const int lp = rperm(lr);
     const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);

@@ -55,8 +55,11 @@ class _PositionalTable(_Holder):
             self.alpha = nn.Parameter(torch.tensor(1.0))
 
     def ensure(self, n):
-        if self.pe.shape[1] < n:   # reference extend_pe(): recompute a longer table
+        """reference extend_pe(): recompute a longer table when needed; returns True if the table changed."""
+        if self.pe.shape[1] < n:
             self.pe = sinusoid_table(n, self.d_model).to(self.pe.device)
+            return True
+        return False
 
 
 class _SelfAttention(_Holder):
@@ -315,8 +318,14 @@ class FeedForwardTransformer(nn.Module):
 
     # ------------------------------------------------------------------ the path
     def _run(self, xs, ilens, olens=None, ds=None, es=None, ps=None, is_inference=False, compat=False,
-             want=("before", "after"), d_override=None):
-        """Runs fs2_encode -> (olens readback) -> fs2_decode.  Returns a dict of device tensors."""
+             want=("before", "after"), d_override=None, capacity=None):
+        """Runs fs2_encode -> (olens readback) -> fs2_decode.  Returns a dict of device tensors.
+
+        ``capacity=(total_frames_bound, per_utterance_bound)`` selects the device-driven frame layout instead: no host
+        read-back between the two calls, nothing in this method waits for the GPU.  Outputs are then padded to
+        ``per_utterance_bound`` frames, ``out["olens"]`` is the DEVICE int64 tensor and ``out["status"]`` a device
+        int32[4] = {rows used, attention work items, overflow flags, longest utterance}: the results are valid only if
+        ``status[2] == 0`` (see ``inference_batch(sync=False)``)."""
         _require_device(xs)
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
@@ -356,6 +365,38 @@ class FeedForwardTransformer(nn.Module):
                                 d_int.data_ptr() if d_int is not None else None, olens_dev.data_ptr(),
                                 enc_out.data_ptr() if enc_out is not None else None, tok_ws.data_ptr(), tok_ws.numel())
             _lib.check(L.fs2_encode(h, st, C.byref(eio)), h)
+            if capacity is not None:
+                total_cap, Lcap = int(capacity[0]), int(capacity[1])
+                self.decoder.embed[-1].ensure(Lcap)      # (a grown table is picked up by the next call's fingerprint check)
+                rows = int(L.fs2_row_capacity(C.byref(batch), total_cap))
+                frm_ws = torch.empty(L.fs2_frame_workspace_bytes_cap(h, C.byref(batch), rows), dtype=torch.uint8, device=dev)
+                status = torch.empty(4, dtype=torch.int32, device=dev)
+                odim = self.odim
+
+                def cbuf(key, shape, dtype=torch.float32):
+                    if key in want:
+                        out[key] = torch.empty(shape, dtype=dtype, device=dev)
+                        return out[key].data_ptr()
+                    return None
+
+                if teacher or "after_packed" in want:
+                    raise ValueError("the device-driven layout serves free-running synthesis with padded outputs")
+                dio = _lib.DecodeIO(
+                    batch, None, Lcap, 0, None, None, 0, 0,
+                    cbuf("before", (B, Lcap, odim)), cbuf("after", (B, Lcap, odim)),
+                    cbuf("e_outs", (B, Lcap)), cbuf("p_outs", (B, Lcap)),
+                    cbuf("qe", (B, Lcap), torch.int32), cbuf("qp", (B, Lcap), torch.int32),
+                    cbuf("lr_index", (B, Lcap), torch.int32), cbuf("decoder_out", (B, Lcap, self._cfg["ddim"])),
+                    tok_ws.data_ptr(), frm_ws.data_ptr(), frm_ws.numel(), None, rows, status.data_ptr())
+                if dio.after is None:
+                    raise ValueError("'after' must be requested")
+                _lib.check(L.fs2_decode(h, st, C.byref(dio)), h)
+                out["olens"], out["status"] = olens_dev, status
+                if d_int is not None:
+                    out["d_int"] = d_int if d_override is None else ds_dev
+                if enc_out is not None:
+                    out["encoder_out"] = enc_out
+                return out
             ol = olens_dev.cpu()                     # the one host sync of the path (frame counts)
             self.last_olens = ol
             if olens is not None:
@@ -363,8 +404,7 @@ class FeedForwardTransformer(nn.Module):
                 if not torch.equal(given, ol):
                     raise ValueError("olens %s do not match the sums of the durations %s" % (given.tolist(), ol.tolist()))
             Lmax = int(ol.max())
-            self.decoder.embed[-1].ensure(Lmax)
-            if self._weights_fingerprint() != self._fingerprint:   # pe table grew: reload and redo the encoder
+            if self.decoder.embed[-1].ensure(Lmax):                # pe table grew: reload and redo the encoder
                 return self._run(xs, ilens, olens, ds, es, ps, is_inference, compat, want, d_override)
             ol_arr = (C.c_int64 * B)(*ol.tolist())
             frm_ws = torch.empty(L.fs2_frame_workspace_bytes(h, C.byref(batch), ol_arr), dtype=torch.uint8, device=dev)
@@ -462,13 +502,69 @@ class FeedForwardTransformer(nn.Module):
         r = self._run(x.unsqueeze(0), torch.tensor([x.shape[0]]), is_inference=True, want=("after",))
         return r["after"][0]
 
-    def inference_batch(self, xs, ilens, d_override=None, packed=False):
+    def inference_batch(self, xs, ilens, d_override=None, packed=False, sync=True):
         """Batched free-running synthesis (not in the reference, which only has single-utterance
         ``inference``): per-utterance semantics; returns (mels [B, Lmax, odim], olens [B] on the host), or with
-        ``packed=True`` (valid frames back to back [sum(olens), odim], olens): the form the multi-GPU gather ships."""
+        ``packed=True`` (valid frames back to back [sum(olens), odim], olens): the form the multi-GPU gather ships.
+
+        ``sync=False``: nothing waits for the GPU.  The frame layout is built on the device inside capacities predicted
+        from earlier calls (frames per phoneme seen so far, with headroom), the call returns
+        (mels [B, Lcap, odim] zero-padded, olens as a DEVICE int64 tensor) and records ``self.last_async`` =
+        (olens_dev, status_dev, ilens); ``async_ok()`` (one host sync) tells whether the capacities sufficed, and
+        feeds the predictor.  If they did not, the outputs of that call are invalid: repeat it with ``sync=True``
+        (which learns the exact sizes).  The first call of a model is always synchronous."""
+        if not sync and not packed and self._frames_per_token is not None:
+            il = torch.as_tensor(ilens).detach().to("cpu", torch.int64)
+            self._harvest_async(block=False)
+            total = int(float(il.sum()) * self._frames_per_token[0] * 1.15) + 64 * int(il.numel())
+            Lcap = -(-int(float(il.max()) * self._frames_per_token[1] * 1.25 + 64) // 32) * 32
+            r = self._run(xs, il, is_inference=True, compat=False, want=("after",), d_override=d_override, capacity=(total, Lcap))
+            # frame counts and flags travel to pinned host memory behind the kernels; an event tells when they are there
+            B = int(il.numel())
+            pin = self._pinned
+            if pin is None or pin[0].numel() < B:
+                pin = self._pinned = (torch.empty(max(B, 64), dtype=torch.int64).pin_memory(), torch.empty(4, dtype=torch.int32).pin_memory())
+            pin[0][:B].copy_(r["olens"], non_blocking=True)
+            pin[1].copy_(r["status"], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(xs.device))
+            self.last_async = (il, ev)
+            return r["after"], r["olens"]
         want = ("after", "after_packed") if packed else ("after",)
         r = self._run(xs, ilens, is_inference=True, compat=False, want=want, d_override=d_override)
+        self._learn_ratio(torch.as_tensor(ilens).detach().to("cpu", torch.int64), r["olens"])
         return (r["after_packed"] if packed else r["after"]), r["olens"]
+
+    # frames-per-phoneme statistics for the capacities of the asynchronous path: (batch mean, max over utterances)
+    _frames_per_token = None
+    _pinned = None
+    last_async = None
+
+    def _learn_ratio(self, il, ol):
+        mean_r = float(ol.sum()) / max(float(il.sum()), 1.0)
+        max_r = float((ol.float() / il.float().clamp(min=1)).max())
+        old = self._frames_per_token
+        self._frames_per_token = (mean_r, max_r) if old is None else (max(mean_r, 0.9 * old[0]), max(max_r, 0.9 * old[1]))
+
+    def _harvest_async(self, block):
+        """Fold the frame counts of the last asynchronous call into the capacity predictor; waits for that call only if
+        ``block``.  Returns its overflow flags (0 = outputs valid), or None when it has not finished yet."""
+        if self.last_async is None:
+            return 0
+        il, ev = self.last_async
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return None
+        self.last_async = None
+        flags = int(self._pinned[1][2])
+        if flags == 0:
+            self._learn_ratio(il, self._pinned[0][: il.numel()].clone())
+        return flags
+
+    def async_ok(self):
+        """True if the capacities of the last ``inference_batch(sync=False)`` call sufficed (waits for that call)."""
+        return self._harvest_async(block=True) == 0
 
     def _source_mask(self, ilens):
         """reference fastspeech.py:359-376 (kept for API parity; the kernels take lengths, not masks)."""

@@ -122,7 +122,27 @@ typedef struct fs2_decode_io {
     size_t workspace_bytes;
     float *after_packed;      /* device [sum(olens), odim]: the valid frames of `after`, utterances back to
                                  back in batch order (what the multi-GPU all-gather ships), or NULL          */
+    /* Device-driven frame layout (no host read-back of the frame counts between fs2_encode and fs2_decode):
+     * set olens = NULL and give capacities instead.  The frame counts are taken from the device copy fs2_encode
+     * left in the token workspace, the packed-row layout and the attention work list are built by a kernel, grids
+     * are sized for the capacities and the surplus tiles exit at once.  Lmax is then the per-utterance capacity of
+     * the padded outputs.  status (device int32[4], required in this mode) receives
+     * {total rows used, attention work items, overflow flags, longest utterance}; overflow flags != 0
+     * (FS2_OVF_*) means a capacity was too small and the outputs are invalid: rerun with larger capacities or
+     * with host olens.  after_packed is not available in this mode. */
+    int64_t row_capacity;     /* 0 = host-driven layout (olens required)                                      */
+    int32_t *status;
 } fs2_decode_io;
+
+#define FS2_OVF_ROWS 1        /* packed rows needed > row_capacity                                           */
+#define FS2_OVF_LMAX 2        /* an utterance is longer than Lmax                                            */
+#define FS2_OVF_PE 4          /* an utterance is longer than the decoder's positional table                  */
+#define FS2_OVF_EMPTY 8       /* an utterance has no frames                                                  */
+
+/* rows to reserve for fs2_decode's device-driven layout given an estimate of the total frame count (alignment
+ * and gap rows of the packed layout included) */
+int64_t fs2_row_capacity(const fs2_batch *batch, int64_t total_frames_bound);
+size_t fs2_frame_workspace_bytes_cap(const fs2_handle *h, const fs2_batch *batch, int64_t row_capacity);
 
 /* lifecycle (replaces FeedForwardTransformer.__init__ / .to(device) / load_state_dict,
  * reference fastspeech.py:37-167, inference.py:156-166) */

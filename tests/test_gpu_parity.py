@@ -206,6 +206,36 @@ def _c3_body(env, precision):
     assert _maxabs(after[i, :L], o["after"][0]) <= MEL_TOL
 
 
+def test_device_driven_layout_matches_host_driven(env):
+    """fs2_decode's device-driven mode (no frame-count read-back between encode and decode; layout, attention work list
+    and bounds built by a kernel inside capacities) gives bit-identical mels to the host-driven mode, in every
+    arithmetic mode; an insufficient capacity is reported through the status flags, never by corrupting memory."""
+    model = env[0]
+    from fastspeech2_amd.synthetic import make_batch
+    b = make_batch("c3", B=12)
+    xs, il, ds = b["xs"].cuda(), b["ilens"], b["ds"].cuda()      # forced LJSpeech-like durations (~6 k frames)
+    for precision in ("fp32", "bf16x3"):
+        model.precision = precision
+        try:
+            with torch.no_grad():
+                ref, ol = model.inference_batch(xs, il, d_override=ds)                       # synchronous, host-driven layout
+                got, ol_dev = model.inference_batch(xs, il, d_override=ds, sync=False)       # capacities learnt from the call above
+                assert model.async_ok()
+                assert torch.equal(ol_dev.cpu(), ol)
+                Lmax = int(ol.max())
+                assert got.shape[1] >= Lmax and float(got[:, Lmax:].abs().max() if got.shape[1] > Lmax else 0.0) == 0.0
+                assert torch.equal(got[:, :Lmax], ref), "device-driven layout changed the result (%s)" % precision
+                r = model._run(xs, il, is_inference=True, want=("after",), d_override=ds, capacity=(int(ol.sum()) // 2, Lmax + 32))
+                st = r["status"].cpu()
+                assert int(st[2]) & 1, "row overflow not flagged: %s" % st.tolist()
+                r = model._run(xs, il, is_inference=True, want=("after",), d_override=ds, capacity=(int(ol.sum()) + 64, Lmax - 8))
+                assert int(r["status"].cpu()[2]) & 2, "Lmax overflow not flagged"
+                again, _ = model.inference_batch(xs, il, d_override=ds)                      # the handle is still healthy
+                assert torch.equal(again, ref)
+        finally:
+            model.precision = "fp32"
+
+
 def test_reference_smoke_shape(env):
     """Counterpart of the reference's only test (tests/test_fastspeech2.py:7-20): B=2, T=L=100, all ones,
     through forward(); here in eval mode, asserting what the reference merely runs."""
