@@ -122,7 +122,7 @@ def lib():
     L.fs2_frame_workspace_bytes.restype = C.c_size_t
     L.fs2_row_capacity.argtypes = [C.POINTER(Batch), C.c_int64]
     L.fs2_row_capacity.restype = C.c_int64
-    L.fs2_frame_workspace_bytes_cap.argtypes = [vp, C.POINTER(Batch), C.c_int64]
+    L.fs2_frame_workspace_bytes_cap.argtypes = [vp, C.POINTER(Batch), C.c_int64, i32]
     L.fs2_frame_workspace_bytes_cap.restype = C.c_size_t
     L.fs2_decode.argtypes = [vp, vp, C.POINTER(DecodeIO)]
     L.fs2_decode.restype = C.c_int

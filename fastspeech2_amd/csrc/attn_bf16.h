@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
     const int lr = lane & 15, lg = lane >> 4;
     if (a.nwork != nullptr && (int)blockIdx.x >= *a.nwork) return;
     const int2 wk = a.work[blockIdx.x];
+    if (wk.x < 0) return;                      // padding entry of the XCD-interleaved work list
     const int b = wk.x, h = blockIdx.y;
     const int s0 = a.start[b], len = a.len[b], klen = a.klen[b];
     const int q0 = wk.y * 64 + wave * 16;

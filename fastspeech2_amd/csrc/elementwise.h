@@ -23,9 +23,10 @@ __global__ void build_row_meta(const int* start, const int* len, int B, int rpad
 }
 
 // Frame-side layout built on the device from the frame counts the duration scan left there (device-driven mode of
-// fs2_decode: no host read-back).  Mirrors build_layout() in fs2_runtime.hip exactly: 32-row aligned starts, kGap zero rows
-// between utterances, attention work list = (utterance, 64-query block) ordered by key length descending (stable).
-// One workgroup.  dims = {rows used, work items, overflow flags, longest utterance}; 8 = kGap, 32 = kAttAlign, 64 = kAttBQ.
+// fs2_decode: no host read-back).  Mirrors build_layout() / build_work_list() in fs2_runtime.hip exactly: 32-row aligned starts,
+// kGap zero rows between utterances, attention work list = (utterance, 64-query block) items in eight interleaved per-XCD queues,
+// utterances dealt longest-key-range first to the shortest queue, padding entries (-1, 0).
+// One workgroup.  dims = {rows used, work list length, overflow flags, longest utterance}; 8 = kGap, 32 = kAttAlign, 64 = kAttBQ.
 __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B, int compat, int masked, int row_cap, int work_cap,
                                                          int lmax_cap, int pe_rows, int* start, int* len, int* klen, int* vlen,
                                                          int* rank_tmp, int* woff_tmp, int2* work, int* dims) {
@@ -45,8 +46,9 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
         len[b] = compat ? mx : v;
         klen[b] = compat ? (masked ? v : mx) : v;
     }
+    for (int i = tid; i < work_cap; i += 1024) work[i] = make_int2(-1, 0);
     __syncthreads();
-    // position of utterance b in the work order: longer key ranges first, ties in batch order
+    // position of utterance b in the dealing order: longer key ranges first, ties in batch order
     for (int b = tid; b < B; b += 1024) {
         const int k = klen[b];
         int r = 0;
@@ -61,14 +63,22 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
             start[b] = row;
             row += len[b] + 8;
         }
-        int w = 0;
-        for (int r = 0; r < B; ++r) { const int b = rank_tmp[r]; woff_tmp[b] = w; w += (len[b] + 63) >> 6; }
+        int qlen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int depth = 0;
+        for (int r = 0; r < B; ++r) {
+            const int b = rank_tmp[r];
+            int j = 0;
+            for (int t = 1; t < 8; ++t) if (qlen[t] < qlen[j]) j = t;
+            woff_tmp[b] = qlen[j] * 8 + j;        // list position of the utterance's first block; the next ones follow 8 apart
+            qlen[j] += (len[b] + 63) >> 6;
+            depth = max(depth, qlen[j]);
+        }
         int ovf = 0;
-        if (row > row_cap || w > work_cap) ovf |= 1;
+        if (row > row_cap || depth * 8 > work_cap) ovf |= 1;
         if (mx > lmax_cap) ovf |= 2;
         if (mx > pe_rows) ovf |= 4;
         if (s_min <= 0) ovf |= 8;
-        dims[0] = row; dims[1] = ovf ? 0 : w; dims[2] = ovf; dims[3] = mx;
+        dims[0] = row; dims[1] = ovf ? 0 : depth * 8; dims[2] = ovf; dims[3] = mx;
     }
     __syncthreads();
     if (dims[2] != 0) {           // a capacity is too small: leave an empty layout (all rows are gap rows, no work) so that
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
     }
     for (int b = tid; b < B; b += 1024) {
         const int nq = (len[b] + 63) >> 6, o = woff_tmp[b];
-        for (int q = 0; q < nq; ++q) work[o + q] = make_int2(b, q);
+        for (int q = 0; q < nq; ++q) work[o + 8 * q] = make_int2(b, q);
     }
 }
 

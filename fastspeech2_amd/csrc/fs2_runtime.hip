@@ -48,6 +48,8 @@ struct Stack {
     float* alpha = nullptr;
 };
 
+constexpr int kXcds = 8;      // MI355X: 8 accelerator dies, workgroups of a launch are dealt to them round-robin
+
 struct HostLayout {
     int B = 0, R = 0, Rpad = 0;
     std::vector<int> start, len, klen, vlen;
@@ -448,21 +450,43 @@ int launch_attention_b16(fs2_handle* h, hipStream_t s, const char* name, const f
 }
 
 // ------------------------------------------------------------------ layouts
+// Attention work list = (utterance, 64-query block) items, dispatched in list order.  Two goals:
+//  * XCD locality: workgroup i of a launch runs on XCD i % 8 (round-robin dispatch) and every XCD has its own L2.  All query
+//    blocks of one utterance stream the same K / V rows, so they are given to ONE XCD: the list is eight interleaved queues
+//    (entry 8 i + j = i-th item of queue j).  With the blocks of an utterance spread over all XCDs the K / V planes were
+//    fetched from HBM once per XCD: 830 MB per decoder-layer launch at c3 (PMC FETCH_SIZE), the whole 128 us of it.
+//  * balance: utterances go to the queues longest first, each to the currently shortest queue (LPT); queues are padded to
+//    the same length with (-1, 0) entries that exit at once.
+void build_work_list(const std::vector<int>& len, const std::vector<int>& klen, std::vector<int2>& work) {
+    const int B = (int)len.size();
+    std::vector<int> order(B);
+    for (int b = 0; b < B; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return klen[x] > klen[y]; });
+    std::vector<int2> q[kXcds];
+    for (int b : order) {
+        int j = 0;
+        for (int t = 1; t < kXcds; ++t) if (q[t].size() < q[j].size()) j = t;
+        for (int i = 0; i * kAttBQ < len[b]; ++i) q[j].push_back(make_int2(b, i));
+    }
+    size_t depth = 0;
+    for (int j = 0; j < kXcds; ++j) depth = std::max(depth, q[j].size());
+    work.assign(depth * kXcds, make_int2(-1, 0));
+    for (int j = 0; j < kXcds; ++j)
+        for (size_t i = 0; i < q[j].size(); ++i) work[i * kXcds + j] = q[j][i];
+}
+
 void build_layout(HostLayout& L, int B, const std::vector<int>& len, const std::vector<int>& klen, const std::vector<int>& vlen) {
     L.B = B; L.len = len; L.klen = klen; L.vlen = vlen;
-    L.start.resize(B); L.work.clear();
+    L.start.resize(B);
     int row = kGap;
     for (int b = 0; b < B; ++b) {
         row = round_up(row, kAttAlign);     // 32-row aligned starts: 16-byte aligned V^T key tiles (attn_bf16.h)
         L.start[b] = row;
-        for (int q = 0; q * kAttBQ < len[b]; ++q) L.work.push_back(make_int2(b, q));
         row += len[b] + kGap;
     }
     L.R = row;
     L.Rpad = round_up(row, 128);
-    // attention work list: longest key ranges first, so that the few long utterances do not form the tail of the launch
-    // (a workgroup's run time is proportional to klen; dispatch follows the list order)
-    std::stable_sort(L.work.begin(), L.work.end(), [&](const int2& x, const int2& y) { return klen[x.x] > klen[y.x]; });
+    build_work_list(len, klen, L.work);
 }
 
 size_t layout_dev_ints(const HostLayout& L) { return (size_t)6 * L.B + 2 * (size_t)L.Rpad + 2 * (size_t)L.nwork() + 64 + 16; }
@@ -1024,16 +1048,17 @@ int64_t fs2_row_capacity(const fs2_batch* b, int64_t total_frames_bound) {
     return round_up((int)std::min<int64_t>(total_frames_bound + (int64_t)b->B * (kGap + kAttAlign) + kGap, INT32_MAX - 256), 128);
 }
 
-void capacity_layout(const fs2_batch& b, int64_t row_capacity, HostLayout& L) {
+void capacity_layout(const fs2_batch& b, int64_t row_capacity, int lmax_cap, HostLayout& L) {
     L.B = b.B; L.R = (int)row_capacity; L.Rpad = round_up((int)row_capacity, 128);
-    L.work_cap = (int)(row_capacity / kAttBQ) + b.B;
+    // eight LPT queues: none is longer than the mean plus one utterance's items
+    L.work_cap = kXcds * (((int)(row_capacity / kAttBQ) + b.B + kXcds - 1) / kXcds + lmax_cap / kAttBQ + 2);
     L.start.clear(); L.len.clear(); L.klen.clear(); L.vlen.clear(); L.work.clear();
 }
 
-size_t fs2_frame_workspace_bytes_cap(const fs2_handle* h, const fs2_batch* b, int64_t row_capacity) {
-    if (!h || !b || b->B <= 0 || row_capacity <= 0 || row_capacity > INT32_MAX - 256) return 0;
+size_t fs2_frame_workspace_bytes_cap(const fs2_handle* h, const fs2_batch* b, int64_t row_capacity, int32_t lmax_cap) {
+    if (!h || !b || b->B <= 0 || row_capacity <= 0 || row_capacity > INT32_MAX - 256 || lmax_cap <= 0) return 0;
     HostLayout L;
-    capacity_layout(*b, row_capacity, L);
+    capacity_layout(*b, row_capacity, lmax_cap, L);
     return carve_frames(h->cfg, L, nullptr, 0, nullptr, nullptr);
 }
 
@@ -1064,7 +1089,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     HIP_TRY(h, hipSetDevice(c.device));
     hipStream_t s = (hipStream_t)stream;
     HostLayout L;
-    if (devlay) capacity_layout(b, io->row_capacity, L);
+    if (devlay) capacity_layout(b, io->row_capacity, io->Lmax, L);
     else frame_layout(b, io->olens, io->masked, L);
     FrameBufs f; bool ok;
     carve_frames(c, L, io->workspace, io->workspace_bytes, &f, &ok);

@@ -369,7 +369,7 @@ class FeedForwardTransformer(nn.Module):
                 total_cap, Lcap = int(capacity[0]), int(capacity[1])
                 self.decoder.embed[-1].ensure(Lcap)      # (a grown table is picked up by the next call's fingerprint check)
                 rows = int(L.fs2_row_capacity(C.byref(batch), total_cap))
-                frm_ws = torch.empty(L.fs2_frame_workspace_bytes_cap(h, C.byref(batch), rows), dtype=torch.uint8, device=dev)
+                frm_ws = torch.empty(L.fs2_frame_workspace_bytes_cap(h, C.byref(batch), rows, Lcap), dtype=torch.uint8, device=dev)
                 status = torch.empty(4, dtype=torch.int32, device=dev)
                 odim = self.odim
 

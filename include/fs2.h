@@ -142,7 +142,7 @@ typedef struct fs2_decode_io {
 /* rows to reserve for fs2_decode's device-driven layout given an estimate of the total frame count (alignment
  * and gap rows of the packed layout included) */
 int64_t fs2_row_capacity(const fs2_batch *batch, int64_t total_frames_bound);
-size_t fs2_frame_workspace_bytes_cap(const fs2_handle *h, const fs2_batch *batch, int64_t row_capacity);
+size_t fs2_frame_workspace_bytes_cap(const fs2_handle *h, const fs2_batch *batch, int64_t row_capacity, int32_t lmax_capacity);
 
 /* lifecycle (replaces FeedForwardTransformer.__init__ / .to(device) / load_state_dict,
  * reference fastspeech.py:37-167, inference.py:156-166) */
