@@ -122,14 +122,15 @@ def main():
         if not use_dist:
             # nothing on the host waits for the GPU: the frame layout is built on the device (fs2_decode's device-driven
             # mode); the very first call is synchronous and teaches the capacity predictor the frames-per-phoneme ratio
-            return model.inference_batch(xs, il, sync=False)
+            # (--profile-kernels uses the host-driven layout so that the per-site FLOP counts are those of the rows in use)
+            return model.inference_batch(xs, il, sync=args.profile_kernels)
         packed, olens = model.inference_batch(xs, il, packed=True)          # valid frames only travel over xGMI
         return gather_packed(packed, olens, index, B * world)
 
     with torch.no_grad():
         for _ in range(max(args.warmup, 1)):
             mel, olens_all = step()
-        if not use_dist:
+        if not use_dist and not args.profile_kernels:
             assert model.async_ok(), "capacities of the asynchronous path were exceeded during warm-up"
         local_frames = int(model.last_olens.sum())
         total_frames = int(olens_all.sum())
@@ -154,7 +155,7 @@ def main():
         if use_dist:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if not use_dist:
+        if not use_dist and not args.profile_kernels:
             assert model.async_ok(), "capacities of the asynchronous path were exceeded in the timed region"
         prof = model.get_profile()
         model.set_profiling(False)
@@ -190,10 +191,10 @@ def main():
                     share_of_kernel_time=round(scout[dom_name] / kernel_ms_per_step, 3),
                     kernel_ms_per_step=round(kernel_ms_per_step, 3))
     try:    # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01c_traffic.json")))
         if tr["workload"] == args.workload and tr["precision"] == args.precision and tr["kernel_site"] == dom_name and world == 1:
             roofline["traffic"] = tr["traffic_bytes"]
-            roofline["traffic_note"] = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r01_traffic.json; algorithmic HBM bytes %d" % tr["algorithmic_bytes"]
+            roofline["traffic_note"] = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r01c_traffic.json; algorithmic HBM bytes %d" % tr["algorithmic_bytes"]
     except (OSError, KeyError, ValueError):
         pass
     if args.precision == "bf16x3":   # three MFMAs are issued per algorithmic product
