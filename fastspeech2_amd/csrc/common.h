@@ -108,21 +108,20 @@ __device__ __forceinline__ void store_planes4(void* planes, size_t row, int nchu
 }
 
 // Elementwise epilogue of a (16 MT) x 64 wave tile held as acc[MT][4] (16 x 16 MFMA tiles, C layout col = l&15,
-// row = 4*(l>>4) + reg).  All loads of a 16-row slab (row flags, residual) are issued before its stores and the
-// pointers are __restrict__, so the compiler does not serialise a memory round trip per element behind
+// row = 4*(l>>4) + reg) - the fp32 kernels.  All loads of a 16-row slab (row flags, residual) are issued before its stores
+// and the pointers are __restrict__, so the compiler does not serialise a memory round trip per element behind
 // possibly-aliasing stores (that cost ~25 us per workgroup before).
-template <int MT, bool PERM = false>
+template <int MT>
 __device__ __forceinline__ void tile_epilogue_64x64(const GemmArgs& a, f32x4 (&acc)[MT][4], int row_base, int col_base, int lr, int lg,
                                                     bool relu_first) {
     const float* __restrict__ biasp = a.bias;
     const float* __restrict__ residp = a.resid;
     const int* __restrict__ rpos = a.row_pos;
     float* __restrict__ Y = a.Y;
-    const int lc = PERM ? rperm(lr) : lr;                 // column of this lane inside a 16-wide tile
     float bv[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int col = col_base + nt * 16 + lc;
+        const int col = col_base + nt * 16 + lr;
         bv[nt] = (biasp && col < a.N) ? biasp[col] : 0.f;
     }
 #pragma unroll
@@ -131,25 +130,25 @@ __device__ __forceinline__ void tile_epilogue_64x64(const GemmArgs& a, f32x4 (&a
         float rv[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = row_base + mt * 16 + (PERM ? rperm(lg * 4 + r) : lg * 4 + r);
+            const int row = row_base + mt * 16 + lg * 4 + r;
             inb[r] = row < a.R;
             valid[r] = inb[r] && (rpos == nullptr || rpos[row] >= 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = row_base + mt * 16 + (PERM ? rperm(lg * 4 + r) : lg * 4 + r);
+            const int row = row_base + mt * 16 + lg * 4 + r;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int col = col_base + nt * 16 + lc;
+                const int col = col_base + nt * 16 + lr;
                 rv[r][nt] = (residp && inb[r] && col < a.N) ? residp[(size_t)row * a.ldr + col] : 0.f;
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = row_base + mt * 16 + (PERM ? rperm(lg * 4 + r) : lg * 4 + r);
+            const int row = row_base + mt * 16 + lg * 4 + r;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int col = col_base + nt * 16 + lc;
+                const int col = col_base + nt * 16 + lr;
                 float v = acc[mt][nt][r] + bv[nt] + rv[r][nt];
                 if (relu_first) v = fmaxf(v, 0.f);
                 v = apply_act(v, a.act_post);

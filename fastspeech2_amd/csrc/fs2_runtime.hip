@@ -169,61 +169,6 @@ hipError_t launch_tile(hipStream_t s, const GemmArgs& a) {
 
 bool rows_supported(int N) { return N == 80 || N == 256 || N == 384; }
 
-template <int NSPLIT, bool K1, int BM>
-hipError_t launch_glds_bf16_t(hipStream_t s, const GemmArgs& a) {
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_bf16<NSPLIT, K1, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds_lds_bytes<K1, BM>());
-        attr = true;
-    }
-    const int nN = (a.N + kB16BN - 1) / kB16BN, nM = ((a.qk_hi ? a.Rvt : a.R) + BM - 1) / BM;
-    const size_t lds = glds_lds_bytes<K1, BM>();
-    hipLaunchKernelGGL((gemm_glds_bf16<NSPLIT, K1, BM>), dim3(nN * nM), dim3(256), lds, s, a);
-    return hipGetLastError();
-}
-
-// Kernel choice per shape (measured on MI355X, c3): the 9-tap FFN conv is ~10 % faster with the A tile register-staged
-// (gemm_tile_bf16: the fp32->bf16 split happens once per chunk, not once per tap); k = 1 GEMMs are ~5-15 % faster
-// with all-DMA staging (gemm_glds_bf16: A and B double-buffered, no staging registers).  FS2_GEMM=regs|glds forces one.
-int gemm_choice() {     // read per launch (a getenv is nanoseconds) so that tests can switch kernels inside one process
-    const char* e = getenv("FS2_GEMM");
-    return !e ? 0 : (!strcmp(e, "glds") ? 1 : (!strcmp(e, "regs") ? 2 : 0));
-}
-bool use_glds(int ktaps) { const int c = gemm_choice(); return c == 1 || (c == 0 && ktaps == 1); }
-
-// 64-row tiles when 128-row tiles would leave most of the 256 CUs (x 2-3 workgroups) without work (encoder, small batches)
-bool small_grid(const GemmArgs& a) {
-    const char* e = getenv("FS2_BM");
-    const int force = !e ? 0 : atoi(e);
-    if (force == 64) return true;
-    if (force == 128) return false;
-    if (a.ktaps == 1) return true;     // k = 1 GEMMs measure 8-20 % faster with 64-row tiles at every size (3-4 workgroups/CU)
-    const long nN = (a.N + kB16BN - 1) / kB16BN, nM = (a.R + 127) / 128;
-    return nN * nM < 400;     // measured: 296 workgroups of 128 rows (enc.ffn1) prefer 64-row tiles, 458 (Postnet, predictors) do not
-}
-
-template <int NSPLIT, int BM>
-hipError_t launch_tile_bf16_t(hipStream_t s, const GemmArgs& a) {
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_bf16<NSPLIT, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b16_lds<BM>());
-        attr = true;
-    }
-    dim3 grid((a.N + kB16BN - 1) / kB16BN, (a.R + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm_tile_bf16<NSPLIT, BM>), grid, dim3(256), b16_lds<BM>(), s, a);
-    return hipGetLastError();
-}
-
-template <int NSPLIT>
-hipError_t launch_tile_bf16(hipStream_t s, const GemmArgs& a) {
-    const bool sm = small_grid(a);
-    if (use_glds(a.ktaps) || a.qk_hi) {
-        if (a.ktaps == 1) return sm ? launch_glds_bf16_t<NSPLIT, true, 64>(s, a) : launch_glds_bf16_t<NSPLIT, true, 128>(s, a);
-        return sm ? launch_glds_bf16_t<NSPLIT, false, 64>(s, a) : launch_glds_bf16_t<NSPLIT, false, 128>(s, a);
-    }
-    return sm ? launch_tile_bf16_t<NSPLIT, 64>(s, a) : launch_tile_bf16_t<NSPLIT, 128>(s, a);
-}
-
 template <int NSPLIT, int BM, bool K1>
 hipError_t launch_pl_t(hipStream_t s, const GemmArgs& a) {
     static bool attr = false;
@@ -281,9 +226,9 @@ hipError_t launch_pl(hipStream_t s, const GemmArgs& a) {
     return bm == 128 ? launch_pl_t<NSPLIT, 128, false>(s, a) : launch_pl_t<NSPLIT, 64, false>(s, a);
 }
 
-// Picks the kernel.  fp32: row-complete tiles when the epilogue needs whole rows, 128x128 tiles otherwise.
-// bf16 / bf16x3: one 256x128 MFMA tile kernel (+ elementwise epilogue), followed by the HBM-bound row kernel
-// when the op ends in LayerNorm / positional encoding / scalar head.
+// Picks the kernel.  fp32: row-complete tiles when the epilogue needs whole rows and N is small, 128x128 tiles (+ ln_rows) otherwise.
+// bf16 / bf16x3 (activation planes in, gemm_planes.h): the row-complete LayerNorm-fused kernel for big k = 1 GEMMs that end in
+// a row epilogue, else the BM x 128 tile kernel followed by ln_rows when a row epilogue is needed.
 int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int precision = FS2_PREC_FP32) {
     if (a.ktaps - 1 > kMaxHalo) return fail(h, FS2_ERR_UNSUPPORTED, "%s: kernel size %d > %d", name, a.ktaps, kMaxHalo + 1);
     if (a.C % 4 != 0 || a.ldx % 4 != 0) return fail(h, FS2_ERR_UNSUPPORTED, "%s: channels %d / ld %d must be multiples of 4", name, a.C, a.ldx);
@@ -296,17 +241,16 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         if (a.C % 8 != 0 || a.N % 4 != 0 || (need_rows && a.N > 1024)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: bf16 path needs C %% 8 == 0, N %% 4 == 0 (N <= 1024 with a row epilogue)", name);
         GemmArgs t = a;
         t.W = reinterpret_cast<const float*>(a.Wb);
-        // planes kernel (gemm_planes.h) whenever the A operand exists as split-bf16 planes or may be built in xp_scratch
-        const bool planes = (a.Xp || a.xp_scratch) && gemm_choice() == 0 && a.ldy % 4 == 0 && (!a.resid || a.ldr % 4 == 0) &&
-                            (!a.qk_hi || a.att_D % kB16BN == 0);
-        const bool row8 = planes && use_row8(a);
+        // the A operand must exist as split-bf16 planes (Xp) or be convertible into xp_scratch (gemm_planes.h)
+        if (!a.Xp && !a.xp_scratch) return fail(h, FS2_ERR_STATE, "%s: no activation planes and no scratch to build them", name);
+        if (a.ldy % 4 != 0 || (a.resid && a.ldr % 4 != 0)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: bf16 path needs row strides that are multiples of 4", name);
+        const bool row8 = use_row8(a);
         const bool y_needed = (need_rows && !row8) || (!a.Yp && !a.qk_hi);
         if (!t.Y && y_needed) { t.Y = a.scratch; t.ldy = a.N; }
         if (!t.Y && y_needed) return fail(h, FS2_ERR_ARG, "%s: no output or scratch buffer", name);
         if (t.qk_hi && (a.ktaps != 1 || a.att_D % kB16BN != 0 || a.N != 3 * a.att_D)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: fused QKV split needs D %% 128 == 0", name);
-        if (a.Yp && !planes) return fail(h, FS2_ERR_STATE, "%s: plane output requested on the fp32-input kernels", name);
         if (need_rows && !row8) { t.act_post = 0; t.Yp = nullptr; }      // the row kernel writes the planes
-        if (planes && !a.Xp) {
+        if (!a.Xp) {
             char nm[112];
             snprintf(nm, sizeof nm, "%s.planes", name);
             Scope sc(h, s, nm, 0.0, 8.0 * a.R * a.Cpad);
@@ -319,8 +263,7 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
             if (row8) {
                 if (a.N == 384) e = (precision == FS2_PREC_BF16X3) ? launch_row8_t<3, 3>(s, t) : launch_row8_t<1, 3>(s, t);
                 else e = (precision == FS2_PREC_BF16X3) ? launch_row8_t<3, 2>(s, t) : launch_row8_t<1, 2>(s, t);
-            } else if (planes) e = (precision == FS2_PREC_BF16X3) ? launch_pl<3>(s, t) : launch_pl<1>(s, t);
-            else e = (precision == FS2_PREC_BF16X3) ? launch_tile_bf16<3>(s, t) : launch_tile_bf16<1>(s, t);
+            } else e = (precision == FS2_PREC_BF16X3) ? launch_pl<3>(s, t) : launch_pl<1>(s, t);
         }
         if (e == hipSuccess && need_rows && !row8) {
             char nm[112];
@@ -542,8 +485,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
     double att_flops = 0;
     for (size_t i = 0; i < L.klen.size(); ++i) att_flops += 4.0 * D * (double)L.klen[i] * std::min(L.len[i], mask_q ? L.klen[i] : L.len[i]);
     // bf16 modes: activations travel between the GEMMs as split-bf16 planes (no conversion work inside the MFMA loops)
-    const int hidden = st.layers.empty() ? 0 : st.layers[0].w1.N;
-    const bool pl = prec != FS2_PREC_FP32 && gemm_choice() == 0 && D % 32 == 0 && hidden % 32 == 0 && b.x0p && b.x1p;
+    const bool pl = prec != FS2_PREC_FP32;
     void* ctxp = pl ? (void*)b.ctx : nullptr;
     void* hidp = pl ? (void*)b.hid : nullptr;
     if (pl && !x0p_ready) {
@@ -559,7 +501,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         GemmArgs a = gemm_args(ly.qkv, b.x0, D, R, dl.row_pos, b.qkv, 3 * D);
         a.Rp = dl.dims;
         if (pl) a.Xp = b.x0p;
-        const bool fused_split = prec != FS2_PREC_FP32 && D % kB16BN == 0 && gemm_choice() != 2;
+        const bool fused_split = prec != FS2_PREC_FP32 && D % kB16BN == 0;
         if (fused_split) {   // bf16 attention operands straight from the GEMM epilogue (no fp32 QKV round trip)
             a.Y = nullptr; a.qk_hi = b.qkh; a.qk_lo = b.qkl; a.vt_hi = b.vth; a.vt_lo = b.vtl; a.att_D = D; a.Rvt = L.Rpad;
             a.q_scale = 1.4426950408889634f / sqrtf((float)(D / heads));
@@ -579,7 +521,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         a = gemm_args(ly.w1, b.x1, D, R, dl.row_pos, pl ? nullptr : b.hid, ly.w1.N);
         a.Rp = dl.dims;
         a.act_post = 1;
-        if (pl) { a.Xp = b.x1p; a.Yp = hidp; a.yp_chunks = ly.w1.N / 32; }
+        if (pl) { a.Xp = b.x1p; a.Yp = hidp; a.yp_chunks = round_up(ly.w1.N, 32) / 32; }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.ffn2_ln", tag);
         a = gemm_args(ly.w2, b.hid, ly.w1.N, R, dl.row_pos, b.x0, D);
@@ -780,7 +722,7 @@ size_t carve_tokens(const fs2_config& c, const fs2_batch& b, const HostLayout& L
     float* x1 = bp.take<float>(R * c.adim);
     float* qkv = bp.take<float>(R * 3 * c.adim);
     float* ctx = bp.take<float>(R * c.adim);
-    float* hid = bp.take<float>(R * c.eunits);
+    float* hid = bp.take<float>(R * (size_t)round_up(c.eunits, 32));     // bf16 modes: hidden layer as planes (32-channel chunks)
     __bf16* qkh = bp.take<__bf16>(R * 2 * c.adim);
     __bf16* qkl = bp.take<__bf16>(R * 2 * c.adim);
     __bf16* vth = bp.take<__bf16>(R * c.adim);
@@ -825,7 +767,7 @@ size_t carve_frames(const fs2_config& c, const HostLayout& L, void* ws, size_t c
     f.sb.x1 = bp.take<float>(R * c.ddim);
     f.sb.qkv = bp.take<float>(R * 3 * c.ddim);
     f.sb.ctx = bp.take<float>(R * c.ddim);
-    f.sb.hid = bp.take<float>(R * (size_t)std::max(c.dunits, 2 * c.postnet_chans));
+    f.sb.hid = bp.take<float>(R * (size_t)std::max(round_up(c.dunits, 32), 2 * c.postnet_chans));
     f.sb.qkh = bp.take<__bf16>(R * 2 * c.ddim);
     f.sb.qkl = bp.take<__bf16>(R * 2 * c.ddim);
     f.sb.vth = bp.take<__bf16>(R * c.ddim);
@@ -1015,7 +957,7 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
         HIP_TRY(h, hipGetLastError());
     }
     if ((rc = run_stack(h, s, "enc", h->enc, c.adim, c.aheads, L.R, L, dl, /*mask_q=*/1, sb, b.precision))) return rc;
-    const bool enc_pl = b.precision != FS2_PREC_FP32 && gemm_choice() == 0 && c.adim % 32 == 0 && c.eunits % 32 == 0;   // run_stack left planes of x0 in x0p
+    const bool enc_pl = b.precision != FS2_PREC_FP32;   // run_stack left planes of x0 in x0p
     if ((rc = run_predictor(h, s, "dur", h->dur, sb.x0, c.adim, L.R, dl.row_pos, p0, p1, dlog_rows, b.precision, enc_pl ? sb.x0p : nullptr, sb.xps))) return rc;
     {
         Scope sc(h, s, "dur.post", 0, 0);
@@ -1115,7 +1057,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
                            io->ps, io->ps_stride, f.e_rows, f.p_rows, h->ebins, h->pbins, c.n_bins - 1, h->Te, h->Tp, f.qe, f.qp);
         HIP_TRY(h, hipGetLastError());
     }
-    const bool dec_pl = b.precision != FS2_PREC_FP32 && gemm_choice() == 0 && c.ddim % 32 == 0 && c.dunits % 32 == 0;
+    const bool dec_pl = b.precision != FS2_PREC_FP32;
     if (c.decoder_input_layer) {   // decoder input layer: Linear -> LN -> ReLU -> + alpha * pe   (reference encoder.py:118-125)
         GemmArgs a = gemm_args(h->dec_in, f.hfr, c.adim, R, dl.row_pos, f.sb.x0, c.ddim);
         a.Rp = dl.dims;
@@ -1211,7 +1153,7 @@ int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
     OP_TRY(hipMalloc((void**)&g.wb, wn * 4));
     float* scratch = nullptr;
     OP_TRY(hipMalloc((void**)&scratch, (size_t)o->R * o->N * sizeof(float)));
-    void* xps = nullptr;          // planes of x for the bf16 modes (gemm_planes.h); FS2_GEMM=regs|glds selects the fp32-input kernels
+    void* xps = nullptr;          // planes of x for the bf16 modes (gemm_planes.h)
     if (o->precision != FS2_PREC_FP32) OP_TRY(hipMalloc(&xps, (size_t)o->R * g.Cpad * sizeof(float)));
     int* rp = nullptr;
     hipMemsetAsync(g.w, 0, wn * sizeof(float), s);

@@ -1,27 +1,16 @@
-// bf16 / split-bf16 ("bf16x3") conv-as-GEMM on v_mfma_f32_16x16x32_bf16 (gfx950, 2.5 PFLOP/s dense peak).
+// Shared pieces of the split-bf16 ("bf16x3") GEMM kernels (gemm_planes.h) on v_mfma_f32_16x16x32_bf16 (gfx950, 2.5 PFLOP/s
+// dense peak): the operand split, the LDS image, the weight repack, the V^T part of the fused QKV epilogue and the row kernel.
 //
-// Same contraction as gemm_f32.h:  Y[m,n] = epi( sum_{tap,c} X[m+tap-P, c] * W[n,tap,c] ), fp32 in HBM on both
-// sides.  Plain bf16 misses the 1e-3 mel tolerance by 20x, so the parity mode splits every
-// operand x = hi + lo (hi = bf16(x), lo = bf16(x - hi), ~16 mantissa bits) and issues three MFMAs per fragment
-// pair, hi*hi + hi*lo + lo*hi, accumulating in fp32 (NSPLIT = 3).  NSPLIT = 1 is plain bf16.
-//   * weights are split once at load time into the exact LDS image: [Npad][chunk][tap][hi 32 | lo 32] (k-step order)
-//     (128 B per (n, tap, chunk));
-//   * activations stay fp32 in HBM and are split in registers while they are staged into LDS
-//     (v_cvt_pk_bf16_f32: ~3 VALU ops per element, amortised over the 9 taps of the FFN conv).
-// Tile: 128 x 128 outputs per workgroup, 4 waves as 2(M) x 2(N), 64 x 64 per wave (4 x 4 MFMA tiles, 64
-// accumulator registers); ~50 KB LDS and <= 168 VGPRs so that three workgroups share a CU and one's staging
-// / barrier phases overlap the others' MFMAs.  One k-step = 32 channels of one tap: 16 fragment pairs x
-// NSPLIT MFMAs per wave, ONE barrier per k-step: the B tile is double-buffered in LDS (step it+1's tile is
-// written right after the barrier that ends step it-1, its global load having been issued a whole step
-// earlier), the A tile (128 + halo rows) is staged once per 32-channel chunk and shared by all taps (tap t
-// reads it shifted by t rows), its successor prefetched into registers during the chunk's last tap.
-// LDS image (both operands): row r = 128 B = 8 slots of 16 B (slots 0-3: hi k 0-7 .. 24-31, slots 4-7: lo),
-// physical slot = slot ^ ((r >> 1) & 7): the 16 rows touched by one ds_read_b128 lane group land on 16
-// distinct 16-B bank slots (conflict-free), writes are 16 B per lane.
-// MFMA operands: lane l supplies A[i = l&15][k = 8*(l>>4) .. +7] and B[k = 8*(l>>4) .. +7][j = l&15];
-// C/D: col = l&15, row = 4*(l>>4) + reg (same as the fp32 kernels, so the epilogue is shared).
-// grid.x walks the N tiles (fastest) so that the workgroups resident on one XCD (block id % 8) keep re-reading
-// the same weight panel from that XCD's L2.
+// Plain bf16 misses the 1e-3 mel tolerance by 10x, so the parity mode splits every operand
+// x = hi + lo (hi = bf16(x), lo = bf16(x - hi), ~16 mantissa bits) and issues three MFMAs per fragment pair,
+// lo*hi + hi*lo + hi*hi, accumulating in fp32 (NSPLIT = 3).  NSPLIT = 1 is plain bf16.
+//   * weights are split once at load time into the exact LDS image: [Npad][chunk][tap][hi 32 | lo 32] (k-step order, 128 B
+//     per (n, tap, chunk)); activations travel as "planes" in the same image (common.h), written by their producer.
+//   * LDS image (both operands): row r = 128 B = 8 slots of 16 B (slots 0-3: hi k 0-7 .. 24-31, slots 4-7: lo), physical
+//     slot = slot ^ ((r >> 1) & 7); with the lane -> row permutation rperm (common.h) every ds_read_b128 lane group lands on
+//     16 distinct 16-B bank slots for every row offset (conv tap).
+//   * MFMA operands: lane l supplies A[i = l&15][k = 8*(l>>4) .. +7] and B[k = 8*(l>>4) .. +7][j = l&15];
+//     C/D: col = l&15, row = 4*(l>>4) + reg.
 #pragma once
 #include "common.h"
 
@@ -42,9 +31,7 @@ __device__ __forceinline__ void dma_barrier() {
 #ifndef FS2_SETPRIO
 #define FS2_SETPRIO 1
 #endif
-constexpr int kB16BM = 128, kB16BN = 128;     // BM is a template parameter of the kernels: 128, or 64 for small grids
-template <int BM> constexpr int b16_arows() { return BM + kMaxHalo; }
-template <int BM> constexpr size_t b16_lds() { return (size_t)b16_arows<BM>() * 128 + 2 * (size_t)kB16BN * 128; }   // A + double-buffered B
+constexpr int kB16BN = 128;     // output columns per workgroup tile
 
 struct SplitPair { uint4 hi, lo; };
 
@@ -66,338 +53,46 @@ __device__ __forceinline__ SplitPair split8(const float4& p, const float4& q) {
 
 __device__ __forceinline__ int swz(int row, int slot) { return (row << 7) + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-// Channel order inside a 32-channel chunk of the bf16 images: the 16-byte slot g (k-group of lane-group g) holds
-// channels {4g..4g+3} and {16+4g..16+4g+3}.  Any permutation is legal as long as A and B agree (the MFMA sums over
-// k); this one lets a lane fetch its 8 A values as two 16-byte pieces at fp32 slots g and 4+g of a row that is kept
-// in natural fp32 order in LDS (gemm_glds_bf16), the same conflict-free slot pattern as the split hi/lo image.
+// Channel order inside a 32-channel chunk of the bf16 images: the 16-byte slot g (k-group of lane-group g) holds channels
+// {4g..4g+3} and {16+4g..16+4g+3}.  Any permutation is legal as long as A and B agree (the MFMA sums over k); with this one a
+// producer that holds 4 consecutive channels writes 8 contiguous bytes of the hi half and 8 of the lo half (store_planes4).
 __device__ __host__ __forceinline__ int kperm(int p) { const int slot = p >> 3, j = p & 7; return (j < 4) ? 4 * slot + j : 16 + 4 * slot + (j - 4); }
 
-template <int NSPLIT, int BM>
-__global__ __launch_bounds__(256, 3) void gemm_tile_bf16(GemmArgs a) {
-    constexpr int MT = BM / 32;          // 16-row MFMA tiles per wave (wave tile = BM/2 x 64)
-    extern __shared__ __attribute__((aligned(16))) char smem_b[];
-    char* As = smem_b;
-    char* Bs0 = smem_b + b16_arows<BM>() * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * kB16BN, m0 = blockIdx.y * BM;
-    if (a.Rp != nullptr && m0 >= ((*a.Rp + 127) & ~127)) return;      // device-driven layout: tile beyond the rows in use
-    const int P = (a.ktaps - 1) >> 1;
-    const int lr = lane & 15, lg = lane >> 4;
-    const int lp = rperm(lr);            // tile row / column this lane feeds to the MFMA (conflict-free LDS reads, common.h)
-    const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
-
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nchunks = a.Cpad / 32;
-    const int niter = nchunks * a.ktaps;
-    const int a_items = (BM + 2 * P) * 4;     // (row, k-group of 8) pairs of the A tile
-    // Staging registers are named scalars (an indexed array of float4 here ends up in scratch memory).
-    float4 ap0, aq0, ap1, aq1, ap2, aq2;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-#define FS2_GLOAD_A1(i, P_, Q_)                                                                   \
-    {                                                                                             \
-        const int idx = tid + (i) * 256;                                                          \
-        const int r = idx >> 2, g = idx & 3;                                                      \
-        const int row = m0 - P + r, c = ch_ * 32 + g * 4;            /* kperm: {4g..} and {16+4g..} */ \
-        P_ = z4; Q_ = z4;                                                                         \
-        if (idx < a_items && row >= 0 && row < a.R) {                                             \
-            const float* src = a.X + (size_t)row * a.ldx + c;                                     \
-            if (c < a.C) P_ = *reinterpret_cast<const float4*>(src);                              \
-            if (c + 16 < a.C) Q_ = *reinterpret_cast<const float4*>(src + 16);                    \
-        }                                                                                         \
-    }
-#define FS2_GLOAD_A(chunk_) { const int ch_ = (chunk_); FS2_GLOAD_A1(0, ap0, aq0) FS2_GLOAD_A1(1, ap1, aq1) FS2_GLOAD_A1(2, ap2, aq2) }
-#define FS2_STORE_A1(i, P_, Q_)                                                                   \
-    {                                                                                             \
-        const int idx = tid + (i) * 256;                                                          \
-        if (idx < a_items) {                                                                      \
-            const int r = idx >> 2, g = idx & 3;                                                  \
-            const SplitPair sp = split8(P_, Q_);                                                  \
-            *reinterpret_cast<uint4*>(As + swz(r, g)) = sp.hi;                                    \
-            *reinterpret_cast<uint4*>(As + swz(r, 4 + g)) = sp.lo;                                \
-        }                                                                                         \
-    }
-#define FS2_STORE_A() { FS2_STORE_A1(0, ap0, aq0) FS2_STORE_A1(1, ap1, aq1) FS2_STORE_A1(2, ap2, aq2) }
-
-    // B tiles go global -> LDS by DMA (no staging registers, no ds_write): wave w issues 1-KB instructions w, w+4, ...;
-    // lane j of an instruction fills (row 8q + (j>>3), physical slot j&7), i.e. fetches the logical slot (j&7)^swizzle.
-    const int jrow = lane >> 3, jslot = lane & 7;
-    // rows wave*8 + jrow + 32u, u = 0..3: the swizzle term ((n >> 1) & 7) does not depend on u, so one pointer + a
-    // uniform stride addresses all four instructions
-    const int nb = wave * 8 + jrow;
-    const __bf16* wlane0 = Wb + ((size_t)(n0 + nb) * niter) * 64 + (jslot ^ ((nb >> 1) & 7)) * 8;
-    const size_t wustride = (size_t)32 * niter * 64;
-#define FS2_DMA_B(it_, buf_)                                                                                      \
-    {                                                                                                             \
-        char* bb_ = Bs0 + (buf_) * (kB16BN * 128);                                                                \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                             \
-            __builtin_amdgcn_global_load_lds(wlane0 + u * wustride + (size_t)(it_) * 64, (lds_void_t*)(bb_ + (wave + u * 4) * 1024), 16, 0, 0); \
-    }
-    // prologue: A(chunk 0) and B(0) staged
-    FS2_GLOAD_A(0)
-    FS2_DMA_B(0, 0)
-    FS2_STORE_A()
-    int it = 0;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        for (int tap = 0; tap < a.ktaps; ++tap, ++it) {     // no integer division on the critical path
-            const bool last_tap = (tap == a.ktaps - 1) && (chunk + 1 < nchunks);
-            dma_barrier();     // DMA of B(it) landed, A(chunk) visible; step it-1 is finished
-            if (it + 1 < niter) FS2_DMA_B(it + 1, (it + 1) & 1)      // buffer last read in step it-1
-            if (last_tap) FS2_GLOAD_A(chunk + 1)       // lands while this step's MFMAs run
-            const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
-            bf16x8_t ah[MT], al[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int r = wm * (BM / 2) + mt * 16 + lp + tap;
-                ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
-                if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
-            }
-            if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);     // favour the wave that is feeding the matrix pipe
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n = wn * 64 + nt * 16 + lp;
-                const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
-                bf16x8_t bl;
-                if (NSPLIT == 3) bl = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
-                // consecutive MFMAs hit different accumulators (dependency distance MT)
-                if (NSPLIT == 3) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
-            }
-            if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
-            if (last_tap) {
-                __syncthreads();   // all waves finished reading this chunk's A tile
-                FS2_STORE_A()
-            }
-        }
-    }
-#undef FS2_DMA_B
-#undef FS2_GLOAD_A1
-#undef FS2_GLOAD_A
-#undef FS2_STORE_A1
-#undef FS2_STORE_A
-    // epilogue (elementwise): bias, residual, activation, gap rows -> 0
-    tile_epilogue_64x64<MT, true>(a, acc, m0 + wm * (BM / 2), n0 + wn * 64, lr, lg, a.relu_pre != 0);
-}
-
-// Fused QKV epilogue: the 128 x 128 fp32 tile (+bias) goes through LDS once and leaves as the split-bf16 attention
-// operands, 16 bytes per store: Q|K columns row-major (8 consecutive columns of one row per lane), V columns
-// transposed (8 consecutive rows of one column per lane -> V^T [D][Rvt], key index contiguous).  Rows that are gaps
-// or beyond R are written as zeros (P = 0 times a non-finite V would poison the P.V sum).
+// V part of the fused QKV epilogue: the BM x 128 fp32 tile (+bias, staged in LDS by the GEMM) leaves as V^T hi/lo planes
+// [D][Rvt], 8 consecutive keys of one channel per 16-byte store (key index contiguous: what the P.V MFMA wants as B operand).
+// Rows that are gaps or beyond R are written as zeros (P = 0 times a non-finite V would poison the P.V sum).
 constexpr int kQkvLd = kB16BN + 4;      // fp32 tile row stride in LDS (floats)
-// second half of the fused QKV epilogue: fp32 tile (bias already added) in LDS -> split-bf16 attention operands in HBM
 template <int BM>
-__device__ __forceinline__ void qkv_tile_store(const GemmArgs& a, const float* tile, int m0, int n0, int tid);
-
-template <int BM>
-__device__ __forceinline__ void qkv_split_epilogue(const GemmArgs& a, f32x4 (&acc)[BM / 32][4], float* tile, int m0, int n0, int wm, int wn,
-                                                   int lr, int lg, int tid) {
-    constexpr int MT = BM / 32;
-    const float* __restrict__ biasp = a.bias;
-    __syncthreads();                      // the operand buffers are dead: reuse them for the output tile
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int cl = wn * 64 + nt * 16 + rperm(lr);
-        const float bv = (biasp && n0 + cl < a.N) ? biasp[n0 + cl] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tile[(wm * (BM / 2) + mt * 16 + rperm(lg * 4 + r)) * kQkvLd + cl] = acc[mt][nt][r] + bv;
-    }
-    __syncthreads();
-    qkv_tile_store<BM>(a, tile, m0, n0, tid);
-}
-
-template <int BM>
-__device__ __forceinline__ void qkv_tile_store(const GemmArgs& a, const float* tile, int m0, int n0, int tid) {
+__device__ __forceinline__ void vt_tile_store(const GemmArgs& a, const float* tile, int m0, int n0, int tid) {
     const int* __restrict__ rpos = a.row_pos;
     const int D = a.att_D;
-    __bf16* qkh = reinterpret_cast<__bf16*>(a.qk_hi);
-    __bf16* qkl = reinterpret_cast<__bf16*>(a.qk_lo);
     __bf16* vth = reinterpret_cast<__bf16*>(a.vt_hi);
     __bf16* vtl = reinterpret_cast<__bf16*>(a.vt_lo);
-    if (n0 < 2 * D) {                     // Q | K tile (tiles never straddle 2D: D is a multiple of 128)
-        const float sc = (n0 < D) ? a.q_scale : 1.f;
 #pragma unroll
-        for (int u = 0; u < BM / 16; ++u) {
-            const int idx = tid + u * 256;
-            const int r = idx >> 4, c = (idx & 15) * 8;
-            const int row = m0 + r;
-            if (row >= a.Rvt) continue;
-            const bool ok = row < a.R && (rpos == nullptr || rpos[row] >= 0);
-            const float* t = tile + r * kQkvLd + c;
-            float4 p = *reinterpret_cast<const float4*>(t), q = *reinterpret_cast<const float4*>(t + 4);
-            const float f = ok ? sc : 0.f;
-            p.x *= f; p.y *= f; p.z *= f; p.w *= f; q.x *= f; q.y *= f; q.z *= f; q.w *= f;
-            const SplitPair sp = split8(p, q);
-            const size_t off = (size_t)row * 2 * D + n0 + c;
-            *reinterpret_cast<uint4*>(qkh + off) = sp.hi;
-            *reinterpret_cast<uint4*>(qkl + off) = sp.lo;
+    for (int u = 0; u < BM / 16; ++u) {
+        const int idx = tid + u * 256;
+        // column c, rows 8j .. 8j+7 of the tile; 4 consecutive lanes share a column (64-byte V^T segments),
+        // consecutive lane quads take consecutive columns (different LDS banks)
+        const int c = (idx >> 2) & 127, j = ((idx >> 9) << 2) | (idx & 3);
+        const int row = m0 + 8 * j;
+        if (row >= a.Rvt) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int rr = row + e;
+            const bool ok = rr < a.R && (rpos == nullptr || rpos[rr] >= 0);
+            v[e] = ok ? tile[(8 * j + e) * kQkvLd + c] : 0.f;
         }
-    } else {                              // V tile -> V^T
-#pragma unroll
-        for (int u = 0; u < BM / 16; ++u) {
-            const int idx = tid + u * 256;
-            // column c, rows 8j .. 8j+7 of the tile; 4 consecutive lanes share a column (64-byte V^T segments),
-            // consecutive lane quads take consecutive columns (different LDS banks)
-            const int c = (idx >> 2) & 127, j = ((idx >> 9) << 2) | (idx & 3);
-            const int row = m0 + 8 * j;
-            if (row >= a.Rvt) continue;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int rr = row + e;
-                const bool ok = rr < a.R && (rpos == nullptr || rpos[rr] >= 0);
-                v[e] = ok ? tile[(8 * j + e) * kQkvLd + c] : 0.f;
-            }
-            const SplitPair sp = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
-            const size_t off = (size_t)(n0 - 2 * D + c) * a.Rvt + row;
-            *reinterpret_cast<uint4*>(vth + off) = sp.hi;
-            *reinterpret_cast<uint4*>(vtl + off) = sp.lo;
-        }
+        const SplitPair sp = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+        const size_t off = (size_t)(n0 - 2 * D + c) * a.Rvt + row;
+        *reinterpret_cast<uint4*>(vth + off) = sp.hi;
+        *reinterpret_cast<uint4*>(vtl + off) = sp.lo;
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// gemm_glds_bf16: same tile, same math, staged with LDS-DMA (global_load_lds, 16 B per lane, lane j -> base + 16 j;
-// semantics verified by tools/probes/glds_probe.hip).  Nothing is staged through registers, so the kernel fits three
-// workgroups per CU (conv form: 50 KB LDS, <= 168 VGPRs) and one's barrier / DMA phases hide under the others' MFMAs.
-//   * A tile: fp32, natural channel order, row = 128 B, slots XOR-swizzled through the per-lane SOURCE address (the
-//     DMA destination is lane-linear); split into hi/lo bf16 in registers when the MFMA fragment is read
-//     (two ds_read_b128 at slots g and 4+g -> kperm order).  Rows outside [0,R) and channels >= C are fetched from a
-//     16-byte zero constant instead of being predicated (a masked DMA lane would leave stale LDS bytes).
-//   * B tile: the split-bf16 weight image, double-buffered; step it+1's tile is requested right after the barrier
-//     that ends step it-1 and is complete at the next barrier (hipcc drains LDS-DMA at __syncthreads()).
-//   * K1 (ktaps == 1): the A tile changes every step, so it is double-buffered too (68 KB LDS, two workgroups/CU);
-//     conv form: one A buffer, refilled behind an extra barrier once per 32-channel chunk (every ktaps steps).
-__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // DMA source for out-of-range pieces
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // LDS-DMA source for out-of-range pieces (a masked lane would leave stale LDS bytes)
 
-template <bool K1, int BM>
-constexpr size_t glds_lds_bytes() {
-    const size_t ops = (size_t)(K1 ? 2 : 1) * b16_arows<BM>() * 128 + 2 * (size_t)kB16BN * 128;
-    const size_t out = K1 ? (size_t)BM * (kB16BN + 4) * 4 : 0;       // fused QKV epilogue stages the fp32 tile here
-    return ops > out ? ops : out;
-}
-
-template <int NSPLIT, bool K1, int BM>
-__global__ __launch_bounds__(256, K1 ? 2 : 3) void gemm_glds_bf16(GemmArgs a) {
-    constexpr int MT = BM / 32;
-    constexpr int kB16ARows = b16_arows<BM>();
-    extern __shared__ __attribute__((aligned(16))) char smem_g[];
-    char* As0 = smem_g;
-    char* Bs0 = smem_g + (K1 ? 2 : 1) * kB16ARows * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nN = (a.N + kB16BN - 1) / kB16BN;
-    const int tn = blockIdx.x % nN, tm = blockIdx.x / nN;
-    const int n0 = tn * kB16BN, m0 = tm * BM;
-    if (a.Rp != nullptr && m0 >= ((*a.Rp + 127) & ~127)) return;      // device-driven layout: tile beyond the rows in use
-    const int P = (a.ktaps - 1) >> 1;
-    const int lr = lane & 15, lg = lane >> 4;
-    const int lp = rperm(lr);            // tile row / column this lane feeds to the MFMA (conflict-free LDS reads, common.h)
-    const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
-
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nchunks = a.Cpad / 32;
-    const int niter = nchunks * a.ktaps;
-    const int a_instr = (BM + 2 * P + 7) >> 3;       // 1-KB DMA instructions (8 rows each) of one A tile
-    const int jrow = lane >> 3, jslot = lane & 7;        // this lane's (row, physical slot) inside a DMA instruction
-
-    // A tile of 32-channel chunk `ch` -> buffer `buf`; wave w issues instructions w, w+4, ...
-    auto dma_A = [&](int ch, int buf) {
-        char* base = As0 + buf * (kB16ARows * 128);
-        for (int q = wave; q < a_instr; q += 4) {
-            const int r = q * 8 + jrow;                              // tile row
-            const int s = jslot ^ ((r >> 1) & 7);                    // logical slot (4 floats) stored at this position
-            const int row = m0 - P + r, c = ch * 32 + s * 4;
-            const bool ok = row >= 0 && row < a.R && c < a.C;
-            const float* src = ok ? a.X + (size_t)row * a.ldx + c : g_zero16;
-            __builtin_amdgcn_global_load_lds(src, (lds_void_t*)(base + q * 1024), 16, 0, 0);
-        }
-    };
-    auto dma_B = [&](int it, int buf) {
-        char* base = Bs0 + buf * (kB16BN * 128);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int q = wave + u * 4;                              // 16 instructions per tile
-            const int n = q * 8 + jrow;
-            const int s = jslot ^ ((n >> 1) & 7);
-            const __bf16* src = Wb + ((size_t)(n0 + n) * niter + it) * 64 + s * 8;
-            __builtin_amdgcn_global_load_lds(src, (lds_void_t*)(base + q * 1024), 16, 0, 0);
-        }
-    };
-
-    dma_A(0, 0);
-    dma_B(0, 0);
-    int it = 0;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        for (int tap = 0; tap < a.ktaps; ++tap, ++it) {
-            dma_barrier();     // DMA of step `it` landed; every wave is done with step it-1
-            if (it + 1 < niter) {
-                dma_B(it + 1, (it + 1) & 1);
-                if (K1) dma_A(it + 1, (it + 1) & 1);
-            }
-            const char* As = As0 + (K1 ? (it & 1) : 0) * (kB16ARows * 128);
-            const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
-            bf16x8_t ah[MT], al[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int r = wm * (BM / 2) + mt * 16 + lp + tap;
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(As + swz(r, lg));
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(As + swz(r, 4 + lg));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const __bf16 h0 = (__bf16)x0[j], h1 = (__bf16)x1[j];
-                    ah[mt][j] = h0;
-                    ah[mt][4 + j] = h1;
-                    if (NSPLIT == 3) {
-                        al[mt][j] = (__bf16)(x0[j] - (float)h0);
-                        al[mt][4 + j] = (__bf16)(x1[j] - (float)h1);
-                    }
-                }
-            }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n = wn * 64 + nt * 16 + lp;
-                const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
-                bf16x8_t bl;
-                if (NSPLIT == 3) bl = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
-                if (NSPLIT == 3) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
-            }
-            if (!K1 && tap == a.ktaps - 1 && chunk + 1 < nchunks) {
-                __syncthreads();              // every wave has read its last fragments of this chunk's A tile
-                dma_A(chunk + 1, 0);
-            }
-        }
-    }
-    if (K1 && a.qk_hi != nullptr) qkv_split_epilogue<BM>(a, acc, reinterpret_cast<float*>(smem_g), m0, n0, wm, wn, lr, lg, tid);
-    else tile_epilogue_64x64<MT, true>(a, acc, m0 + wm * (BM / 2), n0 + wn * 64, lr, lg, a.relu_pre != 0);
-}
-
-// Row epilogue as its own HBM-bound kernel (used after gemm_tile_bf16 when the op ends in a LayerNorm, a
+// Row epilogue as its own HBM-bound kernel (used after gemm_pl_bf16 when the op ends in a LayerNorm, a
 // positional-encoding add or the scalar head): in place on Y [R, N], one wavefront per row, N <= 1024.
 //   v = LN(y) (if ln_g) -> act_post -> v*x_scale + alpha*pe[pos] -> store; dot_out[row] = v . dot_w + dot_b
 // With Yp the result is also written as split-bf16 planes, the A operand of the next GEMM (gemm_planes.h).

@@ -1,7 +1,7 @@
 // gemm_pl_bf16: the split-bf16 conv-as-GEMM with BOTH operands streamed by LDS-DMA and no conversion work in the loop.
 //
-// gemm_tile_bf16 / gemm_glds_bf16 (gemm_bf16.h) read fp32 activations and split them into bf16 hi/lo in the kernel;
-// PMC showed what that costs: 0.9 (9-tap conv) to 8 (k = 1 GEMMs) VALU instructions per MFMA, i.e. the k = 1 GEMMs
+// The first generation of these kernels read fp32 activations and split them into bf16 hi/lo inside the loop; PMC showed what
+// that costs: 0.9 (9-tap conv, split once per chunk) to 8 (k = 1 GEMMs) VALU instructions per MFMA, i.e. the k = 1 GEMMs
 // were VALU-bound at ~25 % of the MFMA rate.  Here the PRODUCER of an activation writes it once as "planes",
 //     Xp[row][chunk] = 128 B = [hi: 32 bf16 in kperm order | lo: 32 bf16],      (common.h: plane_byte / store_planes4)
 // which is byte-for-byte the LDS row image of the MFMA loop, so the A tile is a plain 1-KB-per-instruction DMA
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
                     *reinterpret_cast<f32x4*>(tile + (wm * (BM / 2) + mt * 16 + rperm(lg * 4 + r)) * kQkvLd + wn * 64 + 4 * lr) =
                         f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
             __syncthreads();
-            qkv_tile_store<BM>(a, tile, m0, n0, tid);
+            vt_tile_store<BM>(a, tile, m0, n0, tid);
             return;
         }
     }

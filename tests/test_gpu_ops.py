@@ -94,24 +94,12 @@ def test_conv_gemm_fp32_row_complete_kernel(case, monkeypatch):
     test_conv_gemm(case, "fp32")
 
 
-@pytest.mark.parametrize("bm", ["64", "128"])
-@pytest.mark.parametrize("gemm", ["regs", "glds"])
-@pytest.mark.parametrize("case", CASES[:6], ids=[c[-1] for c in CASES[:6]])
-def test_conv_gemm_bf16x3_kernel_variants(case, gemm, bm, monkeypatch):
-    """Both split-bf16 GEMM kernels (register-staged A / all LDS-DMA) at both tile heights (FS2_GEMM, FS2_BM pin the
-    choice the runtime otherwise makes per shape)."""
-    monkeypatch.setenv("FS2_GEMM", gemm)
-    monkeypatch.setenv("FS2_BM", bm)
-    test_conv_gemm(case, "bf16x3")
-
-
 @pytest.mark.parametrize("bm", ["64", "128", "256"])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("case", CASES, ids=[c[-1] for c in CASES])
 def test_conv_gemm_planes_kernel_tile_heights(case, precision, bm, monkeypatch):
     """The default bf16 path (activations as split-bf16 planes, both operands by LDS-DMA: gemm_planes.h) at every
     tile height (256 rows exists for the conv form only; k = 1 GEMMs fall back to their own choice)."""
-    monkeypatch.delenv("FS2_GEMM", raising=False)
     monkeypatch.setenv("FS2_BM", bm)
     test_conv_gemm(case, precision)
 
@@ -124,7 +112,6 @@ ROW8_CASES = [c for c in CASES if c[3] == 1 and c[7] is not None and c[2] in (25
 def test_conv_gemm_row_complete_ln_fused_kernel(case, precision, monkeypatch):
     """gemm_row8_bf16 (128 rows x all N columns per workgroup, LayerNorm in the epilogue) is chosen by size in the
     model path; force it here on the small op cases (several row tiles, ragged last tile, gap rows)."""
-    monkeypatch.delenv("FS2_GEMM", raising=False)
     monkeypatch.setenv("FS2_ROW8", "1")
     test_conv_gemm(case, precision)
 
