@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("FS2_PRECISION", "bf16x3"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-kernels", action="store_true", help="print the per-kernel hipEvent table to stderr")
+    ap.add_argument("--graph", action="store_true", help="replay the forward as one captured HIP graph (single GPU; the launch-bound small configs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,7 +119,12 @@ def main():
     B = xs.shape[0]
     index = list(range(rank * B, (rank + 1) * B))
 
+    graph_run = None
+
     def step():
+        if graph_run is not None:
+            mel_, ol_, _ = graph_run(xs)
+            return mel_, ol_
         if not use_dist:
             # nothing on the host waits for the GPU: the frame layout is built on the device (fs2_decode's device-driven
             # mode); the very first call is synchronous and teaches the capacity predictor the frames-per-phoneme ratio
@@ -128,19 +134,26 @@ def main():
         return gather_packed(packed, olens, index, B * world)
 
     with torch.no_grad():
+        mel, olens_all = step()                      # first call: synchronous, builds the handle
+        if args.graph and not use_dist and not args.profile_kernels:
+            graph_run = model.capture_graph(xs, il)
         for _ in range(max(args.warmup, 1)):
             mel, olens_all = step()
-        if not use_dist and not args.profile_kernels:
+        if not use_dist and not args.profile_kernels and graph_run is None:
             assert model.async_ok(), "capacities of the asynchronous path were exceeded during warm-up"
         local_frames = int(model.last_olens.sum())
         total_frames = int(olens_all.sum())
         # find the dominant launch site with one fully bracketed (untimed) step, then bracket only that site
         # inside the timed region so that hipEvent records do not perturb the measurement
         model.set_profiling(True)
-        step()
+        if graph_run is not None:
+            model.inference_batch(xs, il)        # a graph replay has no per-launch events: scout with an eager step
+        else:
+            step()
         torch.cuda.synchronize()
         scout = {}
-        for name, ms, fl, by in model.get_profile():
+        scout_prof = model.get_profile()
+        for name, ms, fl, by in scout_prof:
             scout[name] = scout.get(name, 0.0) + ms
         dom_site = max(scout.items(), key=lambda kv: kv[1])[0]
         kernel_ms_per_step = sum(scout.values())
@@ -155,9 +168,11 @@ def main():
         if use_dist:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if not use_dist and not args.profile_kernels:
+        if graph_run is not None:
+            assert int(graph_run(xs)[2].cpu()[2]) == 0, "capacities captured with the graph were exceeded"
+        elif not use_dist and not args.profile_kernels:
             assert model.async_ok(), "capacities of the asynchronous path were exceeded in the timed region"
-        prof = model.get_profile()
+        prof = model.get_profile() if graph_run is None else scout_prof      # (graph mode: the roofline comes from the eager scouting step)
         model.set_profiling(False)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -217,7 +232,8 @@ def main():
                                    "duration bias ln(1+7.87)" % (args.workload, B),
                        "utterances_per_gpu": B, "valid_frames_per_step": total_frames, "phonemes_per_gpu": ntok,
                        "algorithmic_gflop_per_step_per_gpu": round(sum(O.flops(int(t), int(l)) for t, l in zip(il, model.last_olens)) / 1e9, 1),
-                       "parallelism": "utterance-sharded x%d, all-gather(mels) over RCCL" % world if world > 1 else "single GPU"},
+                       "parallelism": "utterance-sharded x%d, all-gather(mels) over RCCL" % world if world > 1 else "single GPU",
+                       "launch": "HIP graph replay" if graph_run is not None else ("eager, host-driven layout" if (use_dist or args.profile_kernels) else "eager, device-driven layout (no host sync)")},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

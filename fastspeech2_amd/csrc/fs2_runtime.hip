@@ -89,6 +89,7 @@ struct fs2_handle {
     int* o32 = nullptr;        // device frame counts (int32) left by the duration scan
     int enc_B = 0, enc_Tmax = 0, enc_compat = 0;
     void* enc_ws = nullptr;
+    std::vector<void*> graph_pinned;   // host staging owned by captured graphs (see upload_layout)
     // profiling
     bool prof = false;
     std::string prof_filter;      // when non-empty only launches with exactly this name are bracketed
@@ -443,7 +444,19 @@ int upload_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, D
     host.insert(host.end(), L.klen.begin(), L.klen.end());
     host.insert(host.end(), L.vlen.begin(), L.vlen.end());
     for (auto& w : L.work) { host.push_back(w.x); host.push_back(w.y); }
-    HIP_TRY(h, hipMemcpyAsync(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    const void* src = host.data();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive) {
+        // Inside a HIP-graph capture the copy becomes a memcpy node that reads its source at every replay: give it pinned host
+        // memory that lives as long as the handle (a pageable std::vector is neither capturable nor alive at replay time).
+        void* pin = nullptr;
+        if (!h) return fail(h, FS2_ERR_STATE, "layout upload inside a graph capture needs a model handle");
+        HIP_TRY(h, hipHostMalloc(&pin, host.size() * sizeof(int), hipHostMallocDefault));
+        memcpy(pin, host.data(), host.size() * sizeof(int));
+        h->graph_pinned.push_back(pin);
+        src = pin;
+    }
+    HIP_TRY(h, hipMemcpyAsync(dev, src, host.size() * sizeof(int), hipMemcpyHostToDevice, s));
     D.start = dev; D.len = dev + L.B; D.klen = dev + 2 * L.B; D.vlen = dev + 3 * L.B;
     D.work = reinterpret_cast<int2*>(dev + 4 * L.B);
     int* rest = dev + 4 * L.B + 2 * L.work.size();
@@ -836,6 +849,7 @@ void fs2_destroy(fs2_handle* h) {
     hipSetDevice(h->cfg.device);
     free_weights(h);
     for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (void* p : h->graph_pinned) hipHostFree(p);
     delete h;
 }
 

@@ -519,6 +519,8 @@ class FeedForwardTransformer(nn.Module):
             total = int(float(il.sum()) * self._frames_per_token[0] * 1.15) + 64 * int(il.numel())
             Lcap = -(-int(float(il.max()) * self._frames_per_token[1] * 1.25 + 64) // 32) * 32
             r = self._run(xs, il, is_inference=True, compat=False, want=("after",), d_override=d_override, capacity=(total, Lcap))
+            if torch.cuda.is_current_stream_capturing():     # graph capture: no host-side bookkeeping inside the graph
+                return r["after"], r["olens"]
             # frame counts and flags travel to pinned host memory behind the kernels; an event tells when they are there
             B = int(il.numel())
             pin = self._pinned
@@ -534,6 +536,42 @@ class FeedForwardTransformer(nn.Module):
         r = self._run(xs, ilens, is_inference=True, compat=False, want=want, d_override=d_override)
         self._learn_ratio(torch.as_tensor(ilens).detach().to("cpu", torch.int64), r["olens"])
         return (r["after_packed"] if packed else r["after"]), r["olens"]
+
+    def capture_graph(self, xs, ilens, d_override=None):
+        """HIP-graph replay of the whole free-running forward for a fixed batch shape (``xs.shape`` and ``ilens``): the
+        launch-bound small-batch case (one utterance: 85 launches) becomes one graph launch.  Returns ``run(new_xs) ->
+        (mels [B, Lcap, odim], olens_dev, status_dev)``; the tensors are the graph's static outputs (overwritten by the
+        next replay).  ``status_dev[2] != 0`` means the capacities captured with the graph were too small for that input:
+        fall back to ``inference_batch``.  Capacities come from one synchronous run on ``xs`` (x 1.5 head-room)."""
+        with torch.no_grad():
+            il = torch.as_tensor(ilens).detach().to("cpu", torch.int64)
+            _, ol = self.inference_batch(xs, il, d_override=d_override)            # builds the handle, learns the sizes
+            total = int(float(ol.sum()) * 1.5) + 64 * int(il.numel())
+            Lcap = -(-int(float(ol.max()) * 1.5 + 64) // 32) * 32
+            static_xs = xs.clone()
+            static_ds = d_override.clone() if d_override is not None else None
+            run_once = lambda: self._run(static_xs, il, is_inference=True, compat=False, want=("after",), d_override=static_ds,
+                                         capacity=(total, Lcap))
+            side = torch.cuda.Stream(device=xs.device)
+            side.wait_stream(torch.cuda.current_stream(xs.device))
+            with torch.cuda.stream(side):
+                run_once()                                                         # warm-up on the capture stream
+            torch.cuda.current_stream(xs.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            # "relaxed": the library pins a small host staging block for the token layout while capturing (hipHostMalloc)
+            with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+                r = run_once()
+        after, olens_dev, status = r["after"], r["olens"], r["status"]
+
+        def run(new_xs, new_ds=None):
+            static_xs.copy_(new_xs)
+            if static_ds is not None and new_ds is not None:
+                static_ds.copy_(new_ds)
+            graph.replay()
+            return after, olens_dev, status
+
+        run.graph = graph
+        return run
 
     # frames-per-phoneme statistics for the capacities of the asynchronous path: (batch mean, max over utterances)
     _frames_per_token = None

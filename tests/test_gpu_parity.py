@@ -236,6 +236,33 @@ def test_device_driven_layout_matches_host_driven(env):
             model.precision = "fp32"
 
 
+def test_hip_graph_replay_of_the_forward(env):
+    """The sync-free forward (device-driven layout) captured once as a HIP graph and replayed: same mels as the eager
+    call, for the captured ids and for new ids of the same lengths."""
+    model = env[0]
+    from fastspeech2_amd.synthetic import make_batch
+    b = make_batch("c3", B=4)
+    xs, il, ds = b["xs"].cuda(), b["ilens"], b["ds"].cuda()
+    model.precision = "bf16x3"
+    try:
+        with torch.no_grad():
+            run = model.capture_graph(xs, il, d_override=ds)
+            ref, ol = model.inference_batch(xs, il, d_override=ds)
+            mel, ol_dev, status = run(xs)
+            assert int(status.cpu()[2]) == 0 and torch.equal(ol_dev.cpu(), ol)
+            assert torch.equal(mel[:, : ref.shape[1]], ref)
+            xs2 = xs.clone()
+            for i in range(xs.shape[0]):
+                T = int(il[i])
+                xs2[i, :T] = xs[i, :T].flip(0)                 # other phonemes, same lengths
+            ref2, _ = model.inference_batch(xs2, il, d_override=ds)
+            mel2, _, status = run(xs2)
+            assert int(status.cpu()[2]) == 0
+            assert torch.equal(mel2[:, : ref2.shape[1]], ref2) and not torch.equal(ref2, ref)
+    finally:
+        model.precision = "fp32"
+
+
 def test_reference_smoke_shape(env):
     """Counterpart of the reference's only test (tests/test_fastspeech2.py:7-20): B=2, T=L=100, all ones,
     through forward(); here in eval mode, asserting what the reference merely runs."""
