@@ -90,8 +90,33 @@ struct AttnB16Args {
     int D; int mask_q;
 };
 
+// max / sum over the four lanes {l, l^16, l^32, l^48} (the four 8-key groups of one query column) with the gfx950 row swaps:
+// v_permlane16_swap / v_permlane32_swap with both operands = x leave (x[own row pair half], x[other half]) in the two results,
+// so one VALU op finishes each butterfly step - no ds_bpermute round trip through the LDS crossbar on the softmax chain.
+__device__ __forceinline__ float quad_rows_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float quad_rows_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <int DK>
 constexpr size_t attn_b16_lds_bytes() { return (size_t)32 * DK * 4 + (size_t)DK * 128; }
+
+// Phase timing for tools/probes/attn_probe.hip (compiled only with -DFS2_ATT_TIMING): cycles of wave 0 of workgroup (0, 0)
+// accumulated per phase of the tile loop.
+#ifdef FS2_ATT_TIMING
+__device__ long long g_att_phase[8];
+#define FS2_T(i) { const long long t_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_att_phase[i] += t_ - tprev; tprev = t_; }
+#else
+#define FS2_T(i)
+#endif
 
 template <int DK, int NSPLIT>
 __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
@@ -174,9 +199,14 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
         FS2_LOAD_K(0)
         FS2_STORE_K()
     }
+#ifdef FS2_ATT_TIMING
+    long long tprev = __builtin_readcyclecounter();
+#endif
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * 32;
+        FS2_T(5)
         __syncthreads();          // (A) K(kt) visible; every wave is done with P.V(kt-1), so the V^T buffer is free
+        FS2_T(0)
         FS2_LOAD_V(key0)          // in flight during Q.K^T and the softmax
         f32x4 st[2];
         st[0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -184,25 +214,49 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
         {
             const char* krow0 = Ks + (8 * (lr >> 2) + (lr & 3)) * KROW;     // sub-tile 0 row; sub-tile 1 is 4 keys further
             const char* krow1 = krow0 + 4 * KROW;
+            // two k-steps of K fragments per batch: 8 ds_read_b128 issued together (the sched_barrier keeps hipcc from folding them
+            // back into a read -> wait -> MFMA chain on two registers: that paid the LDS latency 24 times per tile), then 12 MFMAs on
+            // four accumulators (even / odd k-step), summed at the end: no MFMA waits for the one just before it
+            f32x4 su[2];
+            su[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            su[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int sh = ((c * 4 + lg) ^ lr) << 4, sl = ((KSL + c * 4 + lg) ^ lr) << 4;
-                const bf16x8_t kh0 = *reinterpret_cast<const bf16x8_t*>(krow0 + sh);
-                const bf16x8_t kh1 = *reinterpret_cast<const bf16x8_t*>(krow1 + sh);
-                if (NSPLIT == 3) {
-                    const bf16x8_t kl0 = *reinterpret_cast<const bf16x8_t*>(krow0 + sl);
-                    const bf16x8_t kl1 = *reinterpret_cast<const bf16x8_t*>(krow1 + sl);
-                    st[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl0, qh[c], st[0], 0, 0, 0);
-                    st[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl1, qh[c], st[1], 0, 0, 0);
-                    st[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0, ql[c], st[0], 0, 0, 0);
-                    st[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1, ql[c], st[1], 0, 0, 0);
+            for (int c2 = 0; c2 < NC; c2 += 2) {
+                bf16x8_t kh0[2], kh1[2], kl0[2], kl1[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = c2 + u;
+                    const int sh = ((c * 4 + lg) ^ lr) << 4, sl = ((KSL + c * 4 + lg) ^ lr) << 4;
+                    kh0[u] = *reinterpret_cast<const bf16x8_t*>(krow0 + sh);
+                    kh1[u] = *reinterpret_cast<const bf16x8_t*>(krow1 + sh);
+                    if (NSPLIT == 3) {
+                        kl0[u] = *reinterpret_cast<const bf16x8_t*>(krow0 + sl);
+                        kl1[u] = *reinterpret_cast<const bf16x8_t*>(krow1 + sl);
+                    }
                 }
-                st[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0, qh[c], st[0], 0, 0, 0);
-                st[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1, qh[c], st[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (NSPLIT == 3) {
+                    st[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl0[0], qh[c2], st[0], 0, 0, 0);
+                    st[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl1[0], qh[c2], st[1], 0, 0, 0);
+                    su[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl0[1], qh[c2 + 1], su[0], 0, 0, 0);
+                    su[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl1[1], qh[c2 + 1], su[1], 0, 0, 0);
+                    st[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0[0], ql[c2], st[0], 0, 0, 0);
+                    st[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1[0], ql[c2], st[1], 0, 0, 0);
+                    su[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0[1], ql[c2 + 1], su[0], 0, 0, 0);
+                    su[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1[1], ql[c2 + 1], su[1], 0, 0, 0);
+                }
+                st[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0[0], qh[c2], st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1[0], qh[c2], st[1], 0, 0, 0);
+                su[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0[1], qh[c2 + 1], su[0], 0, 0, 0);
+                su[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1[1], qh[c2 + 1], su[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            st[0] += su[0];
+            st[1] += su[1];
         }
         // st[t][r] = log2(e) * score of key key0 + 8g + 4t + r for query lr (Q was pre-scaled by log2(e)/sqrt(d_k)),
         // so the softmax runs on v_exp_f32 (2^x) directly.
+        FS2_T(1)
         float p[8];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -216,8 +270,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
             }
         }
         float tmax = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        tmax = quad_rows_max(tmax);
         const float m_new = fmaxf(m_run, tmax);
         float psum = 0.f;
 #pragma unroll
@@ -225,8 +278,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
             p[j] = __builtin_amdgcn_exp2f(p[j] - m_new);
             psum += p[j];
         }
-        psum += __shfl_xor(psum, 16);
-        psum += __shfl_xor(psum, 32);
+        psum = quad_rows_sum(psum);
         if (__any(m_new != m_run)) {       // some row's running max moved: rescale the accumulators (rare after the first tiles)
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 2^(-inf) = 0 on the first tile
             l_run *= alpha;
@@ -246,8 +298,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
             ph[j] = hb;
             pl[j] = (__bf16)(p[j] - (float)hb);
         }
+        FS2_T(2)
         FS2_STORE_V()
         __syncthreads();          // (B) V^T(kt) visible; every wave is done with Q.K^T(kt), so the K buffer is free
+        FS2_T(3)
         if (kt + 1 < ntiles) FS2_LOAD_K(key0 + 32)     // in flight during P.V
         constexpr int PG = (DK > 128) ? 2 : 4;     // n-tiles in flight: independent accumulators between dependent MFMAs
 #pragma unroll
@@ -268,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
 #pragma unroll
             for (int u = 0; u < PG; ++u) o[n4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[u], o[n4 + u], 0, 0, 0);
         }
+        FS2_T(4)
         if (kt + 1 < ntiles) FS2_STORE_K()
     }
 #undef FS2_LOAD_K
