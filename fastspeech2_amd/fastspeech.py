@@ -499,7 +499,20 @@ class FeedForwardTransformer(nn.Module):
 
     def inference(self, x):
         """reference fastspeech.py:339-357: x [T] int64 phoneme ids -> mel [L, odim]."""
-        r = self._run(x.unsqueeze(0), torch.tensor([x.shape[0]]), is_inference=True, want=("after",))
+        xs, il = x.unsqueeze(0), torch.tensor([x.shape[0]])
+        if self._frames_per_token is not None:
+            # device-driven layout inside capacities learnt from earlier utterances: the GPU runs the whole forward without
+            # waiting for the host; the frame count is read once, at the end (it is needed for the shape of the result)
+            total = int(float(il[0]) * self._frames_per_token[1] * 1.25) + 64
+            Lcap = -(-total // 32) * 32
+            r = self._run(xs, il, is_inference=True, want=("after",), capacity=(total, Lcap))
+            st = r["status"].cpu()
+            if int(st[2]) == 0:
+                L = int(st[3])
+                self._learn_ratio(il, torch.tensor([L]))
+                return r["after"][0, :L]
+        r = self._run(xs, il, is_inference=True, want=("after",))
+        self._learn_ratio(il, r["olens"])
         return r["after"][0]
 
     def inference_batch(self, xs, ilens, d_override=None, packed=False, sync=True):

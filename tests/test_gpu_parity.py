@@ -236,6 +236,24 @@ def test_device_driven_layout_matches_host_driven(env):
             model.precision = "fp32"
 
 
+def test_inference_second_call_uses_device_layout(env):
+    """`inference(x)` (reference fastspeech.py:339-357): the first call learns the frames-per-phoneme ratio with the host-driven
+    layout, later calls run sync-free inside capacities and read the frame count once at the end; same mel either way, and an
+    utterance that overflows the learnt capacity falls back transparently."""
+    model = env[0]
+    rs = np.random.RandomState(7)
+    x = torch.from_numpy(rs.randint(1, 68, size=40)).long().cuda()
+    with torch.no_grad():
+        model._frames_per_token = None
+        first = model.inference(x)
+        assert model._frames_per_token is not None
+        second = model.inference(x)
+        assert torch.equal(first, second)
+        model._frames_per_token = (0.01, 0.01)          # absurdly small capacities: must fall back, not fail
+        third = model.inference(x)
+        assert torch.equal(first, third)
+
+
 def test_hip_graph_replay_of_the_forward(env):
     """The sync-free forward (device-driven layout) captured once as a HIP graph and replayed: same mels as the eager
     call, for the captured ids and for new ids of the same lengths."""
