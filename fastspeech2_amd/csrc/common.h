@@ -55,7 +55,6 @@ struct GemmArgs {
     // by the epilogue next to / instead of Y.
     const void* Xp; void* xp_scratch; void* Yp; int yp_chunks;
     const int* Rp;                         // device-driven layout: rows actually used (tiles at or beyond round_up(*Rp, 128) exit at once); nullptr: R
-    int probe;                             // FS2_PROBE (performance experiments only): 1 no A refills, 2 no B refills, 4 no MFMA, 8 no epilogue, 16 XCD-aware tile order
 };
 
 __device__ __forceinline__ float wave16_sum(float v) {

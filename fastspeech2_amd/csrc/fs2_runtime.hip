@@ -178,13 +178,8 @@ hipError_t launch_pl_t(hipStream_t s, const GemmArgs& a) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pl_bf16<NSPLIT, BM, K1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    GemmArgs b = a;
-    const char* pe = getenv("FS2_PROBE");
-    b.probe = pe ? atoi(pe) : 0;
-    int nM = ((a.qk_hi ? a.Rvt : a.R) + BM - 1) / BM;
-    if (b.probe & 16) nM = round_up(nM, 8);
-    dim3 grid((a.N + kB16BN - 1) / kB16BN, nM);
-    hipLaunchKernelGGL((gemm_pl_bf16<NSPLIT, BM, K1>), grid, dim3(256), lds, s, b);
+    dim3 grid((a.N + kB16BN - 1) / kB16BN, ((a.qk_hi ? a.Rvt : a.R) + BM - 1) / BM);
+    hipLaunchKernelGGL((gemm_pl_bf16<NSPLIT, BM, K1>), grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

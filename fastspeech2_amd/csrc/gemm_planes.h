@@ -86,14 +86,9 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     char* Bs0 = smem_p + (K1 ? 2 : 1) * AROWS * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int tn = blockIdx.x, tm = blockIdx.y;
-    if (a.probe & 16) {      // workgroup L runs on XCD L % 8: give one XCD all N tiles of an M tile (A tile fetched into one L2 only)
-        const int L = blockIdx.y * gridDim.x + blockIdx.x, k = L >> 3;
-        tn = k % (int)gridDim.x;
-        tm = (k / (int)gridDim.x) * 8 + (L & 7);
-        if (tm * BM >= (a.qk_hi ? a.Rvt : a.R)) return;
-    }
-    const int n0 = tn * kB16BN, m0 = tm * BM;
+    // grid.x walks the N tiles: workgroup L of a launch runs on XCD L % 8, so with 8 N tiles each XCD keeps ONE 128-column weight
+    // panel in its L2 and streams the A planes past it (measured: giving an XCD all N tiles of an M tile instead changes nothing)
+    const int n0 = blockIdx.x * kB16BN, m0 = blockIdx.y * BM;
     if (a.Rp != nullptr && m0 >= ((*a.Rp + 127) & ~127)) return;      // device-driven layout: tile beyond the rows in use
     const int ktaps = K1 ? 1 : a.ktaps;
     const int P = (ktaps - 1) >> 1;
@@ -164,8 +159,8 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
         for (int tap = 0; tap < ktaps; ++tap, ++it) {
             dma_barrier();     // DMA of step `it` landed; every wave is done with step it-1
             if (it + 1 < niter) {
-                if (!(a.probe & 2)) dma_B(it + 1, (it + 1) & 1);
-                if (K1 && !(a.probe & 1)) dma_A(it + 1, (it + 1) & 1);
+                dma_B(it + 1, (it + 1) & 1);
+                if (K1) dma_A(it + 1, (it + 1) & 1);
             }
             const char* As = As0 + (K1 ? (it & 1) : 0) * (AROWS * 128);
             const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
@@ -177,7 +172,6 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
                 if (NSPLIT == 3) bl[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
             }
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
-            if (!(a.probe & 4))
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int r = wm * (BM / 2) + mt * 16 + lp + tap;
@@ -195,11 +189,10 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
             if (!K1 && tap == ktaps - 1 && chunk + 1 < nchunks) {
                 __syncthreads();              // every wave has read its last fragments of this chunk's A tile
-                if (!(a.probe & 1)) dma_A(chunk + 1, 0);
+                dma_A(chunk + 1, 0);
             }
         }
     }
-    if (a.probe & 8) { if (acc[0][0][0] == 123.456f) a.Y[0] = 1.f; return; }
     if constexpr (K1 && BM <= 128) {
         if (a.qk_hi != nullptr && n0 < 2 * a.att_D) {
             // fused QKV epilogue, Q | K tiles: row-major split-bf16 operands straight from the registers (8 + 8 bytes per
