@@ -102,7 +102,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
-    from fastspeech2_amd.parallel import gather_packed
+    from fastspeech2_amd.parallel import gather_packed, gather_packed_async
     from fastspeech2_amd.synthetic import portable_state_dict, bias_durations, make_batch
 
     hp = default_hparams()
@@ -120,6 +120,8 @@ def main():
     index = list(range(rank * B, (rank + 1) * B))
 
     graph_run = None
+    dist_caps = None
+    index_dev = torch.tensor(index, dtype=torch.int64, device=dev)
 
     def step():
         if graph_run is not None:
@@ -130,13 +132,22 @@ def main():
             # mode); the very first call is synchronous and teaches the capacity predictor the frames-per-phoneme ratio
             # (--profile-kernels uses the host-driven layout so that the per-site FLOP counts are those of the rows in use)
             return model.inference_batch(xs, il, sync=args.profile_kernels)
-        packed, olens = model.inference_batch(xs, il, packed=True)          # valid frames only travel over xGMI
-        return gather_packed(packed, olens, index, B * world)
+        if dist_caps is None:
+            packed, olens = model.inference_batch(xs, il, packed=True)          # valid frames only travel over xGMI
+            return gather_packed(packed, olens, index, B * world)
+        # sync-free: device-driven layout inside capacities agreed between the ranks once, packs of equal capacity all-gathered
+        packed, olens = model.inference_batch(xs, il, packed=True, sync=False, capacity=dist_caps)
+        return gather_packed_async(packed, olens, index_dev, B * world, dist_caps[1])
 
     with torch.no_grad():
         mel, olens_all = step()                      # first call: synchronous, builds the handle
         if args.graph and not use_dist and not args.profile_kernels:
             graph_run = model.capture_graph(xs, il)
+        if use_dist and not args.profile_kernels and not os.environ.get("FS2_DIST_SYNC"):
+            # one exchange outside the timed region: every rank's predicted capacities -> the maximum, used by all
+            caps = torch.tensor(model.predict_capacity(il), dtype=torch.int64, device=dev)
+            dist.all_reduce(caps, op=dist.ReduceOp.MAX)
+            dist_caps = (int(caps[0]), int(caps[1]))
         for _ in range(max(args.warmup, 1)):
             mel, olens_all = step()
         if not use_dist and not args.profile_kernels and graph_run is None:
@@ -168,6 +179,8 @@ def main():
         if use_dist:
             dist.barrier()
         dt = time.perf_counter() - t0
+        if dist_caps is not None:
+            assert model.async_ok(), "capacities of the asynchronous path were exceeded in the timed region"
         if graph_run is not None:
             assert int(graph_run(xs)[2].cpu()[2]) == 0, "capacities captured with the graph were exceeded"
         elif not use_dist and not args.profile_kernels:
@@ -233,7 +246,7 @@ def main():
                        "utterances_per_gpu": B, "valid_frames_per_step": total_frames, "phonemes_per_gpu": ntok,
                        "algorithmic_gflop_per_step_per_gpu": round(sum(O.flops(int(t), int(l)) for t, l in zip(il, model.last_olens)) / 1e9, 1),
                        "parallelism": "utterance-sharded x%d, all-gather(mels) over RCCL" % world if world > 1 else "single GPU",
-                       "launch": "HIP graph replay" if graph_run is not None else ("eager, host-driven layout" if (use_dist or args.profile_kernels) else "eager, device-driven layout (no host sync)")},
+                       "launch": "HIP graph replay" if graph_run is not None else ("eager, host-driven layout" if ((use_dist and dist_caps is None) or args.profile_kernels) else "eager, device-driven layout (no host sync)")},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -68,7 +68,7 @@ class OpGemmArgs(C.Structure):
 # every symbol include/fs2.h declares (tests check the library exports all of them)
 EXPORTS = ["fs2_create", "fs2_destroy", "fs2_last_error", "fs2_load_weights", "fs2_token_workspace_bytes",
            "fs2_encode", "fs2_frame_workspace_bytes", "fs2_row_capacity", "fs2_frame_workspace_bytes_cap", "fs2_decode", "fs2_set_profiling", "fs2_set_profile_filter", "fs2_get_profile",
-           "fs2_op_conv_gemm", "fs2_op_attention", "fs2_op_length_regulate", "fs2_op_unpack_rows", "fs2_op_transpose", "fs2_op_bucketize"]
+           "fs2_op_conv_gemm", "fs2_op_attention", "fs2_op_length_regulate", "fs2_op_unpack_rows", "fs2_op_unpack_rows_dev", "fs2_op_transpose", "fs2_op_bucketize"]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
 
@@ -141,6 +141,8 @@ def lib():
     L.fs2_op_length_regulate.restype = C.c_int
     L.fs2_op_unpack_rows.argtypes = [vp, vp, i32, i32, C.POINTER(i32), C.POINTER(i32), i32, vp]
     L.fs2_op_unpack_rows.restype = C.c_int
+    L.fs2_op_unpack_rows_dev.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp]
+    L.fs2_op_unpack_rows_dev.restype = C.c_int
     L.fs2_op_transpose.argtypes = [vp, vp, C.c_int64, i32, vp]
     L.fs2_op_transpose.restype = C.c_int
     L.fs2_op_bucketize.argtypes = [vp, vp, C.c_int64, vp, i32, vp]

@@ -26,10 +26,11 @@ __global__ void build_row_meta(const int* start, const int* len, int B, int rpad
 // fs2_decode: no host read-back).  Mirrors build_layout() / build_work_list() in fs2_runtime.hip exactly: 32-row aligned starts,
 // kGap zero rows between utterances, attention work list = (utterance, 64-query block) items in eight interleaved per-XCD queues,
 // utterances dealt longest-key-range first to the shortest queue, padding entries (-1, 0).
-// One workgroup.  dims = {rows used, work list length, overflow flags, longest utterance}; 8 = kGap, 32 = kAttAlign, 64 = kAttBQ.
+// One workgroup.  dims = {rows used, work list length, overflow flags, longest utterance, valid frames}; pcum[b] = valid frames of the
+// utterances before b (row offset of utterance b in the packed output); 8 = kGap, 32 = kAttAlign, 64 = kAttBQ.
 __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B, int compat, int masked, int row_cap, int work_cap,
                                                          int lmax_cap, int pe_rows, int* start, int* len, int* klen, int* vlen,
-                                                         int* rank_tmp, int* woff_tmp, int2* work, int* dims) {
+                                                         int* rank_tmp, int* woff_tmp, int* pcum, int2* work, int* dims) {
     __shared__ int s_max, s_min;
     const int tid = threadIdx.x;
     if (tid == 0) { s_max = 0; s_min = 0x7fffffff; }
@@ -58,10 +59,13 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
     __syncthreads();
     if (tid == 0) {
         int row = 8;      // kGap
+        int frames = 0;
         for (int b = 0; b < B; ++b) {
             row = (row + 31) & ~31;
             start[b] = row;
             row += len[b] + 8;
+            pcum[b] = frames;
+            frames += vlen[b];
         }
         int qlen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int depth = 0;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
         if (mx > lmax_cap) ovf |= 2;
         if (mx > pe_rows) ovf |= 4;
         if (s_min <= 0) ovf |= 8;
-        dims[0] = row; dims[1] = ovf ? 0 : depth * 8; dims[2] = ovf; dims[3] = mx;
+        dims[0] = row; dims[1] = ovf ? 0 : depth * 8; dims[2] = ovf; dims[3] = mx; dims[4] = frames; dims[5] = 0; dims[6] = 0; dims[7] = 0;
     }
     __syncthreads();
     if (dims[2] != 0) {           // a capacity is too small: leave an empty layout (all rows are gap rows, no work) so that

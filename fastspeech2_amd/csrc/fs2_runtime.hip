@@ -60,7 +60,8 @@ struct HostLayout {
 struct DevLayout {
     int *start = nullptr, *len = nullptr, *klen = nullptr, *vlen = nullptr, *row_pos = nullptr, *row_seq = nullptr;
     int2* work = nullptr;
-    int* dims = nullptr;    // device-driven layout: {rows used, work items, overflow flags, longest utterance}
+    int* dims = nullptr;    // device-driven layout: {rows used, work items, overflow flags, longest utterance, valid frames, 0, 0, 0}
+    int* pcum = nullptr;    // device-driven layout: valid frames before each utterance (packed-output row offsets)
 };
 
 struct ProfRec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
@@ -428,7 +429,7 @@ void build_layout(HostLayout& L, int B, const std::vector<int>& len, const std::
     build_work_list(len, klen, L.work);
 }
 
-size_t layout_dev_ints(const HostLayout& L) { return (size_t)6 * L.B + 2 * (size_t)L.Rpad + 2 * (size_t)L.nwork() + 64 + 16; }
+size_t layout_dev_ints(const HostLayout& L) { return (size_t)7 * L.B + 2 * (size_t)L.Rpad + 2 * (size_t)L.nwork() + 64 + 16; }
 
 // uploads start/len/klen/vlen/work, then derives row_pos/row_seq on the device
 int upload_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, DevLayout& D) {
@@ -468,14 +469,15 @@ int device_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, D
     D.start = dev; D.len = dev + L.B; D.klen = dev + 2 * L.B; D.vlen = dev + 3 * L.B;
     int* rank_tmp = dev + 4 * L.B;
     int* woff_tmp = dev + 5 * L.B;
-    int* rest = reinterpret_cast<int*>(align_up(reinterpret_cast<size_t>(dev + 6 * L.B), 16));
+    D.pcum = dev + 6 * L.B;
+    int* rest = reinterpret_cast<int*>(align_up(reinterpret_cast<size_t>(dev + 7 * L.B), 16));
     D.dims = rest; rest += 16;
     D.work = reinterpret_cast<int2*>(rest);
     rest += 2 * (size_t)L.nwork();
     rest = reinterpret_cast<int*>(align_up(reinterpret_cast<size_t>(rest), 16));
     D.row_pos = rest; D.row_seq = rest + L.Rpad;
     hipLaunchKernelGGL(frame_layout_dev, dim3(1), dim3(1024), 0, s, olens32, L.B, compat, masked, L.R, L.nwork(), lmax_cap, pe_rows,
-                       D.start, D.len, D.klen, D.vlen, rank_tmp, woff_tmp, D.work, D.dims);
+                       D.start, D.len, D.klen, D.vlen, rank_tmp, woff_tmp, D.pcum, D.work, D.dims);
     hipLaunchKernelGGL(build_row_meta, dim3((L.Rpad + 255) / 256), dim3(256), 0, s, D.start, D.len, L.B, L.Rpad, D.row_pos, D.row_seq);
     HIP_TRY(h, hipGetLastError());
     return FS2_OK;
@@ -1026,7 +1028,6 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     const fs2_config& c = h->cfg;
     if (devlay) {
         if (!io->status) return fail(h, FS2_ERR_ARG, "fs2_decode: the device-driven layout needs a status buffer");
-        if (io->after_packed) return fail(h, FS2_ERR_UNSUPPORTED, "after_packed needs host frame counts");
         if (io->row_capacity > INT32_MAX - 256 || io->Lmax <= 0) return fail(h, FS2_ERR_ARG, "row_capacity %lld / Lmax %d", (long long)io->row_capacity, io->Lmax);
     } else {
         int mx = 0;
@@ -1048,7 +1049,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     DevLayout dl;
     if (devlay) {
         if ((rc = device_layout(h, s, L, f.meta, dl, h->o32, b.compat_padded, io->masked, io->Lmax, h->dec.pe_rows))) return rc;
-        HIP_TRY(h, hipMemcpyAsync(io->status, dl.dims, 4 * sizeof(int), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(io->status, dl.dims, 8 * sizeof(int), hipMemcpyDeviceToDevice, s));
     } else if ((rc = upload_layout(h, s, L, f.meta, dl))) return rc;
     const int R = L.R;
     {   // length regulator
@@ -1134,11 +1135,17 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         if (io->dec_out && (rc = unpack<float>(h, s, f.sb.x0, c.ddim, dl.start, lim_len, b.B, io->Lmax, io->dec_out, 0.f))) return rc;
         if (io->after_packed) {
             if (c.odim % 4) return fail(h, FS2_ERR_UNSUPPORTED, "after_packed needs odim %% 4 == 0");
-            std::vector<int> cum(b.B);
-            int run = 0;
-            for (int i = 0; i < b.B; ++i) { cum[i] = run; run += (int)io->olens[i]; }
-            int* dcum = f.qe;    // the bucket-index rows are already unpacked: reuse their storage for the offsets
-            HIP_TRY(h, hipMemcpyAsync(dcum, cum.data(), cum.size() * sizeof(int), hipMemcpyHostToDevice, s));
+            const int* dcum;
+            if (devlay) {
+                dcum = dl.pcum;      // built by frame_layout_dev; the caller's buffer holds row_capacity rows (>= the frames)
+            } else {
+                std::vector<int> cum(b.B);
+                int run = 0;
+                for (int i = 0; i < b.B; ++i) { cum[i] = run; run += (int)io->olens[i]; }
+                int* up = f.qe;    // the bucket-index rows are already unpacked: reuse their storage for the offsets
+                HIP_TRY(h, hipMemcpyAsync(up, cum.data(), cum.size() * sizeof(int), hipMemcpyHostToDevice, s));
+                dcum = up;
+            }
             const int64_t n = (int64_t)R * (c.odim / 4);
             hipLaunchKernelGGL(pack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mel_after, c.odim, dl.row_pos, dl.row_seq, dl.vlen, dcum, R, io->after_packed);
             HIP_TRY(h, hipGetLastError());
@@ -1272,6 +1279,17 @@ int fs2_op_unpack_rows(void* stream, const float* src, int32_t W, int32_t B, con
     OP_TRY(hipMemcpyAsync(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
     const int64_t total = (int64_t)B * Lout * W;
     hipLaunchKernelGGL(unpack_rows<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, W, dev, dev + B, B, Lout, dst, 0.f);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "unpack_rows: %s", hipGetErrorString(e));
+    return FS2_OK;
+}
+
+int fs2_op_unpack_rows_dev(void* stream, const float* src, int32_t W, int32_t B, const int32_t* starts_dev, const int32_t* lens_dev,
+                           int32_t Lout, float* dst) {
+    if (!src || !dst || !starts_dev || !lens_dev || B <= 0 || W <= 0 || Lout <= 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_unpack_rows_dev: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * Lout * W;
+    hipLaunchKernelGGL(unpack_rows<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, W, starts_dev, lens_dev, B, Lout, dst, 0.f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "unpack_rows: %s", hipGetErrorString(e));
     return FS2_OK;

@@ -324,8 +324,9 @@ class FeedForwardTransformer(nn.Module):
         ``capacity=(total_frames_bound, per_utterance_bound)`` selects the device-driven frame layout instead: no host
         read-back between the two calls, nothing in this method waits for the GPU.  Outputs are then padded to
         ``per_utterance_bound`` frames, ``out["olens"]`` is the DEVICE int64 tensor and ``out["status"]`` a device
-        int32[4] = {rows used, attention work items, overflow flags, longest utterance}: the results are valid only if
-        ``status[2] == 0`` (see ``inference_batch(sync=False)``)."""
+        int32[8] = {rows used, attention work items, overflow flags, longest utterance, valid frames, ...}: the results are
+        valid only if ``status[2] == 0`` (see ``inference_batch(sync=False)``); ``after_packed`` then has
+        ``fs2_row_capacity(total_frames_bound)`` rows, of which the first ``status[4]`` are filled."""
         _require_device(xs)
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
@@ -370,7 +371,7 @@ class FeedForwardTransformer(nn.Module):
                 self.decoder.embed[-1].ensure(Lcap)      # (a grown table is picked up by the next call's fingerprint check)
                 rows = int(L.fs2_row_capacity(C.byref(batch), total_cap))
                 frm_ws = torch.empty(L.fs2_frame_workspace_bytes_cap(h, C.byref(batch), rows, Lcap), dtype=torch.uint8, device=dev)
-                status = torch.empty(4, dtype=torch.int32, device=dev)
+                status = torch.empty(8, dtype=torch.int32, device=dev)
                 odim = self.odim
 
                 def cbuf(key, shape, dtype=torch.float32):
@@ -379,15 +380,15 @@ class FeedForwardTransformer(nn.Module):
                         return out[key].data_ptr()
                     return None
 
-                if teacher or "after_packed" in want:
-                    raise ValueError("the device-driven layout serves free-running synthesis with padded outputs")
+                if teacher:
+                    raise ValueError("the device-driven layout serves free-running synthesis")
                 dio = _lib.DecodeIO(
                     batch, None, Lcap, 0, None, None, 0, 0,
                     cbuf("before", (B, Lcap, odim)), cbuf("after", (B, Lcap, odim)),
                     cbuf("e_outs", (B, Lcap)), cbuf("p_outs", (B, Lcap)),
                     cbuf("qe", (B, Lcap), torch.int32), cbuf("qp", (B, Lcap), torch.int32),
                     cbuf("lr_index", (B, Lcap), torch.int32), cbuf("decoder_out", (B, Lcap, self._cfg["ddim"])),
-                    tok_ws.data_ptr(), frm_ws.data_ptr(), frm_ws.numel(), None, rows, status.data_ptr())
+                    tok_ws.data_ptr(), frm_ws.data_ptr(), frm_ws.numel(), cbuf("after_packed", (rows, odim)), rows, status.data_ptr())
                 if dio.after is None:
                     raise ValueError("'after' must be requested")
                 _lib.check(L.fs2_decode(h, st, C.byref(dio)), h)
@@ -515,36 +516,37 @@ class FeedForwardTransformer(nn.Module):
         self._learn_ratio(il, r["olens"])
         return r["after"][0]
 
-    def inference_batch(self, xs, ilens, d_override=None, packed=False, sync=True):
+    def inference_batch(self, xs, ilens, d_override=None, packed=False, sync=True, capacity=None):
         """Batched free-running synthesis (not in the reference, which only has single-utterance
         ``inference``): per-utterance semantics; returns (mels [B, Lmax, odim], olens [B] on the host), or with
         ``packed=True`` (valid frames back to back [sum(olens), odim], olens): the form the multi-GPU gather ships.
 
         ``sync=False``: nothing waits for the GPU.  The frame layout is built on the device inside capacities predicted
-        from earlier calls (frames per phoneme seen so far, with headroom), the call returns
-        (mels [B, Lcap, odim] zero-padded, olens as a DEVICE int64 tensor) and records ``self.last_async`` =
-        (olens_dev, status_dev, ilens); ``async_ok()`` (one host sync) tells whether the capacities sufficed, and
-        feeds the predictor.  If they did not, the outputs of that call are invalid: repeat it with ``sync=True``
-        (which learns the exact sizes).  The first call of a model is always synchronous."""
-        if not sync and not packed and self._frames_per_token is not None:
+        from earlier calls (frames per phoneme seen so far, with headroom; or ``capacity=(total_frames, per_utterance)``
+        given by the caller, e.g. agreed between ranks), the call returns (mels [B, Lcap, odim] zero-padded - or, with
+        ``packed=True``, [rows_cap, odim] whose first sum(olens) rows are the valid frames - , olens as a DEVICE int64 tensor)
+        and records ``self.last_async``; ``async_ok()`` (one host sync) tells whether the capacities sufficed, and feeds
+        the predictor.  If they did not, the outputs of that call are invalid: repeat it with ``sync=True`` (which learns
+        the exact sizes).  The first call of a model is always synchronous."""
+        if not sync and (self._frames_per_token is not None or capacity is not None):
             il = torch.as_tensor(ilens).detach().to("cpu", torch.int64)
             self._harvest_async(block=False)
-            total = int(float(il.sum()) * self._frames_per_token[0] * 1.15) + 64 * int(il.numel())
-            Lcap = -(-int(float(il.max()) * self._frames_per_token[1] * 1.25 + 64) // 32) * 32
-            r = self._run(xs, il, is_inference=True, compat=False, want=("after",), d_override=d_override, capacity=(total, Lcap))
+            total, Lcap = capacity if capacity is not None else self.predict_capacity(il)
+            key = "after_packed" if packed else "after"
+            r = self._run(xs, il, is_inference=True, compat=False, want=("after", key), d_override=d_override, capacity=(total, Lcap))
             if torch.cuda.is_current_stream_capturing():     # graph capture: no host-side bookkeeping inside the graph
-                return r["after"], r["olens"]
+                return r[key], r["olens"]
             # frame counts and flags travel to pinned host memory behind the kernels; an event tells when they are there
             B = int(il.numel())
             pin = self._pinned
             if pin is None or pin[0].numel() < B:
-                pin = self._pinned = (torch.empty(max(B, 64), dtype=torch.int64).pin_memory(), torch.empty(4, dtype=torch.int32).pin_memory())
+                pin = self._pinned = (torch.empty(max(B, 64), dtype=torch.int64).pin_memory(), torch.empty(8, dtype=torch.int32).pin_memory())
             pin[0][:B].copy_(r["olens"], non_blocking=True)
             pin[1].copy_(r["status"], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(xs.device))
             self.last_async = (il, ev)
-            return r["after"], r["olens"]
+            return r[key], r["olens"]
         want = ("after", "after_packed") if packed else ("after",)
         r = self._run(xs, ilens, is_inference=True, compat=False, want=want, d_override=d_override)
         self._learn_ratio(torch.as_tensor(ilens).detach().to("cpu", torch.int64), r["olens"])
@@ -590,6 +592,14 @@ class FeedForwardTransformer(nn.Module):
     _frames_per_token = None
     _pinned = None
     last_async = None
+
+    def predict_capacity(self, ilens):
+        """(total frames, frames of the longest utterance) to reserve for a batch with these phoneme counts: the
+        frames-per-phoneme ratios seen so far plus 15 % / 25 % head-room."""
+        il = torch.as_tensor(ilens).detach().to("cpu", torch.int64)
+        total = int(float(il.sum()) * self._frames_per_token[0] * 1.15) + 64 * int(il.numel())
+        Lcap = -(-int(float(il.max()) * self._frames_per_token[1] * 1.25 + 64) // 32) * 32
+        return total, Lcap
 
     def _learn_ratio(self, il, ol):
         mean_r = float(ol.sum()) / max(float(il.sum()), 1.0)

@@ -157,6 +157,41 @@ def gather_packed(packed_local, olens_local, index_local, total, group=None):
     return unpack_rows(recv, starts, lens, max(lens)), torch.tensor(lens, dtype=torch.int64)
 
 
+def gather_packed_async(packed_cap, olens_dev, index_dev, total, Lout, group=None):
+    """Sync-free form of :func:`gather_packed` for ``inference_batch(sync=False, packed=True)``: nothing is read back to the
+    host.  Every rank passes a pack of the SAME capacity ([rows_cap, odim], valid frames first), its frame counts and the
+    global indices of its utterances as device int64 tensors of the SAME length b; ``total`` = world * b; ``Lout`` = padded
+    length of the result (>= the longest utterance of any rank; e.g. the agreed per-utterance capacity).  Three collectives
+    (packs, counts, indices: RCCL over xGMI), device-side offset arithmetic, one unpack kernel.  Returns
+    (mels [total, Lout, odim] in global utterance order, olens [total] int64 on the device)."""
+    world = dist.get_world_size(group)
+    dev = packed_cap.device
+    cap, odim = packed_cap.shape
+    b = olens_dev.numel()
+    recv = packed_cap.new_empty(world * cap, odim)
+    dist.all_gather_into_tensor(recv, packed_cap.contiguous(), group=group)
+    ol_all = torch.empty(world * b, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(ol_all, olens_dev.contiguous(), group=group)
+    gi_all = torch.empty(world * b, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(gi_all, index_dev.contiguous(), group=group)
+    ol = ol_all.view(world, b)
+    starts = (torch.cumsum(ol, 1) - ol + torch.arange(world, device=dev).unsqueeze(1) * cap).reshape(-1)
+    starts_g = torch.zeros(total, dtype=torch.int32, device=dev).scatter_(0, gi_all, starts.to(torch.int32))
+    lens_g = torch.zeros(total, dtype=torch.int32, device=dev).scatter_(0, gi_all, ol_all.to(torch.int32))
+    if packed_cap.is_cuda:
+        import ctypes as C
+        from . import _lib
+        out = torch.empty(total, Lout, odim, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().fs2_op_unpack_rows_dev(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), recv.data_ptr(), odim, total,
+                                                         starts_g.data_ptr(), lens_g.data_ptr(), Lout, out.data_ptr()))
+    else:       # CPU (gloo tests): same arithmetic in plain torch
+        pos = torch.arange(Lout).unsqueeze(0)
+        idx = (starts_g.long().unsqueeze(1) + pos).clamp(max=recv.shape[0] - 1)
+        out = torch.where((pos < lens_g.long().unsqueeze(1)).unsqueeze(-1), recv[idx], torch.zeros((), dtype=recv.dtype))
+    return out, lens_g.to(torch.int64)
+
+
 class ShardedSynthesizer:
     """Free-running batched synthesis over all ranks of the default process group.
 

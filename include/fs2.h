@@ -126,10 +126,10 @@ typedef struct fs2_decode_io {
      * set olens = NULL and give capacities instead.  The frame counts are taken from the device copy fs2_encode
      * left in the token workspace, the packed-row layout and the attention work list are built by a kernel, grids
      * are sized for the capacities and the surplus tiles exit at once.  Lmax is then the per-utterance capacity of
-     * the padded outputs.  status (device int32[4], required in this mode) receives
-     * {total rows used, attention work items, overflow flags, longest utterance}; overflow flags != 0
-     * (FS2_OVF_*) means a capacity was too small and the outputs are invalid: rerun with larger capacities or
-     * with host olens.  after_packed is not available in this mode. */
+     * the padded outputs.  status (device int32[8], required in this mode) receives
+     * {total rows used, attention work items, overflow flags, longest utterance, valid frames, 0, 0, 0}; overflow
+     * flags != 0 (FS2_OVF_*) means a capacity was too small and the outputs are invalid: rerun with larger
+     * capacities or with host olens.  after_packed, if given, must hold row_capacity rows in this mode. */
     int64_t row_capacity;     /* 0 = host-driven layout (olens required)                                      */
     int32_t *status;
 } fs2_decode_io;
@@ -203,6 +203,10 @@ int fs2_op_length_regulate(void *stream, const float *hs, const int64_t *ds, con
  * padded; starts/lens: HOST [B].  Inverse of fs2_decode_io.after_packed; replaces utils/util.py:91-104 pad_2d_tensor. */
 int fs2_op_unpack_rows(void *stream, const float *src, int32_t W, int32_t B, const int32_t *starts, const int32_t *lens,
                        int32_t Lout, float *dst);
+
+/* same with DEVICE starts / lens (no host copy, no synchronisation): the sync-free multi-GPU gather */
+int fs2_op_unpack_rows_dev(void *stream, const float *src, int32_t W, int32_t B, const int32_t *starts_dev, const int32_t *lens_dev,
+                           int32_t Lout, float *dst);
 
 /* dst [W, N] <- src [N, W]^T : packed mel frames [sum L, 80] -> vocoder layout [80, sum L] (the reference does
  * mel.transpose + np.concatenate on the host, inference.py:173-178; MelGAN takes [1, 80, L], utils/plot.py:96-105) */

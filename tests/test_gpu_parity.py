@@ -230,6 +230,10 @@ def test_device_driven_layout_matches_host_driven(env):
                 assert int(st[2]) & 1, "row overflow not flagged: %s" % st.tolist()
                 r = model._run(xs, il, is_inference=True, want=("after",), d_override=ds, capacity=(int(ol.sum()) + 64, Lmax - 8))
                 assert int(r["status"].cpu()[2]) & 2, "Lmax overflow not flagged"
+                pk, ol_dev = model.inference_batch(xs, il, d_override=ds, sync=False, packed=True)      # packed output, device offsets
+                assert model.async_ok()
+                want_pk, _ = model.inference_batch(xs, il, d_override=ds, packed=True)
+                assert torch.equal(pk[: want_pk.shape[0]], want_pk)
                 again, _ = model.inference_batch(xs, il, d_override=ds)                      # the handle is still healthy
                 assert torch.equal(again, ref)
         finally:

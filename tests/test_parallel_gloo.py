@@ -47,6 +47,18 @@ def _worker(rank, world, port, q):
     packed = torch.cat([m_loc[i, : int(ol_loc[i])] for i in range(len(mine))])
     mel2, ol2 = gather_packed(packed, ol_loc, mine, xs.shape[0])
     assert torch.equal(ol2, ol) and torch.equal(mel2, mel[:, : mel2.shape[1]])
+    # sync-free form (capacity packs of equal size, counts and indices as "device" tensors, equal utterance count per rank):
+    # utterances 0..9 split evenly, rank r takes r, r+2, ...
+    from fastspeech2_amd.parallel import gather_packed_async
+    ev = list(range(rank, 10, world))
+    sel = torch.as_tensor(ev)
+    m_loc, ol_loc = _fake_run_local(xs[sel][:, : int(il[sel].max())], il[sel])
+    cap, Lout = 400, 48
+    pk = torch.full((cap, 8), float("nan"))                   # rows beyond the valid frames are never read
+    valid = torch.cat([m_loc[i, : int(ol_loc[i])] for i in range(len(ev))])
+    pk[: valid.shape[0]] = valid
+    mel3, ol3 = gather_packed_async(pk, ol_loc, sel, 10, Lout)
+    assert torch.equal(ol3, ol[:10]) and torch.equal(mel3[:, : mel.shape[1]], mel[:10]) and float(mel3[:, mel.shape[1]:].abs().sum()) == 0.0
     q.put((rank, mel, ol))
     dist.barrier()
     dist.destroy_process_group()
