@@ -1,5 +1,7 @@
 // libfs2_hip.so -- runtime + C ABI (include/fs2.h) of the MI355X FastSpeech2 mel-generation path.
-// Orchestrates the kernels in gemm_f32.h / attn_f32.h / elementwise.h over the gapped packed row layout.
+// Orchestrates the kernels over the gapped packed row layout: gemm_planes.h / attn_bf16.h (split-bf16 and bf16 modes, activations as
+// planes), gemm_f32.h / attn_f32.h (exact fp32 mode), elementwise.h (HBM-bound steps, device-side layout).  Weight repacking at load
+// time, workspace carving (no allocation inside a forward), host- or device-driven frame layout, per-launch hipEvent profiling.
 // Replaces the tensor work of reference fastspeech.py:169-243 (`FeedForwardTransformer._forward`).
 #include <hip/hip_runtime.h>
 

@@ -36,6 +36,11 @@ def test_struct_sizes_match_header():
     n = sum(len(decl.split(",")) for decl in re.findall(r"int32_t\s+([^;]+);", body))
     assert n == len(_lib.Config._fields_)
     assert ctypes.sizeof(_lib.Batch) == 24 and ctypes.sizeof(_lib.TensorDesc) == 56
+    for cname, mirror in (("fs2_encode_io", _lib.EncodeIO), ("fs2_decode_io", _lib.DecodeIO), ("fs2_op_gemm_args", _lib.OpGemmArgs)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        nfields = sum(len(decl.split(",")) for decl in re.findall(r"([^;{}]+);", body) if decl.strip())
+        assert nfields == len(mirror._fields_), (cname, nfields, len(mirror._fields_))
 
 
 def test_create_without_gpu_fails_loudly(libpath):
