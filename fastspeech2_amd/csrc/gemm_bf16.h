@@ -28,6 +28,15 @@ __device__ __forceinline__ void dma_barrier() {
     __syncthreads();
 }
 
+// One LDS-DMA instruction (64 lanes x 16 B -> 1 KB of LDS at byte offset lds_off, which must be wave-uniform).  Written as
+// inline asm so that M0 comes from an SGPR operand: with __builtin_amdgcn_global_load_lds hipcc keeps the LDS pointer in a
+// VGPR and emits v_readfirstlane + s_mov m0 per instruction, and the phase probe (tools/probes/gemm_probe.hip) showed the 4-6
+// DMA instructions of a k-step costing 13-30 % of the step.  The compiler does not see this VMEM operation: completion is
+// always awaited explicitly (dma_barrier), and its own vmcnt bookkeeping for other loads only becomes more conservative.
+__device__ __forceinline__ void dma16(const void* src, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_off) : "memory");      // (M0 is reserved: hipcc never keeps a value in it across statements)
+}
+
 #ifndef FS2_SETPRIO
 #define FS2_SETPRIO 1
 #endif

@@ -77,6 +77,15 @@ __device__ __forceinline__ void pl_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][
     }
 }
 
+// Phase timing for tools/probes/gemm_probe.hip (compiled only with -DFS2_GEMM_TIMING): s_memtime ticks of wave 0 of workgroup
+// (0, 0), accumulated per phase of the k-loop: 0 barrier wait, 1 DMA issue, 2 B fragment reads + MFMAs, 3 chunk-end A refill.
+#ifdef FS2_GEMM_TIMING
+__device__ long long g_gemm_phase[8];
+#define FS2_GT(i) { const long long t_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_gemm_phase[i] += t_ - tprev; tprev = t_; }
+#else
+#define FS2_GT(i)
+#endif
+
 template <int NSPLIT, int BM, bool K1>
 __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs a) {
     constexpr int MT = BM / 32;               // 16-row MFMA tiles per wave (wave tile = BM/2 x 64)
@@ -84,7 +93,9 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     extern __shared__ __attribute__((aligned(16))) char smem_p[];
     char* As0 = smem_p;
     char* Bs0 = smem_p + (K1 ? 2 : 1) * AROWS * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave index as a SCALAR: every LDS-DMA destination (M0) is then SGPR arithmetic instead of a v_readfirstlane per instruction
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     // grid.x walks the N tiles: workgroup L of a launch runs on XCD L % 8, so with 8 N tiles each XCD keeps ONE 128-column weight
     // panel in its L2 and streams the A planes past it (measured: giving an XCD all N tiles of an M tile instead changes nothing)
@@ -108,14 +119,18 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     const int arow0 = m0 - P + wave * 8 + jrow;
     const __bf16* a_src0 = Xp + (ptrdiff_t)arow0 * nchunks * 64 + sA * 8;      // dereferenced only when the row is in [0, R)
     const size_t a_qstride = (size_t)32 * nchunks * 64;
+    // LDS destinations of the DMA instructions as SCALARS (M0 = SGPR arithmetic; otherwise hipcc keeps the LDS pointer in a VGPR
+    // and pays a v_readfirstlane + M0 hazard per instruction: the issue of the 4-6 instructions of a step took 13-30 % of it)
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t*)smem_p);
+    const unsigned ldsA = lds0 + wave * 1024, ldsB = lds0 + (K1 ? 2 : 1) * AROWS * 128 + wave * 1024;
     auto dma_A = [&](int ch, int buf) {
-        char* dst = As0 + buf * (AROWS * 128) + wave * 1024;
+        unsigned dst = ldsA + buf * (AROWS * 128);
         const __bf16* src = a_src0 + (size_t)ch * 64;
         int row = arow0;
         for (int q = wave; q < a_instr; q += 4) {
             const bool ok = row >= 0 && row < a.R;
             const void* sp = ok ? static_cast<const void*>(src) : static_cast<const void*>(g_zero16);
-            __builtin_amdgcn_global_load_lds(sp, (lds_void_t*)dst, 16, 0, 0);
+            dma16(sp, dst);
             dst += 4096; src += a_qstride; row += 32;
         }
     };
@@ -127,11 +142,11 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     const __bf16* b_src0 = Wb + ((size_t)(n0 + 4 * rperm_inv(jB) + (wave >> 1)) * niter) * 64 + sB * 8;
     const size_t b_o1 = (size_t)2 * niter * 64, b_o2 = (size_t)64 * niter * 64;
     auto dma_B = [&](int it, int buf) {
-        char* dst = Bs0 + buf * (kB16BN * 128) + wave * 1024;
+        const unsigned dst = ldsB + buf * (kB16BN * 128);
         const __bf16* src = b_src0 + (size_t)it * 64;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            __builtin_amdgcn_global_load_lds(src + (u & 1) * b_o1 + (u >> 1) * b_o2, (lds_void_t*)(dst + u * 4096), 16, 0, 0);
+            dma16(src + (u & 1) * b_o1 + (u >> 1) * b_o2, dst + u * 4096);
     };
 
     dma_A(0, 0);
@@ -155,13 +170,18 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
             }
     }
     int it = 0;
+#ifdef FS2_GEMM_TIMING
+    long long tprev = __builtin_readcyclecounter();
+#endif
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         for (int tap = 0; tap < ktaps; ++tap, ++it) {
             dma_barrier();     // DMA of step `it` landed; every wave is done with step it-1
+            FS2_GT(0)
             if (it + 1 < niter) {
                 dma_B(it + 1, (it + 1) & 1);
                 if (K1) dma_A(it + 1, (it + 1) & 1);
             }
+            FS2_GT(1)
             const char* As = As0 + (K1 ? (it & 1) : 0) * (AROWS * 128);
             const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
             bf16x8_t bh[4], bl[4];
@@ -187,9 +207,11 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
                 for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
             }
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
+            FS2_GT(2)
             if (!K1 && tap == ktaps - 1 && chunk + 1 < nchunks) {
                 __syncthreads();              // every wave has read its last fragments of this chunk's A tile
                 dma_A(chunk + 1, 0);
+                FS2_GT(3)
             }
         }
     }
@@ -259,7 +281,9 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
     constexpr int MT = 2, NT = 4 * NB, BM = 128, BN = 128 * NB;
     constexpr int STAGE = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem_r[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave index as a SCALAR: every LDS-DMA destination (M0) is then SGPR arithmetic instead of a v_readfirstlane per instruction
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * BM;
     if (a.Rp != nullptr && m0 >= ((*a.Rp + 127) & ~127)) return;      // device-driven layout: tile beyond the rows in use
