@@ -240,6 +240,39 @@ def test_device_driven_layout_matches_host_driven(env):
             model.precision = "fp32"
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_device_driven_layout_random_batches(env, seed):
+    """Host-driven vs device-driven layout on ragged random batches: single-phoneme utterances, all-zero duration rows (the
+    length regulator's all-ones rule), zero durations inside, one utterance much longer than the rest, B = 1."""
+    model = env[0]
+    rs = np.random.RandomState(100 + seed)
+    B = [1, 5, 17, 33][seed]
+    il = torch.from_numpy(rs.randint(1, 60, size=B)).long()
+    il[rs.randint(B)] = 1
+    if B > 1:
+        il[rs.randint(B)] = 150
+    T = int(il.max())
+    xs = torch.zeros(B, T, dtype=torch.long)
+    ds = torch.zeros(B, T, dtype=torch.long)
+    for b in range(B):
+        t = int(il[b])
+        xs[b, :t] = torch.from_numpy(rs.randint(1, 68, size=t))
+        ds[b, :t] = torch.from_numpy(rs.randint(0, 12, size=t))
+    ds[0, : int(il[0])] = 0                                  # all-zero row -> every phoneme gets one frame
+    xs, ds = xs.cuda(), ds.cuda()
+    model.precision = "bf16x3"
+    try:
+        with torch.no_grad():
+            ref, ol = model.inference_batch(xs, il, d_override=ds)
+            assert int(ol[0]) == int(il[0])
+            got, ol_dev = model.inference_batch(xs, il, d_override=ds, sync=False)
+            assert model.async_ok() and torch.equal(ol_dev.cpu(), ol)
+            Lmax = int(ol.max())
+            assert torch.equal(got[:, :Lmax], ref) and float(got[:, Lmax:].abs().sum()) == 0.0
+    finally:
+        model.precision = "fp32"
+
+
 def test_inference_second_call_uses_device_layout(env):
     """`inference(x)` (reference fastspeech.py:339-357): the first call learns the frames-per-phoneme ratio with the host-driven
     layout, later calls run sync-free inside capacities and read the frame count once at the end; same mel either way, and an
