@@ -98,14 +98,17 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
 // h[row] = E[xs[b, t]] * xscale + alpha * pe[t]      (reference encoder.py:196, embedding.py:77-80,105-120)
 __global__ __launch_bounds__(256) void embed_pe(const int64_t* xs, int Tmax, const float* E, int idim, int D,
                                                 const float* pe, const float* alpha_p, float xscale,
-                                                const int* row_pos, const int* row_seq, int R, float* h) {
+                                                const int* row_pos, const int* row_seq, int R, float* h, void* planes = nullptr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= R) return;
     const int t = row_pos[row];
     float* dst = h + (size_t)row * D;
     if (t < 0) {
-        for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<float4*>(dst + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = lane * 4; c < D; c += 256) {
+            *reinterpret_cast<float4*>(dst + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (planes) store_planes4(planes, row, D / 32, c, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
         return;
     }
     const int b = row_seq[row];
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(256) void embed_pe(const int64_t* xs, int Tmax, con
         o.z = ev.z * xscale + alpha * pv.z;
         o.w = ev.w * xscale + alpha * pv.w;
         *reinterpret_cast<float4*>(dst + c) = o;
+        if (planes) store_planes4(planes, row, D / 32, c, f32x4{o.x, o.y, o.z, o.w});
     }
 }
 
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256) void dur_scan(const int64_t* ds, int Tmax, con
 __global__ __launch_bounds__(256) void lr_expand(const float* hs, int D, const int* tok_start, const int* ilen,
                                                  const int* cum, int Tmax, const int* row_pos, const int* row_seq,
                                                  int uniform_len, const int* vlen, int R, float* out,
-                                                 int* index_rows) {
+                                                 int* index_rows, void* planes = nullptr) {     // planes: also as split-bf16 planes (D / 32 chunks)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= R) return;
@@ -213,12 +217,18 @@ __global__ __launch_bounds__(256) void lr_expand(const float* hs, int D, const i
     }
     if (index_rows && lane == 0) index_rows[row] = idx;
     if (idx < 0) {
-        for (int c4 = lane * 4; c4 < D; c4 += 256) *reinterpret_cast<float4*>(dst + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c4 = lane * 4; c4 < D; c4 += 256) {
+            *reinterpret_cast<float4*>(dst + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (planes) store_planes4(planes, row, D / 32, c4, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
         return;
     }
     const float* src = hs + (size_t)(tok_start[b] + idx) * D;
-    for (int c4 = lane * 4; c4 < D; c4 += 256)
-        *reinterpret_cast<float4*>(dst + c4) = *reinterpret_cast<const float4*>(src + c4);
+    for (int c4 = lane * 4; c4 < D; c4 += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(src + c4);
+        *reinterpret_cast<float4*>(dst + c4) = v;
+        if (planes) store_planes4(planes, row, D / 32, c4, f32x4{v.x, v.y, v.z, v.w});
+    }
 }
 
 // torch.bucketize(x, bins, right=False): first i with x <= bins[i]; NaN -> nb (the `!(b >= x)` form keeps
@@ -245,13 +255,15 @@ __global__ __launch_bounds__(256) void bucket_embed(float* h, int D, const int* 
                                                     const float* es, int es_stride, const float* ps, int ps_stride,
                                                     const float* e_rows, const float* p_rows,
                                                     const float* ebins, const float* pbins, int nb,
-                                                    const float* Te, const float* Tp, int* qe_rows, int* qp_rows) {
+                                                    const float* Te, const float* Tp, int* qe_rows, int* qp_rows, void* planes = nullptr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= R) return;
     const int j = row_pos[row];
     if (j < 0) {
         if (lane == 0) { if (qe_rows) qe_rows[row] = -1; if (qp_rows) qp_rows[row] = -1; }
+        if (planes)
+            for (int c = lane * 4; c < D; c += 256) store_planes4(planes, row, D / 32, c, f32x4{0.f, 0.f, 0.f, 0.f});
         return;
     }
     const int b = row_seq[row];
@@ -272,6 +284,7 @@ __global__ __launch_bounds__(256) void bucket_embed(float* h, int D, const int* 
         v.z = (v.z + a.z) + g.z;
         v.w = (v.w + a.w) + g.w;
         *reinterpret_cast<float4*>(dst + c) = v;
+        if (planes) store_planes4(planes, row, D / 32, c, f32x4{v.x, v.y, v.z, v.w});
     }
 }
 

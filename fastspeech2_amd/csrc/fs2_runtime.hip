@@ -785,7 +785,7 @@ size_t carve_frames(const fs2_config& c, const HostLayout& L, void* ws, size_t c
     f.sb.vth = bp.take<__bf16>(R * c.ddim);
     f.sb.vtl = bp.take<__bf16>(R * c.ddim);
     f.sb.x0p = bp.take<float>(R * (size_t)round_up(std::max(c.ddim, c.postnet_chans), 32));
-    f.sb.x1p = bp.take<float>(R * (size_t)round_up(std::max(c.ddim, c.postnet_chans), 32));
+    f.sb.x1p = bp.take<float>(R * (size_t)round_up(std::max(std::max(c.adim, c.ddim), c.postnet_chans), 32));    // also holds the length-regulator output's planes
     f.sb.xps = bp.take<float>(R * (size_t)round_up(std::max(std::max(c.adim, c.ddim), std::max(std::max(c.var_chans, c.postnet_chans), c.odim)), 32));
     f.before = bp.take<float>(R * c.odim);
     f.after = bp.take<float>(R * c.odim);
@@ -963,14 +963,15 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
     if (!ok) return fail(h, FS2_ERR_WORKSPACE, "fs2_encode: workspace too small");
     if ((rc = upload_layout(h, s, L, meta, h->dtok))) return rc;
     const DevLayout& dl = h->dtok;
+    const bool enc_pl = b.precision != FS2_PREC_FP32;   // activations also travel as planes (x0p holds those of x0 before and after the stack)
     {
         Scope sc(h, s, "enc.embed", 0, 4.0 * L.R * c.adim * 2);
         hipLaunchKernelGGL(embed_pe, dim3((L.R + 3) / 4), dim3(256), 0, s, io->xs, b.Tmax, h->enc_embed, c.idim, c.adim, h->enc.pe,
-                           h->enc.alpha, c.use_scaled_pos_enc ? 1.0f : sqrtf((float)c.adim), dl.row_pos, dl.row_seq, L.R, sb.x0);
+                           h->enc.alpha, c.use_scaled_pos_enc ? 1.0f : sqrtf((float)c.adim), dl.row_pos, dl.row_seq, L.R, sb.x0,
+                           enc_pl && c.adim % 32 == 0 ? sb.x0p : nullptr);
         HIP_TRY(h, hipGetLastError());
     }
-    if ((rc = run_stack(h, s, "enc", h->enc, c.adim, c.aheads, L.R, L, dl, /*mask_q=*/1, sb, b.precision))) return rc;
-    const bool enc_pl = b.precision != FS2_PREC_FP32;   // run_stack left planes of x0 in x0p
+    if ((rc = run_stack(h, s, "enc", h->enc, c.adim, c.aheads, L.R, L, dl, /*mask_q=*/1, sb, b.precision, /*x0p_ready=*/enc_pl && c.adim % 32 == 0))) return rc;
     if ((rc = run_predictor(h, s, "dur", h->dur, sb.x0, c.adim, L.R, dl.row_pos, p0, p1, dlog_rows, b.precision, enc_pl ? sb.x0p : nullptr, sb.xps))) return rc;
     {
         Scope sc(h, s, "dur.post", 0, 0);
@@ -1054,19 +1055,22 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         HIP_TRY(h, hipMemcpyAsync(io->status, dl.dims, 8 * sizeof(int), hipMemcpyDeviceToDevice, s));
     } else if ((rc = upload_layout(h, s, L, f.meta, dl))) return rc;
     const int R = L.R;
+    // bf16 modes: the length-regulator output (and later its sum with the pitch / energy embeddings) is also written as planes,
+    // in x1p (free until the decoder stack's first LayerNorm): the A operand of both variance predictors and of the decoder input layer
+    void* hfr_planes = (b.precision != FS2_PREC_FP32 && c.adim % 32 == 0) ? f.sb.x1p : nullptr;
     {   // length regulator
         Scope sc(h, s, "lr.expand", 0, 4.0 * R * c.adim * 2);
         hipLaunchKernelGGL(lr_expand, dim3((R + 3) / 4), dim3(256), 0, s, h->enc_final, c.adim, h->dtok.start, h->dtok.vlen, h->cum, b.Tmax,
-                           dl.row_pos, dl.row_seq, 0, dl.vlen, R, f.hfr, f.lri);
+                           dl.row_pos, dl.row_seq, 0, dl.vlen, R, f.hfr, f.lri, hfr_planes);
         HIP_TRY(h, hipGetLastError());
     }
     const bool need_e = (io->es == nullptr) || io->e_out, need_p = (io->ps == nullptr) || io->p_out;
-    if (need_e && (rc = run_predictor(h, s, "energy", h->energy, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.e_rows, b.precision, nullptr, f.sb.xps, dl.dims))) return rc;
-    if (need_p && (rc = run_predictor(h, s, "pitch", h->pitch, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.p_rows, b.precision, nullptr, f.sb.xps, dl.dims))) return rc;
+    if (need_e && (rc = run_predictor(h, s, "energy", h->energy, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.e_rows, b.precision, hfr_planes, f.sb.xps, dl.dims))) return rc;
+    if (need_p && (rc = run_predictor(h, s, "pitch", h->pitch, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.p_rows, b.precision, hfr_planes, f.sb.xps, dl.dims))) return rc;
     {
         Scope sc(h, s, "var.embed", 0, 4.0 * R * c.adim * 4);
         hipLaunchKernelGGL(bucket_embed, dim3((R + 3) / 4), dim3(256), 0, s, f.hfr, c.adim, dl.row_pos, dl.row_seq, R, io->es, io->es_stride,
-                           io->ps, io->ps_stride, f.e_rows, f.p_rows, h->ebins, h->pbins, c.n_bins - 1, h->Te, h->Tp, f.qe, f.qp);
+                           io->ps, io->ps_stride, f.e_rows, f.p_rows, h->ebins, h->pbins, c.n_bins - 1, h->Te, h->Tp, f.qe, f.qp, hfr_planes);
         HIP_TRY(h, hipGetLastError());
     }
     const bool dec_pl = b.precision != FS2_PREC_FP32;
@@ -1075,7 +1079,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         a.Rp = dl.dims;
         a.ln_g = h->dec_in_lng; a.ln_b = h->dec_in_lnb; a.ln_eps = 1e-5f; a.act_post = 1;
         a.pe = h->dec.pe; a.pe_ld = c.ddim; a.pe_alpha = h->dec.alpha; a.x_scale = c.use_scaled_pos_enc ? 1.f : sqrtf((float)c.ddim);
-        a.xp_scratch = f.sb.xps;
+        a.Xp = hfr_planes; a.xp_scratch = f.sb.xps;
         if (dec_pl) { a.Yp = f.sb.x0p; a.yp_chunks = c.ddim / 32; }
         if ((rc = launch_gemm(h, s, "dec.in", a, b.precision))) return rc;
     } else {                       // TorchScript twin: the decoder input is just x (* sqrt(d)) + alpha * pe   (encoder.py:138-141)
