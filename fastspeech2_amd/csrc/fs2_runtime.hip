@@ -198,6 +198,26 @@ hipError_t launch_row8_t(hipStream_t s, const GemmArgs& a) {
     return hipGetLastError();
 }
 
+template <int NSPLIT, int NB>
+hipError_t launch_qkv8_t(hipStream_t s, const GemmArgs& a) {
+    static bool attr = false;
+    constexpr size_t lds = row8_lds_bytes<NB>();
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_qkv8_bf16<NSPLIT, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_qkv8_bf16<NSPLIT, NB>), dim3((a.Rvt + 127) / 128), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+// Fused QKV projection on the 8-wave structure when there is about a CU's worth of 128-row tiles (FS2_QKV8=0|1 forces the choice)
+bool use_qkv8(const GemmArgs& a) {
+    if (!a.qk_hi || a.ktaps != 1 || (a.att_D != 256 && a.att_D != 384) || a.N != 3 * a.att_D) return false;
+    const char* e = getenv("FS2_QKV8");
+    if (e) return atoi(e) != 0;
+    return (a.Rvt + 127) / 128 >= 128;
+}
+
 // Row-complete LN-fused kernel (gemm_row8_bf16) for k = 1 GEMMs that end in a row epilogue: one workgroup per CU, so it
 // needs about a CU's worth of 128-row tiles to pay (FS2_ROW8=0|1 forces the choice).
 bool use_row8(const GemmArgs& a) {
@@ -259,7 +279,10 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         }
         {
             Scope sc(h, s, name, flops, bytes);
-            if (row8) {
+            if (use_qkv8(t)) {
+                if (a.att_D == 384) e = (precision == FS2_PREC_BF16X3) ? launch_qkv8_t<3, 3>(s, t) : launch_qkv8_t<1, 3>(s, t);
+                else e = (precision == FS2_PREC_BF16X3) ? launch_qkv8_t<3, 2>(s, t) : launch_qkv8_t<1, 2>(s, t);
+            } else if (row8) {
                 if (a.N == 384) e = (precision == FS2_PREC_BF16X3) ? launch_row8_t<3, 3>(s, t) : launch_row8_t<1, 3>(s, t);
                 else e = (precision == FS2_PREC_BF16X3) ? launch_row8_t<3, 2>(s, t) : launch_row8_t<1, 2>(s, t);
             } else e = (precision == FS2_PREC_BF16X3) ? launch_pl<3>(s, t) : launch_pl<1>(s, t);

@@ -467,4 +467,178 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
     }
 }
 
+// gemm_qkv8_bf16: the fused QKV projection on the row8 structure (8 waves, 128 rows x 128 NB columns per pass, one workgroup per
+// CU).  N = 3 D with D = 128 NB: the workgroup makes three passes over its 128 rows - Q, K, V - re-streaming the A tile from L2;
+// per MFMA it issues 1/2.25 of the LDS-DMA instructions and meets 1/3 of the barriers of the 64 x 128 tiles of gemm_pl_bf16, whose
+// k-step was 31 % DMA issue + 30 % barrier (tools/probes/gemm_probe.hip).  Q (x log2e / sqrt(d_k)) and K leave straight from the
+// registers as row-major split-bf16 planes [Rvt][2D]; V goes through LDS in three 128-column passes and leaves as V^T [D][Rvt]
+// (8 consecutive keys per 16-byte store).  Rows that are gaps or beyond R are written as zeros.
+template <int NSPLIT, int NB>
+__global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
+    constexpr int MT = 2, NT = 4 * NB, BM = 128, BN = 128 * NB;
+    constexpr int STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem_r[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave index as a SCALAR: every LDS-DMA destination (M0) is then SGPR arithmetic instead of a v_readfirstlane per instruction
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM;
+    if (a.Rp != nullptr && m0 >= ((*a.Rp + 127) & ~127)) return;      // device-driven layout: tile beyond the rows in use
+    const int lr = lane & 15, lg = lane >> 4;
+    const int lp = rperm(lr);
+    const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
+    const __bf16* Xp = reinterpret_cast<const __bf16*>(a.Xp);
+
+    const int niter = a.Cpad / 32;
+    const int jrow = lane >> 3, jslot = lane & 7;
+    // A: 16 one-KB instructions per stage, wave w issues q = w and w + 8 (tile rows 8q + jrow)
+    const int sA = jslot ^ (jrow >> 1) ^ ((wave & 1) << 2);
+    const int arow0 = m0 + wave * 8 + jrow;
+    const __bf16* a_src0 = Xp + (size_t)arow0 * niter * 64 + sA * 8;
+    const size_t a_qstride = (size_t)64 * niter * 64;
+    // B: 16 NB instructions per stage, wave w issues q = w + 8u (u < 2 NB): LDS rows 8q + jrow = 16 ((w >> 1) + 4u) + jB,
+    // i.e. 64-column group u, n-tile (w >> 1) of it, tile row jB -> weight row 64u + 4 rperm_inv(jB) + (w >> 1)
+    const int jB = (wave & 1) * 8 + jrow;
+    const int sB = jslot ^ ((jB >> 1) & 7);
+    const __bf16* b_src0 = Wb + ((size_t)(4 * rperm_inv(jB) + (wave >> 1)) * niter) * 64 + sB * 8;
+    const size_t b_ustride = (size_t)64 * niter * 64;
+    auto dma_stage = [&](int it, int buf) {
+        char* as = smem_r + buf * STAGE + wave * 1024;
+        const __bf16* asrc = a_src0 + (size_t)it * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = arow0 + 64 * i < a.R;
+            const void* sp = ok ? static_cast<const void*>(asrc + i * a_qstride) : static_cast<const void*>(g_zero16);
+            __builtin_amdgcn_global_load_lds(sp, (lds_void_t*)(as + i * 8192), 16, 0, 0);
+        }
+        char* bs = smem_r + buf * STAGE + BM * 128 + wave * 1024;
+        const __bf16* bsrc = b_src0 + (size_t)it * 64;
+#pragma unroll
+        for (int u = 0; u < 2 * NB; ++u)
+            __builtin_amdgcn_global_load_lds(bsrc + u * b_ustride, (lds_void_t*)(bs + u * 8192), 16, 0, 0);
+    };
+
+    const int col0 = wn * (64 * NB) + 4 * lr;
+    int rowi[MT][4];
+    bool rvalid[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rowi[mt][r] = m0 + wm * 32 + mt * 16 + rperm(lg * 4 + r);
+            rvalid[mt][r] = rowi[mt][r] < a.R && (a.row_pos == nullptr || a.row_pos[rowi[mt][r]] >= 0);
+        }
+    __bf16* qkh = reinterpret_cast<__bf16*>(a.qk_hi);
+    __bf16* qkl = reinterpret_cast<__bf16*>(a.qk_lo);
+    const __bf16* b_src_blk = b_src0;
+    for (int nb = 0; nb < 3; ++nb, b_src_blk += (size_t)BN * niter * 64) {
+        __syncthreads();                 // every wave is done with the previous pass's operand buffers / LDS tile
+        b_src0 = b_src_blk;
+        dma_stage(0, 0);
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nb * BN + col0 + 64 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mt][4 * g + j][r] = bv[j];
+        }
+        for (int it = 0; it < niter; ++it) {
+            dma_barrier();
+            if (it + 1 < niter) dma_stage(it + 1, (it + 1) & 1);
+            const char* As = smem_r + (it & 1) * STAGE;
+            const char* Bs = As + BM * 128;
+            bf16x8_t ah[MT], al[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = wm * 32 + mt * 16 + lp;
+                ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
+                if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
+            }
+            if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int n2 = 0; n2 < NT; n2 += 2) {
+                bf16x8_t bh[2], bl[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int n = wn * (64 * NB) + (n2 + u) * 16 + lp;
+                    bh[u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
+                    if (NSPLIT == 3) bl[u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
+                }
+                if (NSPLIT == 3) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[u], acc[mt][n2 + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[u], acc[mt][n2 + u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[u], acc[mt][n2 + u], 0, 0, 0);
+            }
+            if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
+        }
+
+        if (nb < 2) {                    // Q | K: 8 + 8 bytes of hi / lo per 4 channels, 128 contiguous bytes per row and plane
+            const float sc = (nb == 0) ? a.q_scale : 1.f;
+#pragma unroll
+            for (int g = 0; g < NB; ++g)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (rowi[mt][r] >= a.Rvt) continue;
+                        const float f = rvalid[mt][r] ? sc : 0.f;
+                        uint2 hi, lo;
+                        split4(f32x4{acc[mt][4 * g][r], acc[mt][4 * g + 1][r], acc[mt][4 * g + 2][r], acc[mt][4 * g + 3][r]} * f, hi, lo);
+                        const size_t off = (size_t)rowi[mt][r] * 2 * BN + nb * BN + col0 + 64 * g;
+                        *reinterpret_cast<uint2*>(qkh + off) = hi;
+                        *reinterpret_cast<uint2*>(qkl + off) = lo;
+                    }
+        } else {                         // V: three 128-column passes through a [128][132] fp32 tile in LDS -> V^T planes
+            float* tile = reinterpret_cast<float*>(smem_r);
+            __bf16* vth = reinterpret_cast<__bf16*>(a.vt_hi);
+            __bf16* vtl = reinterpret_cast<__bf16*>(a.vt_lo);
+            for (int pass = 0; pass < NB; ++pass) {
+                __syncthreads();         // operand buffers / previous pass's tile are dead
+#pragma unroll
+                for (int g = 0; g < NB; ++g) {
+                    const int G = wn * NB + g;           // 64-column group of the block
+                    if ((G >> 1) != pass) continue;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const f32x4 v = f32x4{acc[mt][4 * g][r], acc[mt][4 * g + 1][r], acc[mt][4 * g + 2][r], acc[mt][4 * g + 3][r]};
+                            *reinterpret_cast<f32x4*>(tile + (wm * 32 + mt * 16 + rperm(lg * 4 + r)) * kQkvLd + (G & 1) * 64 + 4 * lr) =
+                                rvalid[mt][r] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                }
+                __syncthreads();
+                // column c of the pass, rows 8j .. 8j+7: 4 consecutive lanes share a column (64-byte V^T segments)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = tid + u * 512;
+                    const int c = (idx >> 2) & 127, j = ((idx >> 9) << 2) | (idx & 3);
+                    const int row = m0 + 8 * j;
+                    if (row >= a.Rvt) continue;
+                    const float* t = tile + (8 * j) * kQkvLd + c;
+                    const SplitPair sp = split8(make_float4(t[0], t[kQkvLd], t[2 * kQkvLd], t[3 * kQkvLd]),
+                                                make_float4(t[4 * kQkvLd], t[5 * kQkvLd], t[6 * kQkvLd], t[7 * kQkvLd]));
+                    const size_t off = (size_t)(pass * 128 + c) * a.Rvt + row;
+                    *reinterpret_cast<uint4*>(vth + off) = sp.hi;
+                    *reinterpret_cast<uint4*>(vtl + off) = sp.lo;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace fs2

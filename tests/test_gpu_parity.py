@@ -132,6 +132,20 @@ def test_c2_row_complete_kernel_choice(env, row8, monkeypatch):
         model.precision = "fp32"
 
 
+@pytest.mark.parametrize("qkv8", ["0", "1"])
+def test_c2_qkv_kernel_choice(env, qkv8, monkeypatch):
+    """The fused QKV projection has two bf16 implementations (64 x 128 tiles / three 128 x D passes of an 8-wave workgroup,
+    chosen by size): c2 in the parity mode with each one forced."""
+    model, sd, cfg, O = env
+    from fastspeech2_amd.synthetic import make_batch
+    monkeypatch.setenv("FS2_QKV8", qkv8)
+    model.precision = "bf16x3"
+    try:
+        _c2_body(model, sd, cfg, O, make_batch("c2"), "bf16x3")
+    finally:
+        model.precision = "fp32"
+
+
 def _c2_body(model, sd, cfg, O, b, precision):
     with torch.no_grad():
         r = model._run(b["xs"].cuda(), b["ilens"], b["olens"], b["ds"].cuda(), b["es"].cuda(), b["ps"].cuda(),
