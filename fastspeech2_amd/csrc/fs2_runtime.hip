@@ -1186,6 +1186,20 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
 // ---------------------------------------------------------------------------------- single operators
 #define OP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); return FS2_ERR_HIP; } } while (0)
 
+// temporary device memory of an operator entry point: released on every exit path (after the stream drained)
+struct DevTmp {
+    hipStream_t s;
+    std::vector<void*> ptrs;
+    explicit DevTmp(hipStream_t s_) : s(s_) {}
+    ~DevTmp() { if (!ptrs.empty()) hipStreamSynchronize(s); for (void* p : ptrs) hipFree(p); }
+    hipError_t alloc(void** out, size_t bytes) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 16));
+        if (e == hipSuccess) { ptrs.push_back(p); *out = p; }
+        return e;
+    }
+};
+
 int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
     if (!o || !o->x || !o->w || o->R <= 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_conv_gemm: bad arguments");
     if (o->precision < FS2_PREC_FP32 || o->precision > FS2_PREC_BF16) return fail(nullptr, FS2_ERR_ARG, "unknown precision %d", o->precision);
@@ -1194,12 +1208,13 @@ int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
     const int Npad = round_up(o->N, 128);
     const int nchunks = g.Cpad / 32;
     const size_t wn = (size_t)Npad * o->ktaps * g.Cpad;
-    OP_TRY(hipMalloc((void**)&g.w, wn * sizeof(float)));
-    OP_TRY(hipMalloc((void**)&g.wb, wn * 4));
+    DevTmp tmp(s);
+    OP_TRY(tmp.alloc((void**)&g.w, wn * sizeof(float)));
+    OP_TRY(tmp.alloc((void**)&g.wb, wn * 4));
     float* scratch = nullptr;
-    OP_TRY(hipMalloc((void**)&scratch, (size_t)o->R * o->N * sizeof(float)));
+    OP_TRY(tmp.alloc((void**)&scratch, (size_t)o->R * o->N * sizeof(float)));
     void* xps = nullptr;          // planes of x for the bf16 modes (gemm_planes.h)
-    if (o->precision != FS2_PREC_FP32) OP_TRY(hipMalloc(&xps, (size_t)o->R * g.Cpad * sizeof(float)));
+    if (o->precision != FS2_PREC_FP32) OP_TRY(tmp.alloc((void**)&xps, (size_t)o->R * g.Cpad * sizeof(float)));
     int* rp = nullptr;
     hipMemsetAsync(g.w, 0, wn * sizeof(float), s);
     hipMemsetAsync(g.wb, 0, wn * 4, s);
@@ -1213,7 +1228,7 @@ int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
     GemmArgs a = gemm_args(g, o->x, o->C, o->R, nullptr, o->y, o->N);
     a.scratch = scratch;
     if (o->row_valid) {   // row_valid (0/1) -> row_pos (-1 / 0)
-        OP_TRY(hipMalloc((void**)&rp, (size_t)o->R * sizeof(int)));
+        OP_TRY(tmp.alloc((void**)&rp, (size_t)o->R * sizeof(int)));
         std::vector<int> hv(o->R);
         OP_TRY(hipMemcpyAsync(hv.data(), o->row_valid, (size_t)o->R * sizeof(int), hipMemcpyDeviceToHost, s));
         OP_TRY(hipStreamSynchronize(s));
@@ -1224,12 +1239,7 @@ int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
     a.resid = o->resid; a.ldr = o->N; a.relu_pre = o->relu_pre; a.ln_g = o->ln_gamma; a.ln_b = o->ln_beta; a.ln_eps = o->ln_eps;
     a.act_post = o->act_post; a.dot_w = o->dot_w; a.dot_b = o->dot_b; a.dot_out = o->dot_out;
     a.xp_scratch = xps;
-    int rc = launch_gemm(nullptr, s, "op.conv_gemm", a, o->precision);
-    hipStreamSynchronize(s);
-    hipFree(g.w); hipFree(g.wb); hipFree(scratch);
-    if (xps) hipFree(xps);
-    if (rp) hipFree(rp);
-    return rc;
+    return launch_gemm(nullptr, s, "op.conv_gemm", a, o->precision);      // (tmp drains the stream and frees)
 }
 
 int fs2_op_attention(void* stream, const float* qkv, float* ctx, int32_t D, int32_t heads, int32_t B, const int32_t* seq_start,
@@ -1249,8 +1259,9 @@ int fs2_op_attention(void* stream, const float* qkv, float* ctx, int32_t D, int3
     host.insert(host.end(), seq_len, seq_len + B);
     host.insert(host.end(), seq_klen, seq_klen + B);
     for (auto& w : work) { host.push_back(w.x); host.push_back(w.y); }
+    DevTmp tmp(s);
     int* dev = nullptr;
-    OP_TRY(hipMalloc((void**)&dev, host.size() * sizeof(int) + 16));
+    OP_TRY(tmp.alloc((void**)&dev, host.size() * sizeof(int) + 16));
     OP_TRY(hipMemcpyAsync(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
     DevLayout dl;
     dl.start = dev; dl.len = dev + B; dl.klen = dev + 2 * B; dl.work = reinterpret_cast<int2*>(dev + 3 * B);
@@ -1260,15 +1271,11 @@ int fs2_op_attention(void* stream, const float* qkv, float* ctx, int32_t D, int3
     } else {
         const int Rvt = round_up(R, 128);
         __bf16* planes = nullptr;
-        OP_TRY(hipMalloc((void**)&planes, (size_t)Rvt * D * 6 * sizeof(__bf16)));
+        OP_TRY(tmp.alloc((void**)&planes, (size_t)Rvt * D * 6 * sizeof(__bf16)));
         __bf16 *qkh = planes, *qkl = planes + (size_t)Rvt * 2 * D, *vth = qkl + (size_t)Rvt * 2 * D, *vtl = vth + (size_t)Rvt * D;
         rc = launch_attention_b16(nullptr, s, "op.attention", qkv, ctx, D, heads, R, Rvt, dl, (int)work.size(), mask_q, 0.0, precision, qkh, qkl, vth, vtl);
-        hipStreamSynchronize(s);
-        hipFree(planes);
     }
-    hipStreamSynchronize(s);
-    hipFree(dev);
-    return rc;
+    return rc;      // (tmp drains the stream and frees)
 }
 
 int fs2_op_length_regulate(void* stream, const float* hs, const int64_t* ds, const int64_t* ilens_host, int32_t B, int32_t Tmax,
@@ -1277,8 +1284,9 @@ int fs2_op_length_regulate(void* stream, const float* hs, const int64_t* ds, con
     hipStream_t s = (hipStream_t)stream;
     std::vector<int> host(2 * B);
     for (int b = 0; b < B; ++b) { host[b] = b * Tmax; host[B + b] = (int)ilens_host[b]; }
+    DevTmp tmp(s);
     int* dev = nullptr;
-    OP_TRY(hipMalloc((void**)&dev, ((size_t)3 * B + (size_t)B * Tmax) * sizeof(int)));
+    OP_TRY(tmp.alloc((void**)&dev, ((size_t)3 * B + (size_t)B * Tmax) * sizeof(int)));
     OP_TRY(hipMemcpyAsync(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
     int *tok_start = dev, *ilen = dev + B, *o32 = dev + 2 * B, *cum = dev + 3 * B;
     hipLaunchKernelGGL(dur_scan, dim3(B), dim3(256), 0, s, ds, Tmax, ilen, cum, olens, o32);
@@ -1286,8 +1294,6 @@ int fs2_op_length_regulate(void* stream, const float* hs, const int64_t* ds, con
     hipLaunchKernelGGL(lr_expand, dim3((R + 3) / 4), dim3(256), 0, s, hs, D, tok_start, ilen, cum, Tmax, (const int*)nullptr,
                        (const int*)nullptr, Lmax, o32, R, out, index);
     hipError_t e = hipGetLastError();
-    hipStreamSynchronize(s);
-    hipFree(dev);
     if (e != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "length_regulate: %s", hipGetErrorString(e));
     return FS2_OK;
 }
