@@ -146,26 +146,29 @@ struct Scope {
     ~Scope() { if (idx != (size_t)-1) hipEventRecord(h->recs[idx].e1, s); }
 };
 
+// Kernels that need more than 64 KB of dynamic LDS must raise their limit once per (kernel, device); the flags live at the
+// call site (one array per kernel instantiation), indexed by the current device.
+struct LdsAttr { bool done[32] = {}; };
+inline void allow_lds(const void* kernel, size_t bytes, LdsAttr& st) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    bool& d = st.done[dev & 31];
+    if (!d) { hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); d = true; }
+}
+
 // ------------------------------------------------------------------ kernel launchers
 template <int NT>
 hipError_t launch_rows(hipStream_t s, const GemmArgs& a) {
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_f32<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)rows_lds_bytes<NT>());
-        attr = true;
-    }
+    static LdsAttr attr;
+    allow_lds(reinterpret_cast<const void*>(&gemm_rows_f32<NT>), rows_lds_bytes<NT>(), attr);
     dim3 grid((a.R + kRowsBM - 1) / kRowsBM);
     hipLaunchKernelGGL(gemm_rows_f32<NT>, grid, dim3(256), rows_lds_bytes<NT>(), s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_tile(hipStream_t s, const GemmArgs& a) {
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds);
-        attr = true;
-    }
+    static LdsAttr attr;
+    allow_lds(reinterpret_cast<const void*>(&gemm_tile_f32), kTileLds, attr);
     dim3 grid((a.R + kTileBM - 1) / kTileBM, (a.N + kTileBN - 1) / kTileBN);
     hipLaunchKernelGGL(gemm_tile_f32, grid, dim3(256), kTileLds, s, a);
     return hipGetLastError();
@@ -175,12 +178,9 @@ bool rows_supported(int N) { return N == 80 || N == 256 || N == 384; }
 
 template <int NSPLIT, int BM, bool K1>
 hipError_t launch_pl_t(hipStream_t s, const GemmArgs& a) {
-    static bool attr = false;
+    static LdsAttr attr;
     constexpr size_t lds = pl_lds_bytes<BM, K1>();
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pl_bf16<NSPLIT, BM, K1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    allow_lds(reinterpret_cast<const void*>(&gemm_pl_bf16<NSPLIT, BM, K1>), lds, attr);
     dim3 grid((a.N + kB16BN - 1) / kB16BN, ((a.qk_hi ? a.Rvt : a.R) + BM - 1) / BM);
     hipLaunchKernelGGL((gemm_pl_bf16<NSPLIT, BM, K1>), grid, dim3(256), lds, s, a);
     return hipGetLastError();
@@ -188,24 +188,18 @@ hipError_t launch_pl_t(hipStream_t s, const GemmArgs& a) {
 
 template <int NSPLIT, int NB>
 hipError_t launch_row8_t(hipStream_t s, const GemmArgs& a) {
-    static bool attr = false;
+    static LdsAttr attr;
     constexpr size_t lds = row8_lds_bytes<NB>();
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_row8_bf16<NSPLIT, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    allow_lds(reinterpret_cast<const void*>(&gemm_row8_bf16<NSPLIT, NB>), lds, attr);
     hipLaunchKernelGGL((gemm_row8_bf16<NSPLIT, NB>), dim3((a.R + 127) / 128), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
 template <int NSPLIT, int NB>
 hipError_t launch_qkv8_t(hipStream_t s, const GemmArgs& a) {
-    static bool attr = false;
+    static LdsAttr attr;
     constexpr size_t lds = row8_lds_bytes<NB>();
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_qkv8_bf16<NSPLIT, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    allow_lds(reinterpret_cast<const void*>(&gemm_qkv8_bf16<NSPLIT, NB>), lds, attr);
     hipLaunchKernelGGL((gemm_qkv8_bf16<NSPLIT, NB>), dim3((a.Rvt + 127) / 128), dim3(512), lds, s, a);
     return hipGetLastError();
 }
@@ -348,16 +342,16 @@ int launch_attention(fs2_handle* h, hipStream_t s, const char* name, const float
     Scope sc(h, s, name, flops, 0.0);
     dim3 grid(nwork, heads);
     if (dk == 128) {
-        static bool attr = false;
-        if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds_bytes<128>()); attr = true; }
+        static LdsAttr attr;
+        allow_lds(reinterpret_cast<const void*>(&attn_f32<128>), attn_lds_bytes<128>(), attr);
         hipLaunchKernelGGL(attn_f32<128>, grid, dim3(256), attn_lds_bytes<128>(), s, a);
     } else if (dk == 192) {
-        static bool attr = false;
-        if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32<192>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds_bytes<192>()); attr = true; }
+        static LdsAttr attr;
+        allow_lds(reinterpret_cast<const void*>(&attn_f32<192>), attn_lds_bytes<192>(), attr);
         hipLaunchKernelGGL(attn_f32<192>, grid, dim3(256), attn_lds_bytes<192>(), s, a);
     } else if (dk == 64) {
-        static bool attr = false;
-        if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds_bytes<64>()); attr = true; }
+        static LdsAttr attr;
+        allow_lds(reinterpret_cast<const void*>(&attn_f32<64>), attn_lds_bytes<64>(), attr);
         hipLaunchKernelGGL(attn_f32<64>, grid, dim3(256), attn_lds_bytes<64>(), s, a);
     } else {
         return fail(h, FS2_ERR_UNSUPPORTED, "attention head dim %d not in {64,128,192}", dk);
@@ -369,11 +363,8 @@ int launch_attention(fs2_handle* h, hipStream_t s, const char* name, const float
 
 template <int DK, int NSPLIT>
 hipError_t launch_attn_b16_t(hipStream_t s, dim3 grid, const AttnB16Args& a) {
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16<DK, NSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_b16_lds_bytes<DK>());
-        attr = true;
-    }
+    static LdsAttr attr;
+    allow_lds(reinterpret_cast<const void*>(&attn_bf16<DK, NSPLIT>), attn_b16_lds_bytes<DK>(), attr);
     hipLaunchKernelGGL((attn_bf16<DK, NSPLIT>), grid, dim3(256), attn_b16_lds_bytes<DK>(), s, a);
     return hipGetLastError();
 }
@@ -388,8 +379,8 @@ int launch_attention_b16(fs2_handle* h, hipStream_t s, const char* name, const f
         char nm[112];
         snprintf(nm, sizeof nm, "%s.split", name);
         Scope sc(h, s, nm, 0.0, 4.0 * R * 3.0 * D * 2);
-        static bool attr = false;
-        if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_split), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (1024 + 1) * 4); attr = true; }
+        static LdsAttr attr;
+        allow_lds(reinterpret_cast<const void*>(&qkv_split), 32 * (1024 + 1) * 4, attr);
         QkvSplitArgs q;
         q.qkv = qkv; q.R = R; q.Rvt = Rvt; q.D = D; q.dk = dk; q.scale = 1.4426950408889634f / sqrtf((float)dk);   // log2(e)/sqrt(d_k): softmax in base 2
         q.qk_hi = qkh; q.qk_lo = qkl; q.vt_hi = vth; q.vt_lo = vtl;
