@@ -235,7 +235,7 @@ def main():
                   file=sys.stderr)
 
     if rank == 0:
-        from oracle import fs2_oracle as O
+        from fastspeech2_amd.parallel import path_flops
         line = {
             "metric": "mel-frames/sec", "value": round(total_frames * args.steps / dt, 1), "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -244,12 +244,13 @@ def main():
             "config": {"workload": "%s: batch=%d LJSpeech-shape per GPU, default.yaml dims, free-running, random-init weights (seed 0), "
                                    "duration bias ln(1+7.87)" % (args.workload, B),
                        "utterances_per_gpu": B, "valid_frames_per_step": total_frames, "phonemes_per_gpu": ntok,
-                       "algorithmic_gflop_per_step_per_gpu": round(sum(O.flops(int(t), int(l)) for t, l in zip(il, model.last_olens)) / 1e9, 1),
+                       "algorithmic_gflop_per_step_per_gpu": round(sum(path_flops(int(t), int(l)) for t, l in zip(il, model.last_olens)) / 1e9, 1),
                        "parallelism": "utterance-sharded x%d, all-gather(mels) over RCCL" % world if world > 1 else "single GPU",
                        "launch": "HIP graph replay" if graph_run is not None else ("eager, host-driven layout" if ((use_dist and dist_caps is None) or args.profile_kernels) else "eager, device-driven layout (no host sync)")},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:      # the only leg of this script that touches oracle/ (as the measured CPU baseline and the checker)
+            from oracle import fs2_oracle as O
             cfg = O.config_from_hp(hp, N_PHONEME_SYMBOLS, odim)
             with torch.no_grad():
                 d_pred = model._run(xs, il, is_inference=True, want=("after",))["d_int"].cpu()

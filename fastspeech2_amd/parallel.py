@@ -11,6 +11,13 @@ import torch
 import torch.distributed as dist
 
 
+def path_flops(T, L):
+    """Algorithmic FLOPs of the path for one utterance of T phonemes and L frames, default dims, valid positions only
+    (SURVEY.md section 8d): T (23,855,616 + 4,096 T) + L (40,383,488 + 6,144 L)."""
+    T, L = float(T), float(L)
+    return T * (23855616.0 + 4096.0 * T) + L * (40383488.0 + 6144.0 * L)
+
+
 def utterance_cost(T, frames_per_token=7.87):
     """Relative cost model of one utterance from its phoneme count (SURVEY.md section 8d FLOPs formula with
     L ~= 7.87 T): dominated by the decoder, 40.4 MFLOP/frame + 6144 L^2 attention."""
