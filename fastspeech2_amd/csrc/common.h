@@ -54,6 +54,10 @@ struct GemmArgs {
     // build them from X when the producer did not; Yp: output planes (yp_chunks 32-channel chunks per row), written
     // by the epilogue next to / instead of Y.
     const void* Xp; void* xp_scratch; void* Yp; int yp_chunks;
+    // deterministic split-K of the k = 1 form (small grids with a long K: the loop is a serial chain of k-steps): workgroup z of
+    // grid.z accumulates chunks [z, z+1) * Cpad/32/ksplit; split 0 (which also adds bias + residual) writes Y, split z > 0 writes
+    // kpart + (z-1) * kpart_stride; the row kernel that follows (ln_rows) adds the partials in a fixed order
+    int ksplit; float* kpart; size_t kpart_stride;
     const int* Rp;                         // device-driven layout: rows actually used (tiles at or beyond round_up(*Rp, 128) exit at once); nullptr: R
 };
 

@@ -181,7 +181,7 @@ hipError_t launch_pl_t(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
     constexpr size_t lds = pl_lds_bytes<BM, K1>();
     allow_lds(reinterpret_cast<const void*>(&gemm_pl_bf16<NSPLIT, BM, K1>), lds, attr);
-    dim3 grid((a.N + kB16BN - 1) / kB16BN, ((a.qk_hi ? a.Rvt : a.R) + BM - 1) / BM);
+    dim3 grid((a.N + kB16BN - 1) / kB16BN, ((a.qk_hi ? a.Rvt : a.R) + BM - 1) / BM, (K1 && a.ksplit > 1) ? a.ksplit : 1);
     hipLaunchKernelGGL((gemm_pl_bf16<NSPLIT, BM, K1>), grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }
@@ -263,6 +263,18 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         if (!t.Y && y_needed) return fail(h, FS2_ERR_ARG, "%s: no output or scratch buffer", name);
         if (t.qk_hi && (a.ktaps != 1 || a.att_D % kB16BN != 0 || a.N != 3 * a.att_D)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: fused QKV split needs D %% 128 == 0", name);
         if (need_rows && !row8) { t.act_post = 0; t.Yp = nullptr; }      // the row kernel writes the planes
+        // split-K: a k = 1 GEMM with a long K on a grid that leaves CUs idle is a serial chain of k-steps; 2-4 workgroups share it and
+        // ln_rows (which follows anyway) adds their partial sums in a fixed order (deterministic, unlike atomics)
+        t.ksplit = 1;
+        if (need_rows && !row8 && a.ktaps == 1 && a.kpart && !getenv("FS2_NOSPLITK")) {
+            const int nchunks = a.Cpad / 32;
+            const long wgs = (long)((a.N + kB16BN - 1) / kB16BN) * ((a.R + 63) / 64);
+            int ksp = 1;
+            for (int cand = 4; cand >= 2; --cand)
+                if (nchunks % cand == 0 && nchunks / cand >= 4 && wgs * cand <= 1024 && cand - 1 <= a.ksplit) { ksp = cand; break; }
+            t.ksplit = ksp;
+            t.kpart_stride = (size_t)a.R * t.ldy;
+        }
         if (!a.Xp) {
             char nm[112];
             snprintf(nm, sizeof nm, "%s.planes", name);
@@ -286,7 +298,7 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
             snprintf(nm, sizeof nm, "%s.rows", name);
             Scope sc(h, s, nm, 0.0, 8.0 * a.R * a.N);
             GemmArgs r = a;
-            r.Y = t.Y; r.ldy = t.ldy;
+            r.Y = t.Y; r.ldy = t.ldy; r.ksplit = t.ksplit; r.kpart_stride = t.kpart_stride;
             hipLaunchKernelGGL(ln_rows, dim3((a.R + 3) / 4), dim3(256), 0, s, r);
             e = hipGetLastError();
         }
@@ -506,7 +518,7 @@ struct StackBufs { float *x0, *x1, *qkv, *ctx, *hid; __bf16 *qkh, *qkl, *vth, *v
 
 // x0 holds the input; returns the buffer holding the output (x0 again).
 int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, int D, int heads, int R,
-              const HostLayout& L, const DevLayout& dl, int mask_q, const StackBufs& b, int prec, bool x0p_ready = false) {
+              const HostLayout& L, const DevLayout& dl, int mask_q, const StackBufs& b, int prec, bool x0p_ready = false, bool allow_splitk = false) {
     char nm[96];
     double att_flops = 0;
     for (size_t i = 0; i < L.klen.size(); ++i) att_flops += 4.0 * D * (double)L.klen[i] * std::min(L.len[i], mask_q ? L.klen[i] : L.len[i]);
@@ -542,6 +554,9 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         a.Rp = dl.dims;
         a.resid = b.x0; a.ldr = D; a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
         if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; }
+        // split-K partials go to the fp32 QKV buffer, idle from here on.  Only where the row count is the same in the host- and the
+        // device-driven layout (the token-level stack): the choice of the split depends on it, and the two layouts must agree bit for bit
+        if (pl && allow_splitk) { a.kpart = b.qkv; a.ksplit = 3; }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.ffn1", tag);
         a = gemm_args(ly.w1, b.x1, D, R, dl.row_pos, pl ? nullptr : b.hid, ly.w1.N);
@@ -554,6 +569,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         a.Rp = dl.dims;
         a.resid = b.x1; a.ldr = D; a.ln_g = ly.ln2g; a.ln_b = ly.ln2b; a.ln_eps = 1e-5f;
         if (pl) { a.Xp = hidp; a.Yp = b.x0p; a.yp_chunks = D / 32; }
+        if (pl && allow_splitk) { a.kpart = b.qkv; a.ksplit = 3; }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
     }
     return FS2_OK;
@@ -985,7 +1001,7 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
                            enc_pl && c.adim % 32 == 0 ? sb.x0p : nullptr);
         HIP_TRY(h, hipGetLastError());
     }
-    if ((rc = run_stack(h, s, "enc", h->enc, c.adim, c.aheads, L.R, L, dl, /*mask_q=*/1, sb, b.precision, /*x0p_ready=*/enc_pl && c.adim % 32 == 0))) return rc;
+    if ((rc = run_stack(h, s, "enc", h->enc, c.adim, c.aheads, L.R, L, dl, /*mask_q=*/1, sb, b.precision, /*x0p_ready=*/enc_pl && c.adim % 32 == 0, /*allow_splitk=*/true))) return rc;
     if ((rc = run_predictor(h, s, "dur", h->dur, sb.x0, c.adim, L.R, dl.row_pos, p0, p1, dlog_rows, b.precision, enc_pl ? sb.x0p : nullptr, sb.xps))) return rc;
     {
         Scope sc(h, s, "dur.post", 0, 0);

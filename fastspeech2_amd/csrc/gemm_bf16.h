@@ -124,6 +124,11 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
     for (int j = 0; j < 4; ++j) {
         const int c = lane * 4 + j * 256;
         v[j] = (c < a.N) ? *reinterpret_cast<const float4*>(y + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < a.N)
+            for (int z = 1; z < a.ksplit; ++z) {      // split-K partials of the GEMM, added in a fixed order
+                const float4 q = *reinterpret_cast<const float4*>(a.kpart + (size_t)(z - 1) * a.kpart_stride + (size_t)row * a.ldy + c);
+                v[j].x += q.x; v[j].y += q.y; v[j].z += q.z; v[j].w += q.w;
+            }
         s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
     }
     if (a.ln_g) {

@@ -149,35 +149,40 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
             dma16(src + (u & 1) * b_o1 + (u >> 1) * b_o2, dst + u * 4096);
     };
 
-    dma_A(0, 0);
-    dma_B(0, 0);
+    // split-K (k = 1 form only): this workgroup's share of the 32-channel chunks
+    const int ks = (K1 && a.ksplit > 1) ? (int)blockIdx.z : 0;
+    const int c_begin = (K1 && a.ksplit > 1) ? ks * (nchunks / a.ksplit) : 0;
+    const int c_end = (K1 && a.ksplit > 1) ? c_begin + nchunks / a.ksplit : nchunks;
+    const int it_end = c_end * ktaps;
+    dma_A(c_begin, K1 ? (c_begin & 1) : 0);
+    dma_B(c_begin * ktaps, (c_begin * ktaps) & 1);
     // The accumulators start at bias + residual (loaded while the first tiles are in flight), so the epilogue has no
     // loads on its critical path: acc[mt][nt][r] belongs to row (mt, r), channel col + nt.
     const int col = n0 + wn * 64 + 4 * lr;    // this lane's four consecutive output channels
     f32x4 acc[MT][4];
     {
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.bias && col < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+        if (a.bias && col < a.N && ks == 0) bv = *reinterpret_cast<const f32x4*>(a.bias + col);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * (BM / 2) + mt * 16 + rperm(lg * 4 + r);
                 f32x4 v = bv;
-                if (a.resid && row < a.R && col < a.N) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
+                if (a.resid && ks == 0 && row < a.R && col < a.N) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[mt][nt][r] = v[nt];
             }
     }
-    int it = 0;
+    int it = c_begin * ktaps;
 #ifdef FS2_GEMM_TIMING
     long long tprev = __builtin_readcyclecounter();
 #endif
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
         for (int tap = 0; tap < ktaps; ++tap, ++it) {
             dma_barrier();     // DMA of step `it` landed; every wave is done with step it-1
             FS2_GT(0)
-            if (it + 1 < niter) {
+            if (it + 1 < it_end) {
                 dma_B(it + 1, (it + 1) & 1);
                 if (K1) dma_A(it + 1, (it + 1) & 1);
             }
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
             }
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
             FS2_GT(2)
-            if (!K1 && tap == ktaps - 1 && chunk + 1 < nchunks) {
+            if (!K1 && tap == ktaps - 1 && chunk + 1 < c_end) {
                 __syncthreads();              // every wave has read its last fragments of this chunk's A tile
                 dma_A(chunk + 1, 0);
                 FS2_GT(3)
@@ -252,6 +257,13 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
             vt_tile_store<BM>(a, tile, m0, n0, tid);
             return;
         }
+    }
+    if (K1 && ks > 0) {          // split-K partial: raw sums into this split's buffer (same row stride as Y)
+        GemmArgs p = a;
+        p.Y = a.kpart + (size_t)(ks - 1) * a.kpart_stride;
+        p.Yp = nullptr; p.relu_pre = 0; p.act_post = 0;
+        pl_epilogue<MT>(p, acc, m0 + wm * (BM / 2), col, lg);
+        return;
     }
     pl_epilogue<MT>(a, acc, m0 + wm * (BM / 2), col, lg);
 }
