@@ -4,8 +4,8 @@ The reference has no distributed code at all.  Utterance
 (per-utterance semantics), weights are small (~130 MB) and replicated, so the path shards by independent
 units: every rank holds the (tiny) id batch, takes a cost-balanced subset of the utterances, runs the
 single-GPU path on it, and the only exchange is an all-gather of the final mels over RCCL/xGMI (backend
-"nccl" on ROCm; "gloo" in the CPU tests).  Results are bit-identical to the single-GPU result because
-per-utterance outputs do not depend on batch-mates.
+"nccl" on ROCm; "gloo" in the CPU tests).  The gather and the order restoration are exact; an utterance's values do not
+depend on its batch-mates (only, in the last bits, on the size-dependent kernel variants: DESIGN.md section 1).
 """
 import torch
 import torch.distributed as dist
