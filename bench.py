@@ -219,10 +219,10 @@ def main():
                     share_of_kernel_time=round(scout[dom_name] / kernel_ms_per_step, 3),
                     kernel_ms_per_step=round(kernel_ms_per_step, 3))
     try:    # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01e_traffic.json")))
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01f_traffic.json")))
         if tr["workload"] == args.workload and tr["precision"] == args.precision and tr["kernel_site"] == dom_name and world == 1:
             roofline["traffic"] = tr["traffic_bytes"]
-            roofline["traffic_note"] = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r01e_traffic.json; algorithmic HBM bytes %d" % tr["algorithmic_bytes"]
+            roofline["traffic_note"] = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r01f_traffic.json; algorithmic HBM bytes %d" % tr["algorithmic_bytes"]
     except (OSError, KeyError, ValueError):
         pass
     if args.precision == "bf16x3":   # three MFMAs are issued per algorithmic product
