@@ -7,15 +7,21 @@
 One "step" = one full free-running forward of the hot path over one synthetic batch already resident in
 HBM: phoneme ids -> encoder -> duration predictor -> length regulator -> pitch/energy -> decoder -> mel
 projection -> Postnet -> padded mels (and, for N > 1, the RCCL all-gather of the mels over xGMI).
-Workload at every N: BASELINE config c3 per GPU ("batch=64 LJSpeech-shape", the config the >=50x-CPU
-target is quoted on), i.e. weak scaling: rank r synthesises its own 64 utterances and all ranks end up
-with all 64*N mels.  Random-init default model (portable generator, seed 0) with the duration bias set
-so that predicted durations are LJSpeech-like; there is no network for real
-checkpoints or datasets.  value = valid mel frames of all ranks / max-over-ranks wall time.
+
+Workloads (BASELINE.json configs, fastspeech2_amd/synthetic.py):
+  N = 1 : c3, "batch=64 LJSpeech-shape" -- the config the >= 50x-CPU target is quoted on.
+  N > 1 : c5, "batch=1024 sharded 8 x MI355X, RCCL all-gather of the mels": ONE global batch of 128 * N utterances (N = 8: the
+          whole of c5), dealt to the ranks by the cost model (LPT, `shard_indices`: shards of unequal size), every rank
+          synthesises its shard without ever waiting for the host and ONE all-gather returns all mels, in order, to every
+          rank (`ShardedSynthesizer`).  Weak scaling: the work per GPU is constant in N.
+Random-init default model (portable generator, seed 0) with the duration bias set so that predicted durations are
+LJSpeech-like; there is no network for real checkpoints or datasets.
+value = valid mel frames of the global batch / max-over-ranks wall time of exactly K steps.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -25,16 +31,26 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
-DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3", "bf16": "bf16"}
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "mixed": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
+DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3", "bf16": "bf16", "mixed": "bf16x3+f16x2"}
+HBM_PEAK_GBPS = 8000.0
+WORKLOAD_TEXT = {
+    "c1": "c1: 1 utterance, 80 phonemes",
+    "c2": "c2: batch=16 synthetic phoneme seqs len 64-128",
+    "c3": "c3: batch=64 LJSpeech-shape",
+    "c4": "c4: batch=256 mixed-length (32-512 phonemes) with Postnet, length-regulator stress",
+    "c5": "c5: batch=1024 LJSpeech-shape sharded over 8 GPUs (128 per GPU)",
+}
 
 
-def cpu_baseline(sd, cfg, batch, gpu_after, budget_s=14.0):
-    """Times the CPU oracle (the validated port of the reference's fp32 PyTorch path) on the host cores,
-    on a bounded sample of the same batch: (i) per-utterance loop of B=1 calls, (ii) one padded batch of
-    16 utterances; returns the faster in mel-frames/s plus the measured mel max-abs diff GPU vs oracle."""
+def cpu_baseline(sd, cfg, batch, gpu, budget_s=14.0):
+    """Times the CPU oracle (the validated port of the reference's fp32 PyTorch path) on the host cores, on a bounded
+    sample of the same batch: (i) per-utterance loop of B=1 calls, (ii) one padded batch of 16 utterances; returns the faster
+    in mel-frames/s, the measured mel max-abs diff GPU vs oracle (durations forced to the GPU's, so that frames align), and the
+    free-running decision statistics (SURVEY.md hard part 2): how often the data-dependent integer decisions of the GPU path
+    -- durations clamp(round(exp(x) - 1)), frame counts, pitch / energy bucket indices -- equal the CPU path's."""
     from oracle import fs2_oracle as O
-    xs, il, ds = batch["xs"], batch["ilens"], batch["ds_pred"]
+    xs, il, ds = batch["xs"], batch["ilens"], gpu["d_int"]
     B = xs.shape[0]
     # Pick the thread count that is fastest for this op mix (small GEMM/conv calls: all logical cores of a
     # 2-socket host oversubscribe badly), so that the CPU side is not handicapped.
@@ -59,7 +75,7 @@ def cpu_baseline(sd, cfg, batch, gpu_after, budget_s=14.0):
         L = int(o["olens"][0])
         frames += L
         n += 1
-        worst = max(worst, float((o["after"][0] - gpu_after[b, :L]).abs().max()))
+        worst = max(worst, float((o["after"][0] - gpu["after"][b, :L]).abs().max()))
         if time.perf_counter() - t0 > budget_s:
             break
     per_utt = frames / (time.perf_counter() - t0)
@@ -69,10 +85,31 @@ def cpu_baseline(sd, cfg, batch, gpu_after, budget_s=14.0):
     o = O.padded_forward(sd, cfg, xs[:nb, :Tm], il[:nb], is_inference=True, d_override=ds[:nb, :Tm])
     padded = int(o["olens"].sum()) / (time.perf_counter() - t1)
     best = max(per_utt, padded)
+    # free-running: nothing forced; the oracle makes its own decisions
+    t2 = time.perf_counter()
+    tok = tok_eq = utt = utt_eq = fr = qe_eq = qp_eq = 0
+    for b in range(B):
+        T = int(il[b])
+        o = O.padded_forward(sd, cfg, xs[b:b + 1, :T], il[b:b + 1], is_inference=True)
+        same = o["d_outs"][0, :T] == ds[b, :T]
+        tok += T
+        tok_eq += int(same.sum())
+        utt += 1
+        utt_eq += int(int(o["olens"][0]) == int(gpu["olens"][b]))
+        if bool(same.all()):          # frames align one to one: compare the bucket indices actually embedded
+            L = int(o["olens"][0])
+            fr += L
+            qe_eq += int((o["qe"][0, :L] == gpu["qe"][b, :L]).sum())
+            qp_eq += int((o["qp"][0, :L] == gpu["qp"][b, :L]).sum())
+        if time.perf_counter() - t2 > 8.0:
+            break
+    flips = dict(utterances_compared=utt, dur_exact_rate=round(tok_eq / max(tok, 1), 6), olens_exact_rate=round(utt_eq / max(utt, 1), 6),
+                 qe_agree_rate=round(qe_eq / max(fr, 1), 6), qp_agree_rate=round(qp_eq / max(fr, 1), 6), frames_compared=fr,
+                 note="free-running GPU vs free-running CPU oracle; bucket indices compared on utterances whose durations all agree")
     return dict(value=round(best, 1), unit="mel-frames/s", cores=torch.get_num_threads(), kind="port",
-                sample="oracle (validated fp32 PyTorch port of the reference path) on the c3 batch: per-utterance loop over the "
-                       "first %d utterances (%d frames) = %.0f fr/s; one padded batch of %d = %.0f fr/s; faster quoted" %
-                       (n, frames, per_utt, nb, padded)), worst
+                sample="oracle (validated fp32 PyTorch port of the reference path; measured equal to the real reference within noise, "
+                       "BASELINE.md section 3) on the c3 batch: per-utterance loop over the first %d utterances (%d frames) = %.0f fr/s; "
+                       "one padded batch of %d = %.0f fr/s; faster quoted" % (n, frames, per_utt, nb, padded)), worst, flips
 
 
 def main():
@@ -80,7 +117,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--workload", default=None, help="c1..c5 (default: c3 on one GPU, c5 = 128 utterances per GPU on several)")
     ap.add_argument("--precision", default=os.environ.get("FS2_PRECISION", "bf16x3"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-kernels", action="store_true", help="print the per-kernel hipEvent table to stderr")
@@ -100,9 +137,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    workload = args.workload or ("c5" if use_dist else "c3")
 
     from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
-    from fastspeech2_amd.parallel import gather_packed, gather_packed_async
+    from fastspeech2_amd.parallel import ShardedSynthesizer, shard_indices, path_flops
     from fastspeech2_amd.synthetic import portable_state_dict, bias_durations, make_batch
 
     hp = default_hparams()
@@ -113,47 +151,49 @@ def main():
     model = model.to(dev)
     model.precision = args.precision
 
-    seed0 = {"c1": 1, "c2": 2, "c3": 3, "c4": 4, "c5": 5}[args.workload]
-    batch = make_batch(args.workload, seed=seed0 + 101 * rank)
+    # ONE global batch, identical on every rank (numpy RandomState, seed = config number).  c5 is cut to 128 utterances per
+    # GPU when fewer than 8 GPUs run it, so the work per GPU does not depend on N (weak scaling); 8 GPUs run all 1024.
+    if workload == "c5":
+        batch = make_batch("c5", B=128 * world)
+    else:
+        batch = make_batch(workload)
     xs, il = batch["xs"].to(dev), batch["ilens"]
     B = xs.shape[0]
-    index = list(range(rank * B, (rank + 1) * B))
+    parts = shard_indices(il.tolist(), world)
+    mine = parts[rank]
+    synth = ShardedSynthesizer(model) if use_dist else None
 
     graph_run = None
-    dist_caps = None
-    index_dev = torch.tensor(index, dtype=torch.int64, device=dev)
 
     def step():
         if graph_run is not None:
             mel_, ol_, _ = graph_run(xs)
             return mel_, ol_
-        if not use_dist:
-            # nothing on the host waits for the GPU: the frame layout is built on the device (fs2_decode's device-driven
-            # mode); the very first call is synchronous and teaches the capacity predictor the frames-per-phoneme ratio
-            # (--profile-kernels uses the host-driven layout so that the per-site FLOP counts are those of the rows in use)
-            return model.inference_batch(xs, il, sync=args.profile_kernels)
-        if dist_caps is None:
-            packed, olens = model.inference_batch(xs, il, packed=True)          # valid frames only travel over xGMI
-            return gather_packed(packed, olens, index, B * world)
-        # sync-free: device-driven layout inside capacities agreed between the ranks once, packs of equal capacity all-gathered
-        packed, olens = model.inference_batch(xs, il, packed=True, sync=False, capacity=dist_caps)
-        return gather_packed_async(packed, olens, index_dev, B * world, dist_caps[1])
+        if synth is not None:
+            # LPT shard -> sync-free single-GPU path -> one all-gather (packs + frame counts) -> ordered padded mels on every rank
+            return synth(xs, il, sync=args.profile_kernels)
+        # nothing on the host waits for the GPU: the frame layout is built on the device (fs2_decode's device-driven
+        # mode); the very first call is synchronous and teaches the capacity predictor the frames-per-phoneme ratio
+        # (--profile-kernels uses the host-driven layout so that the per-site FLOP counts are those of the rows in use)
+        return model.inference_batch(xs, il, sync=args.profile_kernels)
+
+    def all_ok():
+        if graph_run is not None:
+            return int(graph_run(xs)[2].cpu()[2]) == 0
+        if args.profile_kernels:
+            return True
+        return synth.ok() if synth is not None else model.async_ok()
 
     with torch.no_grad():
-        mel, olens_all = step()                      # first call: synchronous, builds the handle
+        mel, olens_all = step()                      # first call: synchronous, builds the handle, learns the frame ratio
         if args.graph and not use_dist and not args.profile_kernels:
             graph_run = model.capture_graph(xs, il)
-        if use_dist and not args.profile_kernels and not os.environ.get("FS2_DIST_SYNC"):
-            # one exchange outside the timed region: every rank's predicted capacities -> the maximum, used by all
-            caps = torch.tensor(model.predict_capacity(il), dtype=torch.int64, device=dev)
-            dist.all_reduce(caps, op=dist.ReduceOp.MAX)
-            dist_caps = (int(caps[0]), int(caps[1]))
         for _ in range(max(args.warmup, 1)):
             mel, olens_all = step()
-        if not use_dist and not args.profile_kernels and graph_run is None:
-            assert model.async_ok(), "capacities of the asynchronous path were exceeded during warm-up"
-        local_frames = int(model.last_olens.sum())
+        assert all_ok(), "capacities of the asynchronous path were exceeded during warm-up"
         total_frames = int(olens_all.sum())
+        local_frames = int(olens_all.cpu()[torch.as_tensor(mine, dtype=torch.int64)].sum()) if mine else 0
+        local_tokens = int(il[torch.as_tensor(mine, dtype=torch.int64)].sum()) if mine else 0
         # find the dominant launch site with one fully bracketed (untimed) step, then bracket only that site
         # inside the timed region so that hipEvent records do not perturb the measurement
         model.set_profiling(True)
@@ -162,29 +202,29 @@ def main():
         else:
             step()
         torch.cuda.synchronize()
-        scout = {}
+        scout, scout_n = {}, {}
         scout_prof = model.get_profile()
         for name, ms, fl, by in scout_prof:
             scout[name] = scout.get(name, 0.0) + ms
+            scout_n[name] = scout_n.get(name, 0) + 1
         dom_site = max(scout.items(), key=lambda kv: kv[1])[0]
         kernel_ms_per_step = sum(scout.values())
         model.set_profiling(True, only=None if args.profile_kernels else dom_site)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        ev[0].record()
+        for i in range(args.steps):
             mel, olens_all = step()
+            ev[i + 1].record()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if dist_caps is not None:
-            assert model.async_ok(), "capacities of the asynchronous path were exceeded in the timed region"
-        if graph_run is not None:
-            assert int(graph_run(xs)[2].cpu()[2]) == 0, "capacities captured with the graph were exceeded"
-        elif not use_dist and not args.profile_kernels:
-            assert model.async_ok(), "capacities of the asynchronous path were exceeded in the timed region"
+        assert all_ok(), "capacities of the asynchronous path were exceeded in the timed region"
+        step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
         prof = model.get_profile() if graph_run is None else scout_prof      # (graph mode: the roofline comes from the eager scouting step)
         model.set_profiling(False)
     if use_dist:
@@ -202,11 +242,10 @@ def main():
     dom = max(agg.items(), key=lambda kv: kv[1][1])
     dom_name, (dom_n, dom_ms, _) = dom
     c = model._cfg
-    # algorithmic FLOPs per launch of the dominant kernel, valid frames/tokens only
-    ntok = int(il.sum())
+    # algorithmic FLOPs per launch of the dominant kernel, valid frames/tokens of THIS rank only
     per_row = {"dec.ffn1": 2.0 * c["ffn_kernel"] * c["ddim"] * c["dunits"], "enc.ffn1": 2.0 * c["ffn_kernel"] * c["adim"] * c["eunits"],
                "dec.ffn2_ln": 2.0 * c["dunits"] * c["ddim"], "dec.qkv": 6.0 * c["ddim"] ** 2, "dec.out_ln": 2.0 * c["ddim"] ** 2}
-    rows = ntok if dom_name.startswith("enc") or dom_name.startswith("dur") else local_frames
+    rows = local_tokens if dom_name.startswith("enc") or dom_name.startswith("dur") else local_frames
     if dom_name in per_row:
         algo = per_row[dom_name] * rows
     else:   # fall back to the launch's own count (includes the ~1.5 % gap rows)
@@ -217,17 +256,31 @@ def main():
     roofline = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
                     frac=round(achieved / peak, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
                     share_of_kernel_time=round(scout[dom_name] / kernel_ms_per_step, 3),
-                    kernel_ms_per_step=round(kernel_ms_per_step, 3))
-    try:    # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01f_traffic.json")))
-        if tr["workload"] == args.workload and tr["precision"] == args.precision and tr["kernel_site"] == dom_name and world == 1:
+                    kernel_ms_per_step_scouted=round(kernel_ms_per_step, 3))
+    try:    # HBM-side bytes per launch: rocprofv3 PMC passes of this same command (tools/profile_round.sh -> profiles/)
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        if tr["workload"] == workload and tr["precision"] == args.precision and tr["kernel_site"] == dom_name and world == 1:
             roofline["traffic"] = tr["traffic_bytes"]
-            roofline["traffic_note"] = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r01f_traffic.json; algorithmic HBM bytes %d" % tr["algorithmic_bytes"]
+            roofline["traffic_note"] = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r02_traffic.json (separate --pmc passes of this command); algorithmic HBM bytes %d" % tr["algorithmic_bytes"]
     except (OSError, KeyError, ValueError):
         pass
     if args.precision == "bf16x3":   # three MFMAs are issued per algorithmic product
         roofline["issued_tflops"] = round(3 * achieved, 1)
         roofline["issued_frac"] = round(3 * achieved / peak, 4)
+    # HBM-bound kernels of the path against the 8 TB/s roofline: algorithmic bytes of the valid rows / time
+    ad, dd, od = c["adim"], c["ddim"], c["odim"]
+    pl = 2 if args.precision != "fp32" else 1          # fp32 tensor + split-bf16 planes of the same size
+    hbm_bytes = {"lr.expand": local_frames * ad * 4 * pl + local_tokens * ad * 4 + local_frames * 4,
+                 "var.embed": local_frames * ad * 4 * (1 + pl) + local_frames * 16,
+                 "enc.embed": local_tokens * ad * 4 * (1 + pl),
+                 "unpack": local_frames * od * 4 + len(mine) * int(mel.shape[1]) * od * 4}
+    roofline_hbm = []
+    for name, nbytes in hbm_bytes.items():
+        if name in scout and scout[name] > 0:
+            ms = scout[name] / scout_n[name]
+            gbps = nbytes / (ms * 1e-3) / 1e9
+            roofline_hbm.append(dict(kernel=name, bytes=int(nbytes), avg_launch_ms=round(ms, 4), achieved=round(gbps, 1), peak=HBM_PEAK_GBPS,
+                                     unit="GB/s", frac=round(gbps / HBM_PEAK_GBPS, 4)))
     if args.profile_kernels and rank == 0:
         tot = sum(v[1] for v in agg.values())
         for name, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -235,29 +288,41 @@ def main():
                   file=sys.stderr)
 
     if rank == 0:
-        from fastspeech2_amd.parallel import path_flops
+        ol_host = olens_all.cpu()
+        if graph_run is not None:
+            launch = "HIP graph replay"
+        elif args.profile_kernels:
+            launch = "eager, host-driven layout"
+        else:
+            launch = "eager, device-driven layout (no host sync)"
         line = {
             "metric": "mel-frames/sec", "value": round(total_frames * args.steps / dt, 1), "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "ms_per_step_median": round(statistics.median(step_ms), 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[args.precision],
             "data": "synthetic",
-            "config": {"workload": "%s: batch=%d LJSpeech-shape per GPU, default.yaml dims, free-running, random-init weights (seed 0), "
-                                   "duration bias ln(1+7.87)" % (args.workload, B),
-                       "utterances_per_gpu": B, "valid_frames_per_step": total_frames, "phonemes_per_gpu": ntok,
-                       "algorithmic_gflop_per_step_per_gpu": round(sum(path_flops(int(t), int(l)) for t, l in zip(il, model.last_olens)) / 1e9, 1),
-                       "parallelism": "utterance-sharded x%d, all-gather(mels) over RCCL" % world if world > 1 else "single GPU",
-                       "launch": "HIP graph replay" if graph_run is not None else ("eager, host-driven layout" if ((use_dist and dist_caps is None) or args.profile_kernels) else "eager, device-driven layout (no host sync)")},
+            "config": {"workload": "%s%s; default.yaml dims, free-running, random-init weights (seed 0), duration bias ln(1+7.87)"
+                                   % (WORKLOAD_TEXT[workload], " -- here %d utterances on %d GPU(s)" % (B, world) if workload == "c5" else ""),
+                       "utterances": B, "utterances_per_gpu": [len(p) for p in parts], "valid_frames_per_step": total_frames,
+                       "phonemes": int(il.sum()),
+                       "algorithmic_gflop_per_step": round(sum(path_flops(int(t), int(l)) for t, l in zip(il, ol_host)) / 1e9, 1),
+                       "parallelism": ("LPT utterance-sharded x%d (unequal shards), one all-gather(packed mels + frame counts) over RCCL" % world)
+                                      if use_dist else "single GPU",
+                       "launch": launch},
             "roofline": roofline,
+            "roofline_hbm": roofline_hbm,
         }
-        if world == 1 and not args.no_cpu_baseline:      # the only leg of this script that touches oracle/ (as the measured CPU baseline and the checker)
+        if world == 1 and not use_dist and not args.no_cpu_baseline:      # the only leg of this script that touches oracle/ (as the measured CPU baseline and the checker)
             from oracle import fs2_oracle as O
             cfg = O.config_from_hp(hp, N_PHONEME_SYMBOLS, odim)
             with torch.no_grad():
-                d_pred = model._run(xs, il, is_inference=True, want=("after",))["d_int"].cpu()
-            cb, worst = cpu_baseline(sd, cfg, dict(xs=batch["xs"], ilens=il, ds_pred=d_pred), mel.cpu())
+                r = model._run(xs, il, is_inference=True, want=("after", "qe", "qp"))
+            gpu = dict(after=r["after"].cpu(), d_int=r["d_int"].cpu(), olens=r["olens"], qe=r["qe"].cpu().long(), qp=r["qp"].cpu().long())
+            cb, worst, flips = cpu_baseline(sd, cfg, dict(xs=batch["xs"], ilens=il), gpu)
             line["cpu_baseline"] = cb
             line["vs_cpu"] = round(line["value"] / cb["value"], 1)
             line["mel_max_abs_diff"] = worst
+            line["decision_agreement"] = flips
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

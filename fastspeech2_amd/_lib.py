@@ -45,7 +45,7 @@ class Batch(C.Structure):
 class EncodeIO(C.Structure):
     _fields_ = [("batch", Batch), ("xs", C.c_void_p), ("ds", C.c_void_p), ("d_log", C.c_void_p),
                 ("d_int", C.c_void_p), ("olens", C.c_void_p), ("enc_out", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("duration_alpha", C.c_float)]
 
 
 class DecodeIO(C.Structure):
@@ -68,7 +68,7 @@ class OpGemmArgs(C.Structure):
 # every symbol include/fs2.h declares (tests check the library exports all of them)
 EXPORTS = ["fs2_create", "fs2_destroy", "fs2_last_error", "fs2_load_weights", "fs2_token_workspace_bytes",
            "fs2_encode", "fs2_frame_workspace_bytes", "fs2_row_capacity", "fs2_frame_workspace_bytes_cap", "fs2_decode", "fs2_set_profiling", "fs2_set_profile_filter", "fs2_get_profile",
-           "fs2_op_conv_gemm", "fs2_op_attention", "fs2_op_length_regulate", "fs2_op_unpack_rows", "fs2_op_unpack_rows_dev", "fs2_op_transpose", "fs2_op_bucketize"]
+           "fs2_op_conv_gemm", "fs2_op_attention", "fs2_op_length_regulate", "fs2_op_unpack_rows", "fs2_op_unpack_rows_dev", "fs2_op_transpose", "fs2_op_bucketize", "fs2_op_duration", "fs2_set_option"]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
 
@@ -137,7 +137,7 @@ def lib():
     L.fs2_op_conv_gemm.restype = C.c_int
     L.fs2_op_attention.argtypes = [vp, vp, vp, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, i32]
     L.fs2_op_attention.restype = C.c_int
-    L.fs2_op_length_regulate.argtypes = [vp, vp, vp, i64p, i32, i32, i32, i32, vp, vp, vp]
+    L.fs2_op_length_regulate.argtypes = [vp, vp, vp, i64p, i32, i32, i32, i32, C.c_float, vp, vp, vp]
     L.fs2_op_length_regulate.restype = C.c_int
     L.fs2_op_unpack_rows.argtypes = [vp, vp, i32, i32, C.POINTER(i32), C.POINTER(i32), i32, vp]
     L.fs2_op_unpack_rows.restype = C.c_int
@@ -147,8 +147,17 @@ def lib():
     L.fs2_op_transpose.restype = C.c_int
     L.fs2_op_bucketize.argtypes = [vp, vp, C.c_int64, vp, i32, vp]
     L.fs2_op_bucketize.restype = C.c_int
+    L.fs2_op_duration.argtypes = [vp, vp, C.c_int64, vp]
+    L.fs2_op_duration.restype = C.c_int
+    L.fs2_set_option.argtypes = [C.c_char_p, i32]
+    L.fs2_set_option.restype = C.c_int
     _lib = L
     return L
+
+
+def set_option(name, value):
+    """Kernel-choice switch for A/B measurements and tests (include/fs2.h: fs2_set_option); -1 = automatic."""
+    check(lib().fs2_set_option(name.encode(), int(value)))
 
 
 def check(code, handle=None):

@@ -130,6 +130,18 @@ __global__ __launch_bounds__(256) void embed_pe(const int64_t* xs, int Tmax, con
     }
 }
 
+// d = clamp(round_half_even(exp(y) - 1), 0) as int64 (reference duration_predictor.py:77-81: torch.clamp(torch.round(xs.exp() -
+// offset), min=0).long()).  rintf = round half to even (torch.round); +inf and values beyond the int64 range saturate.
+__device__ __forceinline__ int64_t duration_from_log(float y) {
+    const float f = fmaxf(rintf(expf(y) - 1.0f), 0.f);
+    return (f >= 9.0e18f) ? INT64_MAX : (int64_t)f;      // (NaN: fmaxf returns 0)
+}
+
+__global__ void duration_kernel(const float* d_log, int64_t n, int64_t* d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = duration_from_log(d_log[i]);
+}
+
 // Duration post-op (reference duration_predictor.py:77-84): packed per-row log-durations ->
 // padded [B,Tmax] outputs; d = clamp(round_half_even(exp(y) - 1), 0), pads -> 0.
 __global__ void dur_finalize(const float* dlog_rows, const int* start, const int* vlen, int B, int Tmax,
@@ -141,8 +153,7 @@ __global__ void dur_finalize(const float* dlog_rows, const int* start, const int
     int64_t d = 0;
     if (t < vlen[b]) {
         y = dlog_rows[start[b] + t];
-        const float f = fmaxf(rintf(expf(y) - 1.0f), 0.f);     // rintf = round half to even
-        d = (f >= 9.0e18f) ? INT64_MAX : (int64_t)f;
+        d = duration_from_log(y);
     }
     if (d_log) d_log[i] = y;
     if (d_int) d_int[i] = d;
@@ -150,8 +161,16 @@ __global__ void dur_finalize(const float* dlog_rows, const int* start, const int
 
 // Per-utterance inclusive prefix sum of the durations actually used (reference length_regulator.py:60,
 // 85-88: slice to ilen, an all-zero row becomes all ones).  One workgroup per utterance.
+// alpha: the length regulator's speed control (length_regulator.py:57-59): d <- round_half_even(float(d) * alpha) when alpha != 1.
+__device__ __forceinline__ int scaled_duration(int64_t d, float alpha) {
+    if (d <= 0) return 0;
+    if (alpha == 1.0f) return (int)d;
+    const float f = rintf((float)d * alpha);
+    return f > 0.f ? (int)f : 0;
+}
+
 __global__ __launch_bounds__(256) void dur_scan(const int64_t* ds, int Tmax, const int* ilen, int* cum,
-                                                int64_t* olens, int* olens32) {
+                                                int64_t* olens, int* olens32, float alpha = 1.0f) {
     __shared__ int wsum[4];
     __shared__ int carry_s;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(256) void dur_scan(const int64_t* ds, int Tmax, con
     const int64_t* d = ds + (size_t)b * Tmax;
     // pass 1: total
     int tot = 0;
-    for (int t = tid; t < T; t += 256) tot += (int)(d[t] > 0 ? d[t] : 0);
+    for (int t = tid; t < T; t += 256) tot += scaled_duration(d[t], alpha);
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
     if (lane == 0) wsum[wave] = tot;
     __syncthreads();
@@ -170,7 +189,7 @@ __global__ __launch_bounds__(256) void dur_scan(const int64_t* ds, int Tmax, con
     __syncthreads();
     for (int base = 0; base < T; base += 256) {
         const int t = base + tid;
-        int v = (t < T) ? (ones ? 1 : (int)(d[t] > 0 ? d[t] : 0)) : 0;
+        int v = (t < T) ? (ones ? 1 : scaled_duration(d[t], alpha)) : 0;
         int x = v;   // inclusive scan inside the wave
         for (int o = 1; o < 64; o <<= 1) {
             const int y = __shfl_up(x, o);
@@ -312,6 +331,16 @@ __global__ void pack_rows(const float* src, int W, const int* row_pos, const int
     const int j = row_pos[row];
     if (j >= vlen[b]) return;
     *reinterpret_cast<float4*>(dst + (size_t)(cum[b] + j) * W + c) = *reinterpret_cast<const float4*>(src + (size_t)row * W + c);
+}
+
+// device-driven layout: when the overflow flags (dims[2]) are set the outputs of the call are invalid -> fill them with NaN
+__global__ void poison_on_overflow(const int* dims, float* a, int64_t na, float* b, int64_t nb, float* c, int64_t nc) {
+    if (dims[2] == 0) return;
+    const float q = __builtin_nanf("");
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = i0; i < na; i += stride) a[i] = q;
+    for (int64_t i = i0; i < nb; i += stride) b[i] = q;
+    for (int64_t i = i0; i < nc; i += stride) c[i] = q;
 }
 
 // [N, W] -> [W, N] through a 32 x 33 LDS tile (coalesced on both sides)

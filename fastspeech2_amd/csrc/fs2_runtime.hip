@@ -52,6 +52,39 @@ struct Stack {
 
 constexpr int kXcds = 8;      // MI355X: 8 accelerator dies, workgroups of a launch are dealt to them round-robin
 
+// A/B switches of the kernel choice.  Read from the environment ONCE, when the library is first used, and
+// changed afterwards only through fs2_set_option(): the launch path never touches the environment.  -1 = automatic choice.
+struct Options {
+    int bm = -1;         // FS2_BM       tile height of gemm_pl_bf16 (64 | 128 | 256)
+    int row8 = -1;       // FS2_ROW8     force (1) / forbid (0) the row-complete LayerNorm-fused k = 1 GEMM
+    int qkv8 = -1;       // FS2_QKV8     force / forbid the 8-wave fused QKV projection
+    int nosplitk = 0;    // FS2_NOSPLITK no split-K of the token-level k = 1 GEMMs
+    int f32_rows = 0;    // FS2_F32_ROWS row-complete fp32 GEMM for LayerNorm-terminated ops
+};
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+Options& opts() {
+    static Options o = [] {
+        Options x;
+        x.bm = env_int("FS2_BM", -1); x.row8 = env_int("FS2_ROW8", -1); x.qkv8 = env_int("FS2_QKV8", -1);
+        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0;
+        return x;
+    }();
+    return o;
+}
+
+// Every entry point that takes a handle runs on the handle's device and leaves the caller's current device as it found it.
+struct DeviceGuard {
+    int prev = -1; bool switched = false; hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = (err == hipSuccess); }
+    }
+    ~DeviceGuard() { if (switched) hipSetDevice(prev); }
+};
+
 struct HostLayout {
     int B = 0, R = 0, Rpad = 0;
     std::vector<int> start, len, klen, vlen;
@@ -207,8 +240,7 @@ hipError_t launch_qkv8_t(hipStream_t s, const GemmArgs& a) {
 // Fused QKV projection on the 8-wave structure when there is about a CU's worth of 128-row tiles (FS2_QKV8=0|1 forces the choice)
 bool use_qkv8(const GemmArgs& a) {
     if (!a.qk_hi || a.ktaps != 1 || (a.att_D != 256 && a.att_D != 384) || a.N != 3 * a.att_D) return false;
-    const char* e = getenv("FS2_QKV8");
-    if (e) return atoi(e) != 0;
+    if (opts().qkv8 >= 0) return opts().qkv8 != 0;
     return (a.Rvt + 127) / 128 >= 128;
 }
 
@@ -216,8 +248,7 @@ bool use_qkv8(const GemmArgs& a) {
 // needs about a CU's worth of 128-row tiles to pay (FS2_ROW8=0|1 forces the choice).
 bool use_row8(const GemmArgs& a) {
     if (a.ktaps != 1 || a.dot_w || a.qk_hi || (a.N != 256 && a.N != 384) || !(a.ln_g || a.pe)) return false;
-    const char* e = getenv("FS2_ROW8");
-    if (e) return atoi(e) != 0;
+    if (opts().row8 >= 0) return opts().row8 != 0;
     return (a.R + 127) / 128 >= 128;
 }
 
@@ -225,8 +256,7 @@ bool use_row8(const GemmArgs& a) {
 // (FS2_BM=64|128|256 forces one; k = 1 GEMMs have no 256-row form: two 256-row A buffers would not fit two workgroups per CU).
 template <int NSPLIT>
 hipError_t launch_pl(hipStream_t s, const GemmArgs& a) {
-    const char* e = getenv("FS2_BM");
-    const int force = !e ? 0 : atoi(e);
+    const int force = opts().bm > 0 ? opts().bm : 0;
     const long rows = a.qk_hi ? a.Rvt : a.R;
     const long nN = (a.N + kB16BN - 1) / kB16BN;
     int bm;
@@ -266,7 +296,7 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         // split-K: a k = 1 GEMM with a long K on a grid that leaves CUs idle is a serial chain of k-steps; 2-4 workgroups share it and
         // ln_rows (which follows anyway) adds their partial sums in a fixed order (deterministic, unlike atomics)
         t.ksplit = 1;
-        if (need_rows && !row8 && a.ktaps == 1 && a.kpart && !getenv("FS2_NOSPLITK")) {
+        if (need_rows && !row8 && a.ktaps == 1 && a.kpart && !opts().nosplitk) {
             const int nchunks = a.Cpad / 32;
             const long wgs = (long)((a.N + kB16BN - 1) / kB16BN) * ((a.R + 63) / 64);
             int ksp = 1;
@@ -302,7 +332,7 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
             hipLaunchKernelGGL(ln_rows, dim3((a.R + 3) / 4), dim3(256), 0, s, r);
             e = hipGetLastError();
         }
-    } else if (need_rows && a.N >= 128 && a.N <= 1024 && a.N % 4 == 0 && (a.Y || a.scratch) && !getenv("FS2_F32_ROWS")) {
+    } else if (need_rows && a.N >= 128 && a.N <= 1024 && a.N % 4 == 0 && (a.Y || a.scratch) && !opts().f32_rows) {
         // fp32, LayerNorm-terminated: 128x128 MFMA tiles + the HBM-bound row kernel (2x faster than the row-complete
         // GEMM, whose 16-rows-per-wave shape re-stages the whole weight matrix for every 64 rows)
         GemmArgs t = a;
@@ -865,8 +895,10 @@ int fs2_create(const fs2_config* cfg, fs2_handle** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, FS2_ERR_HIP, "no HIP device is visible: libfs2_hip has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, FS2_ERR_ARG, "device %d out of range (%d visible)", cfg->device, ndev);
-    hipError_t e = hipSetDevice(cfg->device);
-    if (e != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    {
+        DeviceGuard g(cfg->device);      // only proves the device can be made current; the caller's current device is restored
+        if (g.err != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(g.err));
+    }
     fs2_handle* h = new fs2_handle();
     h->cfg = *cfg;
     *out = h;
@@ -875,7 +907,7 @@ int fs2_create(const fs2_config* cfg, fs2_handle** out) {
 
 void fs2_destroy(fs2_handle* h) {
     if (!h) return;
-    hipSetDevice(h->cfg.device);
+    DeviceGuard g(h->cfg.device);
     free_weights(h);
     for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (void* p : h->graph_pinned) hipHostFree(p);
@@ -886,7 +918,8 @@ const char* fs2_last_error(const fs2_handle* h) { return h ? h->err.c_str() : g_
 
 int fs2_load_weights(fs2_handle* h, const fs2_tensor_desc* t, int32_t n, void* stream) {
     if (!h || !t || n <= 0) return fail(h, FS2_ERR_ARG, "fs2_load_weights: bad arguments");
-    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    DeviceGuard g(h->cfg.device);
+    HIP_TRY(h, g.err);
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(h, hipStreamSynchronize(s));   // nothing may still be reading the old weights
     free_weights(h);
@@ -979,7 +1012,9 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
     int rc = check_batch(h, io->batch);
     if (rc) return rc;
     if (!io->xs || !io->olens || !io->workspace) return fail(h, FS2_ERR_ARG, "fs2_encode: xs/olens/workspace must be given");
-    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (io->duration_alpha < 0.f) return fail(h, FS2_ERR_ARG, "fs2_encode: duration_alpha %g must be > 0 (0 = 1.0)", (double)io->duration_alpha);
+    DeviceGuard g(h->cfg.device);
+    HIP_TRY(h, g.err);
     hipStream_t s = (hipStream_t)stream;
     const fs2_config& c = h->cfg;
     const fs2_batch& b = io->batch;
@@ -1009,7 +1044,8 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
         hipLaunchKernelGGL(dur_finalize, dim3((n + 255) / 256), dim3(256), 0, s, dlog_rows, dl.start, dl.vlen, b.B, b.Tmax, io->d_log, dint);
         HIP_TRY(h, hipGetLastError());
         if (io->d_int) HIP_TRY(h, hipMemcpyAsync(io->d_int, dint, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(dur_scan, dim3(b.B), dim3(256), 0, s, io->ds ? io->ds : dint, b.Tmax, dl.vlen, cum, io->olens, o32);
+        hipLaunchKernelGGL(dur_scan, dim3(b.B), dim3(256), 0, s, io->ds ? io->ds : dint, b.Tmax, dl.vlen, cum, io->olens, o32,
+                           io->duration_alpha > 0.f ? io->duration_alpha : 1.f);
         HIP_TRY(h, hipGetLastError());
     }
     if (io->enc_out) {
@@ -1071,7 +1107,8 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         if (io->Lmax < mx) return fail(h, FS2_ERR_ARG, "Lmax %d < longest utterance %d", io->Lmax, mx);
         if (mx > h->dec.pe_rows) return fail(h, FS2_ERR_ARG, "utterance of %d frames exceeds the positional table (%d rows): extend `pe` and reload", mx, h->dec.pe_rows);
     }
-    HIP_TRY(h, hipSetDevice(c.device));
+    DeviceGuard g(c.device);
+    HIP_TRY(h, g.err);
     hipStream_t s = (hipStream_t)stream;
     HostLayout L;
     if (devlay) capacity_layout(b, io->row_capacity, io->Lmax, L);
@@ -1186,6 +1223,14 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
             hipLaunchKernelGGL(pack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mel_after, c.odim, dl.row_pos, dl.row_seq, dl.vlen, dcum, R, io->after_packed);
             HIP_TRY(h, hipGetLastError());
         }
+        if (devlay) {
+            // a capacity was too small: the mels of this call do not exist.  NaN-fill them so that a caller who forgets to look at
+            // `status` cannot mistake the (empty-layout) zeros or uninitialised rows for silence
+            hipLaunchKernelGGL(poison_on_overflow, dim3(256), dim3(256), 0, s, dl.dims, io->after, (int64_t)b.B * io->Lmax * c.odim,
+                               io->after_packed, io->after_packed ? io->row_capacity * c.odim : (int64_t)0, io->before,
+                               io->before ? (int64_t)b.B * io->Lmax * c.odim : (int64_t)0);
+            HIP_TRY(h, hipGetLastError());
+        }
     }
     return FS2_OK;
 }
@@ -1286,8 +1331,8 @@ int fs2_op_attention(void* stream, const float* qkv, float* ctx, int32_t D, int3
 }
 
 int fs2_op_length_regulate(void* stream, const float* hs, const int64_t* ds, const int64_t* ilens_host, int32_t B, int32_t Tmax,
-                           int32_t D, int32_t Lmax, float* out, int32_t* index, int64_t* olens) {
-    if (!hs || !ds || !ilens_host || !out || B <= 0 || D % 4) return fail(nullptr, FS2_ERR_ARG, "fs2_op_length_regulate: bad arguments");
+                           int32_t D, int32_t Lmax, float alpha, float* out, int32_t* index, int64_t* olens) {
+    if (!hs || !ds || !ilens_host || !out || B <= 0 || D % 4 || !(alpha > 0.f)) return fail(nullptr, FS2_ERR_ARG, "fs2_op_length_regulate: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     std::vector<int> host(2 * B);
     for (int b = 0; b < B; ++b) { host[b] = b * Tmax; host[B + b] = (int)ilens_host[b]; }
@@ -1296,7 +1341,7 @@ int fs2_op_length_regulate(void* stream, const float* hs, const int64_t* ds, con
     OP_TRY(tmp.alloc((void**)&dev, ((size_t)3 * B + (size_t)B * Tmax) * sizeof(int)));
     OP_TRY(hipMemcpyAsync(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
     int *tok_start = dev, *ilen = dev + B, *o32 = dev + 2 * B, *cum = dev + 3 * B;
-    hipLaunchKernelGGL(dur_scan, dim3(B), dim3(256), 0, s, ds, Tmax, ilen, cum, olens, o32);
+    hipLaunchKernelGGL(dur_scan, dim3(B), dim3(256), 0, s, ds, Tmax, ilen, cum, olens, o32, alpha);
     const int R = B * Lmax;
     hipLaunchKernelGGL(lr_expand, dim3((R + 3) / 4), dim3(256), 0, s, hs, D, tok_start, ilen, cum, Tmax, (const int*)nullptr,
                        (const int*)nullptr, Lmax, o32, R, out, index);
@@ -1343,6 +1388,28 @@ int fs2_op_transpose(void* stream, const float* src, int64_t N, int32_t W, float
     hipLaunchKernelGGL(transpose_rows, dim3((unsigned)((N + 31) / 32), (W + 31) / 32), dim3(256), 0, (hipStream_t)stream, src, N, W, dst);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "transpose: %s", hipGetErrorString(e));
+    return FS2_OK;
+}
+
+int fs2_op_duration(void* stream, const float* d_log, int64_t n, int64_t* d) {
+    if (!d_log || !d || n < 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_duration: bad arguments");
+    if (n == 0) return FS2_OK;
+    hipLaunchKernelGGL(duration_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_log, n, d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "duration: %s", hipGetErrorString(e));
+    return FS2_OK;
+}
+
+int fs2_set_option(const char* name, int32_t value) {
+    if (!name) return fail(nullptr, FS2_ERR_ARG, "fs2_set_option: null name");
+    Options& o = opts();
+    const std::string n = name;
+    if (n == "FS2_BM") o.bm = value;
+    else if (n == "FS2_ROW8") o.row8 = value;
+    else if (n == "FS2_QKV8") o.qkv8 = value;
+    else if (n == "FS2_NOSPLITK") o.nosplitk = value > 0;
+    else if (n == "FS2_F32_ROWS") o.f32_rows = value > 0;
+    else return fail(nullptr, FS2_ERR_ARG, "fs2_set_option: unknown option %s", name);
     return FS2_OK;
 }
 

@@ -21,7 +21,48 @@ from torch import nn
 
 from . import _lib
 
-__all__ = ["FeedForwardTransformer"]
+__all__ = ["FeedForwardTransformer", "AsyncMels", "Fs2CapacityError"]
+
+
+class Fs2CapacityError(RuntimeError):
+    """A capacity of the device-driven frame layout was too small: the mels of that call are NaN-filled (invalid)."""
+
+
+class AsyncMels(tuple):
+    """What ``inference_batch(sync=False)`` returns: unpacks like ``(mels, olens_dev)`` and carries the call's own validity
+    record.  ``status`` is the device int32[8] of fs2_decode ({rows, work items, overflow flags, longest utterance, valid frames,
+    ...}); ``ok()`` waits for THIS call (its own event and pinned copy of the flags) and tells whether its capacities
+    sufficed; ``check()`` raises ``Fs2CapacityError`` instead.  On overflow the mels are NaN-filled on the device, so a caller
+    that never looks still cannot mistake them for audio."""
+
+    def __new__(cls, mels, olens, status, record):
+        self = super().__new__(cls, (mels, olens))
+        self.status, self._record = status, record
+        return self
+
+    def ok(self):
+        return self._record is None or self._record.flags(block=True) == 0
+
+    def check(self):
+        if not self.ok():
+            raise Fs2CapacityError("device-driven layout overflow (flags %d): rerun this batch with sync=True or a larger "
+                                   "capacity" % self._record.flags(block=True))
+        return self
+
+
+class _AsyncRecord:
+    """Frame counts and flags of one asynchronous call, copied to pinned host memory behind its kernels."""
+    __slots__ = ("il", "event", "olens_pin", "status_pin", "harvested")
+
+    def __init__(self, il, event, olens_pin, status_pin):
+        self.il, self.event, self.olens_pin, self.status_pin, self.harvested = il, event, olens_pin, status_pin, False
+
+    def flags(self, block):
+        if block:
+            self.event.synchronize()
+        elif not self.event.query():
+            return None
+        return int(self.status_pin[2])
 
 
 # ----------------------------------------------------------------------------------------------
@@ -237,6 +278,9 @@ class FeedForwardTransformer(nn.Module):
         self._handle = None
         self._handle_device = None
         self._fingerprint = None
+        self._weights_generation = 0
+        self._pending = []             # _AsyncRecord of asynchronous calls not yet folded into the capacity predictor
+        self._pin_ring, self._pin_next = [], 0
         self.last_olens = None
 
     # ------------------------------------------------------------------ init (fastspeech.py:378-387)
@@ -270,12 +314,14 @@ class FeedForwardTransformer(nn.Module):
         h = getattr(self, "_handle", None)
         if h is not None:
             try:
-                _lib.lib().fs2_destroy(h)
+                _lib.lib().fs2_destroy(h)      # restores the caller's current device itself (DeviceGuard in the library)
             except Exception:   # interpreter shutdown
                 pass
             self.__dict__["_handle"] = None
 
     def _weights_fingerprint(self):
+        """(storage, version) of every parameter / buffer.  Catches load_state_dict, .to(), optimizer steps and every in-place
+        op autograd sees; writes through ``.data`` bypass the version counter: call ``refresh_weights()`` after those."""
         sd = self.state_dict(keep_vars=True)
         return tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
 
@@ -293,7 +339,8 @@ class FeedForwardTransformer(nn.Module):
                               device=device.index if device.index is not None else torch.cuda.current_device(),
                               decoder_input_layer=self._cfg['decoder_input_layer'])
             h = C.c_void_p()
-            _lib.check(L.fs2_create(C.byref(cfg), C.byref(h)))
+            with torch.cuda.device(device):      # (the library also restores the caller's current device itself)
+                _lib.check(L.fs2_create(C.byref(cfg), C.byref(h)))
             self._handle, self._handle_device, self._fingerprint = h, device, None
         fp = self._weights_fingerprint()
         if fp != self._fingerprint:
@@ -310,6 +357,7 @@ class FeedForwardTransformer(nn.Module):
             with torch.cuda.device(device):
                 _lib.check(L.fs2_load_weights(self._handle, arr, len(descs), _stream(device)), self._handle)
             self._fingerprint = fp
+            self._weights_generation += 1      # device copies were re-allocated: captured graphs of older generations are stale
         return L
 
     def refresh_weights(self):
@@ -318,7 +366,7 @@ class FeedForwardTransformer(nn.Module):
 
     # ------------------------------------------------------------------ the path
     def _run(self, xs, ilens, olens=None, ds=None, es=None, ps=None, is_inference=False, compat=False,
-             want=("before", "after"), d_override=None, capacity=None):
+             want=("before", "after"), d_override=None, capacity=None, alpha=1.0):
         """Runs fs2_encode -> (olens readback) -> fs2_decode.  Returns a dict of device tensors.
 
         ``capacity=(total_frames_bound, per_utterance_bound)`` selects the device-driven frame layout instead: no host
@@ -364,7 +412,7 @@ class FeedForwardTransformer(nn.Module):
             eio = _lib.EncodeIO(batch, xs.data_ptr(), ds_dev.data_ptr() if ds_dev is not None else None,
                                 d_log.data_ptr() if d_log is not None else None,
                                 d_int.data_ptr() if d_int is not None else None, olens_dev.data_ptr(),
-                                enc_out.data_ptr() if enc_out is not None else None, tok_ws.data_ptr(), tok_ws.numel())
+                                enc_out.data_ptr() if enc_out is not None else None, tok_ws.data_ptr(), tok_ws.numel(), float(alpha))
             _lib.check(L.fs2_encode(h, st, C.byref(eio)), h)
             if capacity is not None:
                 total_cap, Lcap = int(capacity[0]), int(capacity[1])
@@ -406,7 +454,7 @@ class FeedForwardTransformer(nn.Module):
                     raise ValueError("olens %s do not match the sums of the durations %s" % (given.tolist(), ol.tolist()))
             Lmax = int(ol.max())
             if self.decoder.embed[-1].ensure(Lmax):                # pe table grew: reload and redo the encoder
-                return self._run(xs, ilens, olens, ds, es, ps, is_inference, compat, want, d_override)
+                return self._run(xs, ilens, olens, ds, es, ps, is_inference, compat, want, d_override, alpha=alpha)
             ol_arr = (C.c_int64 * B)(*ol.tolist())
             frm_ws = torch.empty(L.fs2_frame_workspace_bytes(h, C.byref(batch), ol_arr), dtype=torch.uint8, device=dev)
             odim = self.odim
@@ -498,71 +546,75 @@ class FeedForwardTransformer(nn.Module):
                        {"pitch_loss": pitch_loss.item()}, {"loss": loss.item()}]
         return loss, report_keys
 
-    def inference(self, x):
-        """reference fastspeech.py:339-357: x [T] int64 phoneme ids -> mel [L, odim]."""
+    def inference(self, x, alpha=1.0):
+        """reference fastspeech.py:339-357: x [T] int64 phoneme ids -> mel [L, odim].  ``alpha`` (not in the reference's
+        ``inference``, but in its LengthRegulator, length_regulator.py:57-59) scales the durations: > 1 slower speech."""
         xs, il = x.unsqueeze(0), torch.tensor([x.shape[0]])
         if self._frames_per_token is not None:
             # device-driven layout inside capacities learnt from earlier utterances: the GPU runs the whole forward without
             # waiting for the host; the frame count is read once, at the end (it is needed for the shape of the result)
-            total = int(float(il[0]) * self._frames_per_token[1] * 1.25) + 64
-            Lcap = -(-total // 32) * 32
-            r = self._run(xs, il, is_inference=True, want=("after",), capacity=(total, Lcap))
+            total, Lcap = self.predict_capacity(il, alpha)
+            r = self._run(xs, il, is_inference=True, want=("after",), capacity=(max(total, Lcap), Lcap), alpha=alpha)
             st = r["status"].cpu()
             if int(st[2]) == 0:
                 L = int(st[3])
-                self._learn_ratio(il, torch.tensor([L]))
+                self._learn_ratio(il, torch.tensor([L]), alpha)
                 return r["after"][0, :L]
-        r = self._run(xs, il, is_inference=True, want=("after",))
-        self._learn_ratio(il, r["olens"])
+        r = self._run(xs, il, is_inference=True, want=("after",), alpha=alpha)
+        self._learn_ratio(il, r["olens"], alpha)
         return r["after"][0]
 
-    def inference_batch(self, xs, ilens, d_override=None, packed=False, sync=True, capacity=None):
+    def inference_batch(self, xs, ilens, d_override=None, packed=False, sync=True, capacity=None, alpha=1.0):
         """Batched free-running synthesis (not in the reference, which only has single-utterance
         ``inference``): per-utterance semantics; returns (mels [B, Lmax, odim], olens [B] on the host), or with
         ``packed=True`` (valid frames back to back [sum(olens), odim], olens): the form the multi-GPU gather ships.
+        An empty batch (B = 0, e.g. a rank that got no utterance) returns empty tensors without touching the GPU.
 
         ``sync=False``: nothing waits for the GPU.  The frame layout is built on the device inside capacities predicted
         from earlier calls (frames per phoneme seen so far, with headroom; or ``capacity=(total_frames, per_utterance)``
-        given by the caller, e.g. agreed between ranks), the call returns (mels [B, Lcap, odim] zero-padded - or, with
-        ``packed=True``, [rows_cap, odim] whose first sum(olens) rows are the valid frames - , olens as a DEVICE int64 tensor)
-        and records ``self.last_async``; ``async_ok()`` (one host sync) tells whether the capacities sufficed, and feeds
-        the predictor.  If they did not, the outputs of that call are invalid: repeat it with ``sync=True`` (which learns
-        the exact sizes).  The first call of a model is always synchronous."""
+        given by the caller, e.g. agreed between ranks) and the call returns an :class:`AsyncMels`, which unpacks like
+        (mels [B, Lcap, odim] zero-padded - or, with ``packed=True``, [rows_cap, odim] whose first sum(olens) rows are the
+        valid frames - , olens as a DEVICE int64 tensor) and carries ``status`` / ``ok()`` / ``check()`` for THIS call.
+        If a capacity did not suffice the mels of that call are NaN-filled on the device (never silently wrong);
+        ``ok()`` is then False: repeat the batch with ``sync=True`` (which learns the exact sizes).  Any number of
+        asynchronous calls may be in flight; ``async_ok()`` waits for all of them and tells whether every one since the last
+        ``async_ok()`` was valid.  The first call of a model is always synchronous.  ``alpha``: duration scale."""
+        il = torch.as_tensor(ilens).detach().to("cpu", torch.int64).reshape(-1)
+        if il.numel() == 0:
+            _require_device(xs)
+            empty = torch.zeros((0, self.odim) if packed else (0, 1, self.odim), device=xs.device)
+            return empty, (torch.zeros(0, dtype=torch.int64) if sync else torch.zeros(0, dtype=torch.int64, device=xs.device))
         if not sync and (self._frames_per_token is not None or capacity is not None):
-            il = torch.as_tensor(ilens).detach().to("cpu", torch.int64)
             self._harvest_async(block=False)
-            total, Lcap = capacity if capacity is not None else self.predict_capacity(il)
+            total, Lcap = capacity if capacity is not None else self.predict_capacity(il, alpha)
             key = "after_packed" if packed else "after"
-            r = self._run(xs, il, is_inference=True, compat=False, want=("after", key), d_override=d_override, capacity=(total, Lcap))
+            r = self._run(xs, il, is_inference=True, compat=False, want=("after", key), d_override=d_override, capacity=(total, Lcap), alpha=alpha)
             if torch.cuda.is_current_stream_capturing():     # graph capture: no host-side bookkeeping inside the graph
-                return r[key], r["olens"]
-            # frame counts and flags travel to pinned host memory behind the kernels; an event tells when they are there
-            B = int(il.numel())
-            pin = self._pinned
-            if pin is None or pin[0].numel() < B:
-                pin = self._pinned = (torch.empty(max(B, 64), dtype=torch.int64).pin_memory(), torch.empty(8, dtype=torch.int32).pin_memory())
-            pin[0][:B].copy_(r["olens"], non_blocking=True)
-            pin[1].copy_(r["status"], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(xs.device))
-            self.last_async = (il, ev)
-            return r[key], r["olens"]
+                return AsyncMels(r[key], r["olens"], r["status"], None)
+            return AsyncMels(r[key], r["olens"], r["status"], self._record_async(il, r, xs.device, alpha))
         want = ("after", "after_packed") if packed else ("after",)
-        r = self._run(xs, ilens, is_inference=True, compat=False, want=want, d_override=d_override)
-        self._learn_ratio(torch.as_tensor(ilens).detach().to("cpu", torch.int64), r["olens"])
+        r = self._run(xs, il, is_inference=True, compat=False, want=want, d_override=d_override, alpha=alpha)
+        if d_override is None:
+            self._learn_ratio(il, r["olens"], alpha)
+        else:
+            self._learn_ratio(il, r["olens"], 1.0)
         return (r["after_packed"] if packed else r["after"]), r["olens"]
 
     def capture_graph(self, xs, ilens, d_override=None):
         """HIP-graph replay of the whole free-running forward for a fixed batch shape (``xs.shape`` and ``ilens``): the
         launch-bound small-batch case (one utterance: 85 launches) becomes one graph launch.  Returns ``run(new_xs) ->
         (mels [B, Lcap, odim], olens_dev, status_dev)``; the tensors are the graph's static outputs (overwritten by the
-        next replay).  ``status_dev[2] != 0`` means the capacities captured with the graph were too small for that input:
-        fall back to ``inference_batch``.  Capacities come from one synchronous run on ``xs`` (x 1.5 head-room)."""
+        next replay).  ``status_dev[2] != 0`` means the capacities captured with the graph were too small for that input
+        (the mels are then NaN): fall back to ``inference_batch``.  Capacities come from one synchronous run on ``xs``
+        (x 1.5 head-room).  The graph holds pointers into the library's weight copies: ``run`` raises if the weights were
+        re-uploaded since the capture (load_state_dict, a grown positional table, .to()): capture again."""
         with torch.no_grad():
             il = torch.as_tensor(ilens).detach().to("cpu", torch.int64)
             _, ol = self.inference_batch(xs, il, d_override=d_override)            # builds the handle, learns the sizes
             total = int(float(ol.sum()) * 1.5) + 64 * int(il.numel())
             Lcap = -(-int(float(ol.max()) * 1.5 + 64) // 32) * 32
+            self.decoder.embed[-1].ensure(Lcap)
+            self._ensure_ready(xs.device, xs.shape[1], Lcap)                        # a grown table is uploaded BEFORE the capture
             static_xs = xs.clone()
             static_ds = d_override.clone() if d_override is not None else None
             run_once = lambda: self._run(static_xs, il, is_inference=True, compat=False, want=("after",), d_override=static_ds,
@@ -577,8 +629,12 @@ class FeedForwardTransformer(nn.Module):
             with torch.cuda.graph(graph, capture_error_mode="relaxed"):
                 r = run_once()
         after, olens_dev, status = r["after"], r["olens"], r["status"]
+        generation, handle = self._weights_generation, self._handle
 
         def run(new_xs, new_ds=None):
+            if self._handle is not handle or self._weights_generation != generation or self._weights_fingerprint() != self._fingerprint:
+                raise RuntimeError("the model's weights changed since capture_graph(): the graph points at released device "
+                                   "copies; capture a new graph")
             static_xs.copy_(new_xs)
             if static_ds is not None and new_ds is not None:
                 static_ds.copy_(new_ds)
@@ -590,42 +646,82 @@ class FeedForwardTransformer(nn.Module):
 
     # frames-per-phoneme statistics for the capacities of the asynchronous path: (batch mean, max over utterances)
     _frames_per_token = None
-    _pinned = None
-    last_async = None
+    _overflow_seen = False
+    last_async = None           # the most recent _AsyncRecord (kept for introspection)
 
-    def predict_capacity(self, ilens):
+    def predict_capacity(self, ilens, alpha=1.0):
         """(total frames, frames of the longest utterance) to reserve for a batch with these phoneme counts: the
-        frames-per-phoneme ratios seen so far plus 15 % / 25 % head-room."""
+        frames-per-phoneme ratios seen so far (x the duration scale ``alpha``) plus 15 % / 25 % head-room."""
         il = torch.as_tensor(ilens).detach().to("cpu", torch.int64)
-        total = int(float(il.sum()) * self._frames_per_token[0] * 1.15) + 64 * int(il.numel())
-        Lcap = -(-int(float(il.max()) * self._frames_per_token[1] * 1.25 + 64) // 32) * 32
+        a = float(alpha)
+        mean_r, max_r = self._frames_per_token[0] * a + (0.5 if a != 1.0 else 0.0), self._frames_per_token[1] * a + (0.5 if a != 1.0 else 0.0)
+        total = int(float(il.sum()) * mean_r * 1.15) + 64 * int(il.numel())
+        Lcap = -(-int(float(il.max()) * max_r * 1.25 + 64) // 32) * 32
         return total, Lcap
 
-    def _learn_ratio(self, il, ol):
-        mean_r = float(ol.sum()) / max(float(il.sum()), 1.0)
-        max_r = float((ol.float() / il.float().clamp(min=1)).max())
+    def _learn_ratio(self, il, ol, alpha=1.0):
+        a = max(float(alpha), 1e-6)
+        mean_r = float(ol.sum()) / max(float(il.sum()), 1.0) / a
+        max_r = float((ol.float() / il.float().clamp(min=1)).max()) / a
         old = self._frames_per_token
         self._frames_per_token = (mean_r, max_r) if old is None else (max(mean_r, 0.9 * old[0]), max(max_r, 0.9 * old[1]))
 
-    def _harvest_async(self, block):
-        """Fold the frame counts of the last asynchronous call into the capacity predictor; waits for that call only if
-        ``block``.  Returns its overflow flags (0 = outputs valid), or None when it has not finished yet."""
-        if self.last_async is None:
-            return 0
-        il, ev = self.last_async
-        if block:
-            ev.synchronize()
-        elif not ev.query():
+    _PIN_SLOTS = 16
+
+    def _record_async(self, il, r, device, alpha):
+        """Queue the frame counts and flags of an asynchronous call: they travel to pinned host memory behind the kernels, an
+        event tells when they are there.  A ring of pinned slots serves any number of calls in flight (a slot still in use
+        when the ring wraps is waited for and folded first)."""
+        B = int(il.numel())
+        if len(self._pin_ring) < self._PIN_SLOTS:
+            self._pin_ring.append([torch.empty(max(B, 64), dtype=torch.int64).pin_memory(), torch.empty(8, dtype=torch.int32).pin_memory(), None])
+            slot = self._pin_ring[-1]
+        else:
+            slot = self._pin_ring[self._pin_next]
+            self._pin_next = (self._pin_next + 1) % self._PIN_SLOTS
+            if slot[2] is not None and not slot[2].harvested:
+                self._fold(slot[2], block=True)
+            if slot[0].numel() < B:
+                slot[0] = torch.empty(B, dtype=torch.int64).pin_memory()
+        slot[0][:B].copy_(r["olens"], non_blocking=True)
+        slot[1].copy_(r["status"], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        rec = _AsyncRecord((il, alpha), ev, slot[0], slot[1])
+        slot[2] = rec
+        self._pending.append(rec)
+        self.last_async = rec
+        return rec
+
+    def _fold(self, rec, block):
+        """Fold one asynchronous call into the capacity predictor.  Returns its flags, or None if it has not finished."""
+        flags = rec.flags(block)
+        if flags is None:
             return None
-        self.last_async = None
-        flags = int(self._pinned[1][2])
-        if flags == 0:
-            self._learn_ratio(il, self._pinned[0][: il.numel()].clone())
+        if not rec.harvested:
+            rec.harvested = True
+            il, alpha = rec.il
+            if flags == 0:
+                self._learn_ratio(il, rec.olens_pin[: il.numel()].clone(), alpha)
+            else:
+                self._overflow_seen = True
+            if rec in self._pending:
+                self._pending.remove(rec)
         return flags
 
+    def _harvest_async(self, block):
+        """Fold every finished asynchronous call (all of them if ``block``) into the capacity predictor."""
+        for rec in list(self._pending):
+            if self._fold(rec, block) is None:
+                break
+
     def async_ok(self):
-        """True if the capacities of the last ``inference_batch(sync=False)`` call sufficed (waits for that call)."""
-        return self._harvest_async(block=True) == 0
+        """Waits for every ``inference_batch(sync=False)`` call still in flight; True if the capacities of ALL asynchronous
+        calls since the previous ``async_ok()`` sufficed (an overflowed call returned NaN-filled mels)."""
+        self._harvest_async(block=True)
+        ok = not self._overflow_seen
+        self._overflow_seen = False
+        return ok
 
     def _source_mask(self, ilens):
         """reference fastspeech.py:359-376 (kept for API parity; the kernels take lengths, not masks)."""

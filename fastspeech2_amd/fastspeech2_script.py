@@ -34,8 +34,11 @@ def _float_keys(module):
 
 
 def _twin_inference(x, flat_weights, config_json):
-    key = (flat_weights.data_ptr(), flat_weights._version, flat_weights.device, config_json)
-    inner = _CACHE.get(key)
+    # The cache entry keeps a reference to the flat buffer it was built from: its storage therefore cannot be released and handed
+    # to another tensor while the entry lives, so (data_ptr, version) identifies the weights without reading them back.
+    key = (flat_weights.data_ptr(), flat_weights._version, flat_weights.numel(), flat_weights.device, config_json)
+    entry = _CACHE.get(key)
+    inner = entry[0] if entry is not None else None
     if inner is None:
         cfg = json.loads(config_json)
         inner = _Base(cfg["idim"], cfg["odim"], DotDict(cfg["hp"]), _script_twin=True)
@@ -50,7 +53,7 @@ def _twin_inference(x, flat_weights, config_json):
         inner.load_state_dict(sd)
         inner = inner.to(flat_weights.device).eval()
         _CACHE.clear()          # one live model per process is the export use case
-        _CACHE[key] = inner
+        _CACHE[key] = (inner, flat_weights)
     with torch.no_grad():
         return inner.inference(x)
 

@@ -26,10 +26,14 @@ def hparams_from_str(hp_str):
     return DotDict(merged)
 
 
-def load_checkpoint(model, checkpoint, old_model=False, map_location="cpu"):
+def load_checkpoint(model, checkpoint, old_model=False, map_location="cpu", trust_checkpoint=False):
     """Load reference weights into ``model``.  ``checkpoint``: a path or an already loaded object.
-    Returns the dict of extras found (``step``, ``hp_str``, ``githash``) -- empty for bare state dicts."""
-    obj = torch.load(checkpoint, map_location=map_location, weights_only=False) if isinstance(checkpoint, (str, os.PathLike)) else checkpoint
+    Returns the dict of extras found (``step``, ``hp_str``, ``githash``) -- empty for bare state dicts.
+
+    Files are read with ``torch.load(weights_only=True)``: the reference's checkpoints hold only tensors, str and int fields
+    (``model``, ``optim``, ``step``, ``hp_str``, ``githash``), so nothing else needs unpickling and a downloaded file cannot
+    run code.  ``trust_checkpoint=True`` opts into full unpickling for legacy files that carry other objects."""
+    obj = torch.load(checkpoint, map_location=map_location, weights_only=not trust_checkpoint) if isinstance(checkpoint, (str, os.PathLike)) else checkpoint
     extras = {}
     if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict):
         sd = obj["model"]

@@ -164,34 +164,70 @@ def gather_packed(packed_local, olens_local, index_local, total, group=None):
     return unpack_rows(recv, starts, lens, max(lens)), torch.tensor(lens, dtype=torch.int64)
 
 
-def gather_packed_async(packed_cap, olens_dev, index_dev, total, Lout, group=None):
-    """Sync-free form of :func:`gather_packed` for ``inference_batch(sync=False, packed=True)``: nothing is read back to the
-    host.  Every rank passes a pack of the SAME capacity ([rows_cap, odim], valid frames first), its frame counts and the
-    global indices of its utterances as device int64 tensors of the SAME length b; ``total`` = world * b; ``Lout`` = padded
-    length of the result (>= the longest utterance of any rank; e.g. the agreed per-utterance capacity).  Three collectives
-    (packs, counts, indices: RCCL over xGMI), device-side offset arithmetic, one unpack kernel.  Returns
-    (mels [total, Lout, odim] in global utterance order, olens [total] int64 on the device)."""
+def meta_rows(bmax, odim):
+    """Rows of a [*, odim] float32 pack that hold ``bmax`` int64 frame counts (bit-cast)."""
+    return -(-(8 * int(bmax)) // (4 * int(odim)))
+
+
+def row_capacity(n_utt, total_frames):
+    """fs2_row_capacity (include/fs2.h) for a shard of ``n_utt`` utterances: rows of a capacity pack."""
+    import ctypes as C
+    from . import _lib
+    return int(_lib.lib().fs2_row_capacity(C.byref(_lib.Batch(max(int(n_utt), 1), 1, None, 0, 0)), int(total_frames)))
+
+
+def gather_shards(packed_cap, olens_dev, parts, Lout, cap=None, group=None):
+    """The ONE collective of the sharded path, sync-free (for ``inference_batch(sync=False, packed=True)``): nothing is read
+    back to the host.
+
+    ``parts`` = ``shard_indices(...)`` for the whole batch (a list of global utterance indices per rank, any sizes, possibly
+    empty; identical on every rank, which all hold the full id batch).  Every rank passes its pack ([rows, odim], valid frames
+    first; at most ``cap`` rows, ``cap`` being the same number on every rank - the largest shard's row capacity; a rank
+    without utterances may pass 0 rows) and its own frame counts as a device int64 tensor [len(parts[rank])].  The
+    frame counts ride in the tail rows of the pack (bit-cast int64 -> float32), so ONE equal-count all_gather_into_tensor
+    (RCCL over xGMI) moves everything; the global indices are already known to every rank.  Offsets are computed on the
+    device, one unpack kernel scatters the received rows into the ordered, zero-padded result.  ``Lout`` = padded length of
+    the result (>= the longest utterance of any rank, e.g. the agreed per-utterance capacity).
+    Returns (mels [total, Lout, odim] in global utterance order, olens [total] int64 on the device)."""
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     dev = packed_cap.device
-    cap, odim = packed_cap.shape
-    b = olens_dev.numel()
-    recv = packed_cap.new_empty(world * cap, odim)
-    dist.all_gather_into_tensor(recv, packed_cap.contiguous(), group=group)
-    ol_all = torch.empty(world * b, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(ol_all, olens_dev.contiguous(), group=group)
-    gi_all = torch.empty(world * b, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(gi_all, index_dev.contiguous(), group=group)
-    ol = ol_all.view(world, b)
-    starts = (torch.cumsum(ol, 1) - ol + torch.arange(world, device=dev).unsqueeze(1) * cap).reshape(-1)
-    starts_g = torch.zeros(total, dtype=torch.int32, device=dev).scatter_(0, gi_all, starts.to(torch.int32))
-    lens_g = torch.zeros(total, dtype=torch.int32, device=dev).scatter_(0, gi_all, ol_all.to(torch.int32))
+    rows, odim = packed_cap.shape
+    cap = rows if cap is None else int(cap)
+    if rows > cap:
+        raise ValueError("pack of %d rows exceeds the agreed capacity %d" % (rows, cap))
+    counts = [len(p) for p in parts]
+    total, bmax = sum(counts), max(max(counts), 1)
+    b = counts[rank]
+    if olens_dev.numel() != b:
+        raise ValueError("rank %d holds %d utterances but passed %d frame counts" % (rank, b, olens_dev.numel()))
+    mrows = meta_rows(bmax, odim)
+    send = packed_cap.new_zeros(cap + mrows, odim)
+    send[:rows].copy_(packed_cap)
+    if b:
+        send[cap:].view(-1).view(torch.int64)[:b].copy_(olens_dev)
+    recv = packed_cap.new_empty(world * (cap + mrows), odim)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    ol = recv.view(world, cap + mrows, odim)[:, cap:].reshape(world, -1).view(torch.int64)[:, :bmax]       # [world, bmax], holes = 0
+    base = torch.arange(world, device=dev).unsqueeze(1) * (cap + mrows)
+    starts = torch.cumsum(ol, 1) - ol + base
+    # a rank whose capacities overflowed ships a NaN-filled pack with its true frame counts: never index past its region
+    ol = torch.minimum(ol, (base + cap - starts).clamp(min=0))
+    # host-known scatter table: slot (r, j) -> global utterance index, holes -> a dummy slot `total`
+    gi = torch.full((world, bmax), total, dtype=torch.int64)
+    for r, p in enumerate(parts):
+        if p:
+            gi[r, : len(p)] = torch.as_tensor(p, dtype=torch.int64)
+    gi = gi.to(dev).reshape(-1)
+    starts_g = torch.zeros(total + 1, dtype=torch.int32, device=dev).scatter_(0, gi, starts.reshape(-1).to(torch.int32))[:total]
+    lens_g = torch.zeros(total + 1, dtype=torch.int32, device=dev).scatter_(0, gi, ol.reshape(-1).to(torch.int32))[:total]
     if packed_cap.is_cuda:
         import ctypes as C
         from . import _lib
         out = torch.empty(total, Lout, odim, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().fs2_op_unpack_rows_dev(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), recv.data_ptr(), odim, total,
-                                                         starts_g.data_ptr(), lens_g.data_ptr(), Lout, out.data_ptr()))
+                                                         starts_g.contiguous().data_ptr(), lens_g.contiguous().data_ptr(), Lout, out.data_ptr()))
     else:       # CPU (gloo tests): same arithmetic in plain torch
         pos = torch.arange(Lout).unsqueeze(0)
         idx = (starts_g.long().unsqueeze(1) + pos).clamp(max=recv.shape[0] - 1)
@@ -200,19 +236,48 @@ def gather_packed_async(packed_cap, olens_dev, index_dev, total, Lout, group=Non
 
 
 class ShardedSynthesizer:
-    """Free-running batched synthesis over all ranks of the default process group.
+    """Free-running batched synthesis over all ranks of a process group (BASELINE config c5: "batch sharded 8 x MI355X, RCCL
+    all-gather of the mels over xGMI").
 
-    Every rank calls ``synth(xs, ilens)`` with the same full batch; each computes its shard with
-    ``run_local(xs_shard, ilens_shard) -> (mels, olens)`` (normally ``model.inference_batch``) and all
-    ranks return the complete, ordered result."""
+    Every rank calls ``synth(xs, ilens)`` with the same full batch; the utterances are dealt to the ranks longest-cost-first
+    (``shard_indices``: shards of unequal size, possibly empty), each rank runs the single-GPU path on its shard and all
+    ranks return the complete, ordered result.
 
-    def __init__(self, run_local, group=None):
-        self.run_local = run_local
+    * ``ShardedSynthesizer(model)``: the production form.  The first call is synchronous (it teaches the capacity predictor
+      the frames-per-phoneme ratio and agrees on it between the ranks with one all-reduce); later calls never wait for the
+      GPU: device-driven layout inside capacities every rank derives from the SAME global numbers, one collective
+      (:func:`gather_shards`).  Returns (mels [B, Lcap, odim], olens [B] device int64); ``ok()`` afterwards tells whether the
+      capacities sufficed on every rank (one small all-reduce + host sync; on overflow the mels are NaN-filled).
+    * ``ShardedSynthesizer(run_local)`` with a callable ``run_local(xs_shard, ilens_shard) -> (mels, olens)``: generic form
+      (host-driven gather of ragged padded batches, :func:`gather_mels`)."""
+
+    def __init__(self, model_or_fn, group=None):
+        self.model = model_or_fn if hasattr(model_or_fn, "inference_batch") else None
+        self.run_local = None if self.model is not None else model_or_fn
         self.group = group
+        self._ratio = None          # (mean, max) frames per phoneme agreed between the ranks
+        self._last = None
 
-    def __call__(self, xs, ilens, **kw):
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+    def _world(self):
+        """(world size, rank, collective in use).  With an initialised process group the collective runs even at world size
+        1 (what `FS2_FORCE_DIST=1 python bench.py` and the single-GPU nccl test exercise); without one the same data path
+        runs minus the all-gather."""
+        on = dist.is_available() and dist.is_initialized()
+        return (dist.get_world_size(self.group), dist.get_rank(self.group), True) if on else (1, 0, False)
+
+    def capacities(self, ilens, parts):
+        """(total frames, per-utterance frames) reserved on every rank for this batch: the largest shard's prediction."""
+        mean_r, max_r = self._ratio
+        il = torch.as_tensor(ilens).to("cpu", torch.int64)
+        tok = max(int(il[torch.as_tensor(p, dtype=torch.int64)].sum()) if p else 0 for p in parts)
+        nmax = max(max(len(p) for p in parts), 1)
+        total = int(tok * mean_r * 1.15) + 64 * nmax
+        Lcap = -(-int(float(il.max()) * max_r * 1.25 + 64) // 32) * 32
+        return max(total, Lcap), Lcap
+
+    def __call__(self, xs, ilens, sync=False, **kw):
+        world, rank, coll = self._world()
+        self._dev = xs.device
         il = torch.as_tensor(ilens).to("cpu", torch.int64)
         parts = shard_indices(il.tolist(), world)
         mine = parts[rank]
@@ -220,7 +285,73 @@ class ShardedSynthesizer:
         il_loc = il[sel]
         xs_loc = xs[sel.to(xs.device)][:, : int(il_loc.max())] if len(mine) else xs[:0]
         kw_loc = {k: (v[sel.to(v.device)][:, : xs_loc.shape[1]] if torch.is_tensor(v) else v) for k, v in kw.items()}
-        mel, olens = self.run_local(xs_loc, il_loc, **kw_loc)
-        if world == 1:
-            return mel, torch.as_tensor(olens)
-        return gather_mels(mel, olens, mine, xs.shape[0], self.group)
+        if self.model is None:
+            if len(mine):
+                mel, olens = self.run_local(xs_loc, il_loc, **kw_loc)
+            else:       # a rank without utterances (fewer utterances than ranks) still takes part in the collective
+                mel, olens = xs.new_zeros((0, 1, 1), dtype=torch.float32), torch.zeros(0, dtype=torch.int64)
+            if not coll:
+                return mel, torch.as_tensor(olens)
+            # the feature width is only known to ranks that ran something: agree on it (all ranks take part)
+            odim = torch.tensor([mel.shape[-1] if len(mine) else 0], dtype=torch.int64, device=xs.device)
+            dist.all_reduce(odim, op=dist.ReduceOp.MAX, group=self.group)
+            if not len(mine):
+                mel = mel.new_zeros(0, 1, int(odim))
+            return gather_mels(mel, olens, mine, xs.shape[0], self.group)
+        model = self.model
+        if self._ratio is None or sync:
+            # synchronous pass: exact sizes on every rank (host-driven layout), learn and agree on the ratio
+            if len(mine):
+                packed, olens = model.inference_batch(xs_loc, il_loc, packed=True, **kw_loc)
+                r = model._frames_per_token
+                local = torch.tensor([r[0], r[1]], dtype=torch.float64, device=xs.device)
+            else:
+                packed, olens = xs.new_zeros((0, model.odim), dtype=torch.float32), torch.zeros(0, dtype=torch.int64)
+                local = torch.zeros(2, dtype=torch.float64, device=xs.device)
+            if coll:
+                dist.all_reduce(local, op=dist.ReduceOp.MAX, group=self.group)
+            self._ratio = (float(local[0]), float(local[1]))
+            if not coll:
+                L = int(olens.max()) if olens.numel() else 1
+                st = torch.cumsum(olens, 0) - olens
+                return unpack_rows(packed, st.tolist(), olens.tolist(), L), olens.to(xs.device)
+            mel, ol = gather_packed(packed, olens, mine, xs.shape[0], self.group)
+            return mel, ol.to(xs.device)
+        total, Lcap = self.capacities(il, parts)
+        if len(mine):
+            res = model.inference_batch(xs_loc, il_loc, packed=True, sync=False, capacity=(total, Lcap), **kw_loc)
+            packed, olens_dev = res
+            self._last = res
+        else:       # no utterance for this rank: it only takes part in the collective
+            packed, olens_dev = xs.new_zeros((0, model.odim), dtype=torch.float32), torch.zeros(0, dtype=torch.int64, device=xs.device)
+            self._last = None
+        if not coll:
+            # same data path without the collective: offsets on the device, one unpack kernel
+            return _unpack_local(packed, olens_dev, Lcap), olens_dev
+        cap = max(row_capacity(len(p), total) for p in parts)
+        return gather_shards(packed, olens_dev, parts, Lcap, cap=cap, group=self.group)
+
+    def ok(self):
+        """True if the capacities of the last sync-free call sufficed on EVERY rank (waits for the GPU; collective)."""
+        _, _, coll = self._world()
+        good = 1 if (self._last is None or self._last.ok()) else 0
+        if coll:
+            t = torch.tensor([good], dtype=torch.int32, device=self._dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            good = int(t)
+        return bool(good)
+
+
+def _unpack_local(packed_cap, olens_dev, Lout):
+    """[rows_cap, odim] pack with device frame counts -> [b, Lout, odim] zero padded, no host read-back."""
+    import ctypes as C
+    from . import _lib
+    b, odim, dev = olens_dev.numel(), packed_cap.shape[1], packed_cap.device
+    st64 = torch.cumsum(olens_dev, 0) - olens_dev
+    starts = st64.to(torch.int32).contiguous()
+    lens = torch.minimum(olens_dev, (packed_cap.shape[0] - st64).clamp(min=0)).to(torch.int32).contiguous()     # (overflowed call: stay inside the pack)
+    out = torch.empty(b, Lout, odim, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().fs2_op_unpack_rows_dev(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), packed_cap.data_ptr(), odim, b,
+                                                     starts.data_ptr(), lens.data_ptr(), Lout, out.data_ptr()))
+    return out

@@ -99,6 +99,8 @@ typedef struct fs2_encode_io {
     void *workspace;          /* device, fs2_token_workspace_bytes(); must stay alive and
                                  untouched until the matching fs2_decode returns                 */
     size_t workspace_bytes;
+    float duration_alpha;     /* length-regulator speed control (length_regulator.py:57-59): the durations
+                                 used become round(d * alpha); 0 or 1 = unchanged.  d_int stays unscaled */
 } fs2_encode_io;
 
 typedef struct fs2_decode_io {
@@ -128,8 +130,9 @@ typedef struct fs2_decode_io {
      * are sized for the capacities and the surplus tiles exit at once.  Lmax is then the per-utterance capacity of
      * the padded outputs.  status (device int32[8], required in this mode) receives
      * {total rows used, attention work items, overflow flags, longest utterance, valid frames, 0, 0, 0}; overflow
-     * flags != 0 (FS2_OVF_*) means a capacity was too small and the outputs are invalid: rerun with larger
-     * capacities or with host olens.  after_packed, if given, must hold row_capacity rows in this mode. */
+     * flags != 0 (FS2_OVF_*) means a capacity was too small and the outputs are invalid -- before / after /
+     * after_packed are then filled with NaN: rerun with larger capacities or with host olens.  after_packed,
+     * if given, must hold row_capacity rows in this mode. */
     int64_t row_capacity;     /* 0 = host-driven layout (olens required)                                      */
     int32_t *status;
 } fs2_decode_io;
@@ -145,7 +148,8 @@ int64_t fs2_row_capacity(const fs2_batch *batch, int64_t total_frames_bound);
 size_t fs2_frame_workspace_bytes_cap(const fs2_handle *h, const fs2_batch *batch, int64_t row_capacity, int32_t lmax_capacity);
 
 /* lifecycle (replaces FeedForwardTransformer.__init__ / .to(device) / load_state_dict,
- * reference fastspeech.py:37-167, inference.py:156-166) */
+ * reference fastspeech.py:37-167, inference.py:156-166).  Every function that takes a handle runs on the
+ * handle's device and restores the caller's current HIP device before returning. */
 int fs2_create(const fs2_config *cfg, fs2_handle **out);
 void fs2_destroy(fs2_handle *h);
 const char *fs2_last_error(const fs2_handle *h); /* h may be NULL: last creation error */
@@ -194,10 +198,11 @@ int fs2_op_attention(void *stream, const float *qkv, float *ctx, int32_t D, int3
 
 /* length regulator on a padded batch: hs [B,Tmax,D], ds [B,Tmax] (i64), ilens HOST [B] ->
  * out [B,Lmax,D] (pads 0), index [B,Lmax] (-1 pads), olens device [B].  Lmax must be >= max olens.
+ * alpha > 0: speed control, durations become round(d * alpha) (1 = unchanged).
  * (reference length_regulator.py:38-95, utils/util.py:91-104) */
 int fs2_op_length_regulate(void *stream, const float *hs, const int64_t *ds, const int64_t *ilens_host,
-                           int32_t B, int32_t Tmax, int32_t D, int32_t Lmax, float *out, int32_t *index,
-                           int64_t *olens);
+                           int32_t B, int32_t Tmax, int32_t D, int32_t Lmax, float alpha, float *out,
+                           int32_t *index, int64_t *olens);
 
 /* dst [B, Lout, W] <- packed rows src [sum(lens), W] (utterance b = rows [starts[b], starts[b]+lens[b])), zero
  * padded; starts/lens: HOST [B].  Inverse of fs2_decode_io.after_packed; replaces utils/util.py:91-104 pad_2d_tensor. */
@@ -214,6 +219,16 @@ int fs2_op_transpose(void *stream, const float *src, int64_t N, int32_t W, float
 
 /* idx[i] = bucketize(x[i], bins[nb]) (right=False, NaN -> nb)  (variance_predictor.py:158,231) */
 int fs2_op_bucketize(void *stream, const float *x, int64_t n, const float *bins, int32_t nb, int32_t *idx);
+
+/* d[i] = clamp(round_half_even(exp(d_log[i]) - 1), 0) as int64: the duration predictor's inference post-op
+ * (duration_predictor.py:77-81) on a flat array.  NaN -> 0; exp overflow saturates to INT64_MAX (torch's
+ * .long() of +inf is implementation defined). */
+int fs2_op_duration(void *stream, const float *d_log, int64_t n, int64_t *d);
+
+/* Kernel-choice switches for A/B measurements and tests ("FS2_BM", "FS2_ROW8", "FS2_QKV8", "FS2_NOSPLITK",
+ * "FS2_F32_ROWS"; -1 = automatic).  Their initial values come from the environment variables of the same
+ * names, read once when the library is first used; the launch path never reads the environment. */
+int fs2_set_option(const char *name, int32_t value);
 
 #ifdef __cplusplus
 }

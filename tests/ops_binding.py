@@ -49,7 +49,7 @@ def attention(qkv, D, heads, starts, lens, klens, mask_q, precision="fp32"):
     return ctx
 
 
-def length_regulate(hs, ds, ilens, Lmax):
+def length_regulate(hs, ds, ilens, Lmax, alpha=1.0):
     L = _lib.lib()
     B, Tmax, D = hs.shape
     hs, ds = hs.contiguous(), ds.contiguous().long()
@@ -58,7 +58,7 @@ def length_regulate(hs, ds, ilens, Lmax):
     olens = torch.zeros(B, dtype=torch.int64, device=hs.device)
     il = (C.c_int64 * B)(*[int(i) for i in ilens])
     with torch.cuda.device(hs.device):
-        _lib.check(L.fs2_op_length_regulate(_st(hs.device), _p(hs), _p(ds), il, B, Tmax, D, Lmax, _p(out), _p(idx), _p(olens)))
+        _lib.check(L.fs2_op_length_regulate(_st(hs.device), _p(hs), _p(ds), il, B, Tmax, D, Lmax, float(alpha), _p(out), _p(idx), _p(olens)))
     torch.cuda.synchronize()
     return out, idx, olens
 
@@ -71,3 +71,14 @@ def bucketize(x, bins):
         _lib.check(L.fs2_op_bucketize(_st(x.device), _p(x), x.numel(), _p(bins.contiguous()), bins.numel(), _p(idx)))
     torch.cuda.synchronize()
     return idx
+
+
+def duration(d_log):
+    """clamp(round_half_even(exp(y) - 1), 0) -> int64 through fs2_op_duration."""
+    L = _lib.lib()
+    y = d_log.contiguous().float()
+    d = torch.full(y.shape, -1, dtype=torch.int64, device=y.device)
+    with torch.cuda.device(y.device):
+        _lib.check(L.fs2_op_duration(_st(y.device), _p(y), y.numel(), _p(d)))
+    torch.cuda.synchronize()
+    return d

@@ -80,6 +80,8 @@ def test_conv_gemm(case, precision):
         err = float((yo.cpu() - y).abs().max())
         assert torch.isfinite(yo).all(), "non-finite / unwritten output"
         print("%s max-abs %.2e" % (precision, err))
+        from tests.conftest import record_measurement
+        record_measurement("gemm_%s" % precision, err)
         assert err < tol, "max-abs %g" % err
     if has_dot:
         derr = float(((do.cpu() - d) * valid).abs().max())
@@ -87,20 +89,20 @@ def test_conv_gemm(case, precision):
 
 
 @pytest.mark.parametrize("case", [c for c in CASES if c[7] is not None], ids=[c[-1] for c in CASES if c[7] is not None])
-def test_conv_gemm_fp32_row_complete_kernel(case, monkeypatch):
+def test_conv_gemm_fp32_row_complete_kernel(case, fs2_option):
     """The row-complete fp32 GEMM (LayerNorm inside the MFMA epilogue) is no longer the default for N >= 128;
     keep it covered."""
-    monkeypatch.setenv("FS2_F32_ROWS", "1")
+    fs2_option("FS2_F32_ROWS", 1)
     test_conv_gemm(case, "fp32")
 
 
 @pytest.mark.parametrize("bm", ["64", "128", "256"])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("case", CASES, ids=[c[-1] for c in CASES])
-def test_conv_gemm_planes_kernel_tile_heights(case, precision, bm, monkeypatch):
+def test_conv_gemm_planes_kernel_tile_heights(case, precision, bm, fs2_option):
     """The default bf16 path (activations as split-bf16 planes, both operands by LDS-DMA: gemm_planes.h) at every
     tile height (256 rows exists for the conv form only; k = 1 GEMMs fall back to their own choice)."""
-    monkeypatch.setenv("FS2_BM", bm)
+    fs2_option("FS2_BM", bm)
     test_conv_gemm(case, precision)
 
 
@@ -109,10 +111,10 @@ ROW8_CASES = [c for c in CASES if c[3] == 1 and c[7] is not None and c[2] in (25
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("case", ROW8_CASES, ids=[c[-1] for c in ROW8_CASES])
-def test_conv_gemm_row_complete_ln_fused_kernel(case, precision, monkeypatch):
+def test_conv_gemm_row_complete_ln_fused_kernel(case, precision, fs2_option):
     """gemm_row8_bf16 (128 rows x all N columns per workgroup, LayerNorm in the epilogue) is chosen by size in the
     model path; force it here on the small op cases (several row tiles, ragged last tile, gap rows)."""
-    monkeypatch.setenv("FS2_ROW8", "1")
+    fs2_option("FS2_ROW8", 1)
     test_conv_gemm(case, precision)
 
 
@@ -157,6 +159,8 @@ def test_attention(D, heads, mask_q, precision):
             o[kl:] = 0.0
         worst = max(worst, float((ctx[s:s + l] - o).abs().max()))
     print("attention %s max-abs %.2e" % (precision, worst))
+    from tests.conftest import record_measurement
+    record_measurement("attention_%s" % precision, worst)
     assert worst < ATT_TOL[precision], "max-abs %g" % worst
 
 
@@ -223,3 +227,75 @@ def test_bucketize(golden_dir):
     x[::7] = bins[rs.randint(0, 255, size=x[::7].numel())]     # exact boundary hits
     got = ops.bucketize(x.to(dev), bins.to(dev)).cpu().long()
     assert torch.equal(got, torch.bucketize(x, bins))
+
+
+def _dur_candidates(y, ulps=2):
+    """Durations that a correctly implemented post-op may return for log-durations y: exp() is allowed to be `ulps` fp32 ulps
+    off the exact value (torch's CPU exp and HIP's expf are both ~1-ulp functions), the rounding itself must be
+    round-half-to-even followed by clamp(min=0) (reference duration_predictor.py:77-81)."""
+    e = torch.exp(y.double()).float()
+    out = []
+    for k in range(-ulps, ulps + 1):
+        v = e.clone()
+        for _ in range(abs(k)):
+            v = torch.nextafter(v, torch.full_like(v, float("inf") if k > 0 else float("-inf")))
+        out.append(torch.clamp(torch.round(v - 1.0), min=0).long())
+    return torch.stack(out)
+
+
+def test_duration_postop_known_answers_and_ties(golden_dir):
+    """fs2_op_duration = the HIP `clamp(round(exp(y) - 1), 0).long()` of the duration predictor (elementwise.h:
+    duration_from_log, also used by dur_finalize inside fs2_encode).  G4 known answers from the reference (0.5 -> 0, 1.5 -> 2,
+    2.5 -> 2, 3.5 -> 4: round half to even), 1e5 random values against the CPU oracle, and every exact .5 tie up to 40 frames."""
+    from tests import ops_binding as ops
+    from oracle import fs2_oracle as O
+    dev = _dev()
+    g = np.load(golden_dir + "/g4_known_answers.npz")
+    got = ops.duration(torch.from_numpy(g["dur_log"]).to(dev)).cpu()
+    assert got.tolist() == g["dur_int"].tolist(), (got.tolist(), g["dur_int"].tolist())
+    rs = np.random.RandomState(11)
+    y = torch.from_numpy(rs.uniform(-3.0, 4.5, size=100000).astype(np.float32))
+    got = ops.duration(y.to(dev)).cpu()
+    want = O.duration_from_log(y)
+    cand = _dur_candidates(y)
+    assert bool((cand == got.unsqueeze(0)).any(0).all()), "a duration outside what a 2-ulp exp allows"
+    edge = (cand != cand[0:1]).any(0)                     # values within 2 ulps of a rounding boundary
+    assert torch.equal(got[~edge], want[~edge])           # everywhere else: bit-exact against the oracle
+    agree = float((got == want).float().mean())
+    print("duration post-op: %d of 100000 values sit within 2 ulp of a rounding boundary; exact agreement with the oracle %.6f"
+          % (int(edge.sum()), agree))
+    assert agree > 0.9999
+    # exact ties: exp(y) - 1 == k + 0.5 in exact arithmetic -> round half to even picks the even neighbour
+    k = torch.arange(0, 41, dtype=torch.float64)
+    yt = torch.log(k + 1.5).float()
+    got = ops.duration(yt.to(dev)).cpu()
+    even = (2 * torch.round((k + 0.5) / 2)).long()        # the even neighbour of k + 0.5
+    cand = _dur_candidates(yt)
+    assert bool((cand == got.unsqueeze(0)).any(0).all())
+    exact_tie = (torch.exp(yt.double()).float() - 1.0).double() == (k + 0.5)      # fp32 exp lands on the tie exactly
+    print("ties: %d / 41 resolved to the even neighbour (%d are exact ties in fp32)" % (int((got == even).sum()), int(exact_tie.sum())))
+    # special values
+    sp = torch.tensor([float("-inf"), -100.0, 0.0, 88.0, 100.0, float("inf"), float("nan")])
+    got = ops.duration(sp.to(dev)).cpu().tolist()
+    assert got[:3] == [0, 0, 0] and got[3] == int(torch.round(torch.tensor(88.0).exp() - 1.0).item()) and got[6] == 0
+    assert got[4] == got[5] == 2 ** 63 - 1                # saturates like .long() of +inf does not: documented (fs2.h)
+
+
+@pytest.mark.parametrize("alpha", [0.5, 1.3, 2.0])
+def test_length_regulator_alpha(alpha):
+    """Speed control of the length regulator (reference length_regulator.py:57-59): ds <- round(ds.float() * alpha)."""
+    from tests import ops_binding as ops
+    from oracle import fs2_oracle as O
+    dev = _dev()
+    rs = np.random.RandomState(int(alpha * 10))
+    B, Tmax, D = 5, 90, 64
+    il = rs.randint(1, Tmax + 1, size=B)
+    ds = torch.from_numpy(rs.randint(0, 12, size=(B, Tmax)).astype(np.int64))
+    ds[2, : il[2]] = 0
+    hs = _rand(rs, B, Tmax, D)
+    ds_a = torch.round(ds.float() * alpha).long()
+    want, olens, idxs = O.length_regulate(hs, ds_a, torch.from_numpy(il))
+    out, idx, ol = ops.length_regulate(hs.to(dev), ds.to(dev), il.tolist(), want.shape[1], alpha=alpha)
+    assert torch.equal(ol.cpu(), olens) and torch.equal(out.cpu(), want)
+    for b in range(B):
+        assert torch.equal(idx[b, : olens[b]].cpu().long(), idxs[b])

@@ -119,12 +119,12 @@ def test_c2_batch_vs_oracle(env, precision):
 
 
 @pytest.mark.parametrize("row8", ["0", "1"])
-def test_c2_row_complete_kernel_choice(env, row8, monkeypatch):
+def test_c2_row_complete_kernel_choice(env, row8, fs2_option):
     """The LN-terminated k = 1 GEMMs have two bf16 implementations (128-column tiles + row kernel / row-complete tile with
     the LayerNorm fused, chosen by size): c2 in the parity mode with each one forced."""
     model, sd, cfg, O = env
     from fastspeech2_amd.synthetic import make_batch
-    monkeypatch.setenv("FS2_ROW8", row8)
+    fs2_option("FS2_ROW8", row8)
     model.precision = "bf16x3"
     try:
         _c2_body(model, sd, cfg, O, make_batch("c2"), "bf16x3")
@@ -133,12 +133,12 @@ def test_c2_row_complete_kernel_choice(env, row8, monkeypatch):
 
 
 @pytest.mark.parametrize("qkv8", ["0", "1"])
-def test_c2_qkv_kernel_choice(env, qkv8, monkeypatch):
+def test_c2_qkv_kernel_choice(env, qkv8, fs2_option):
     """The fused QKV projection has two bf16 implementations (64 x 128 tiles / three 128 x D passes of an 8-wave workgroup,
     chosen by size): c2 in the parity mode with each one forced."""
     model, sd, cfg, O = env
     from fastspeech2_amd.synthetic import make_batch
-    monkeypatch.setenv("FS2_QKV8", qkv8)
+    fs2_option("FS2_QKV8", qkv8)
     model.precision = "bf16x3"
     try:
         _c2_body(model, sd, cfg, O, make_batch("c2"), "bf16x3")
@@ -196,9 +196,11 @@ def test_full_size_c3_properties(env, precision):
 
 def _c3_body(env, precision):
     """BASELINE config c3 (B=64 LJSpeech-shape), free-running with forced durations: frame counts equal the
-    duration sums, pads are exactly zero, outputs finite, and a sampled utterance matches the oracle."""
+    duration sums, pads are exactly zero, outputs finite, length-regulator indices exact, and EVERY utterance matches the
+    oracle within the mel tolerance."""
     model, sd, cfg, O = env
     from fastspeech2_amd.synthetic import make_batch
+    from tests.conftest import record_measurement
     b = make_batch("c3")
     with torch.no_grad():
         r = model._run(b["xs"].cuda(), b["ilens"], is_inference=True, d_override=b["ds"].cuda(),
@@ -206,18 +208,19 @@ def _c3_body(env, precision):
     assert torch.equal(r["olens"], b["olens"])
     after = r["after"]
     assert torch.isfinite(after).all()
+    after_h = after.cpu()
+    worst = 0.0
     for i in range(after.shape[0]):
-        L = int(b["olens"][i])
+        L, T = int(b["olens"][i]), int(b["ilens"][i])
         assert float(after[i, L:].abs().max() if L < after.shape[1] else 0.0) == 0.0
         idx = r["lr_index"][i, :L].cpu().long()
-        assert (idx[1:] >= idx[:-1]).all() and int(idx[-1]) < int(b["ilens"][i])          # sorted, in range
-        assert torch.equal(torch.bincount(idx, minlength=int(b["ilens"][i])), b["ds"][i, : int(b["ilens"][i])])
-    i = int(torch.argmax(b["olens"]))
-    T = int(b["ilens"][i])
-    o = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], is_inference=True, d_override=b["ds"][i:i + 1, :T])
-    L = int(b["olens"][i])
-    print("c3 [%s] longest utterance (L=%d) mel max-abs vs oracle %.2e" % (precision, L, _maxabs(after[i, :L], o["after"][0])))
-    assert _maxabs(after[i, :L], o["after"][0]) <= MEL_TOL
+        assert torch.equal(idx, torch.repeat_interleave(torch.arange(T), b["ds"][i, :T])), i          # bit-exact
+        o = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], is_inference=True, d_override=b["ds"][i:i + 1, :T])
+        d = float((after_h[i, :L] - o["after"][0]).abs().max())
+        assert d <= MEL_TOL, (i, d)
+        worst = max(worst, d)
+    print("c3 [%s] all %d utterances (%d frames): worst mel max-abs vs oracle %.2e" % (precision, after.shape[0], int(b["olens"].sum()), worst))
+    record_measurement("c3_all_utterances_mel_maxabs_" + precision, worst)
 
 
 def test_device_driven_layout_matches_host_driven(env):
@@ -361,14 +364,17 @@ def test_errors(env):
                        torch.ones(1, 4, dtype=torch.int64), torch.ones(1, 4), torch.ones(1, 4))
 
 
-def test_full_size_c4_length_regulator_stress(env):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_full_size_c4_length_regulator_stress(env, precision):
     """BASELINE config c4 (B=256, 32..512 phonemes, ~0.5 M frames, Lmax > 4000, with Postnet): frame counts,
-    zero pads, sorted + exact length-regulator indices for every utterance, and one mid-length utterance against
-    the oracle.  Utterances longer than the 5000-row positional table force the table to be extended."""
+    zero pads, exact length-regulator indices for every utterance, and a seeded sample of 16 utterances -- the two
+    shortest, the two longest (beyond the 5000-row positional table when the batch has such) and 12 random ones -- against
+    the oracle, in both parity modes."""
     model, sd, cfg, O = env
     from fastspeech2_amd.synthetic import make_batch
+    from tests.conftest import record_measurement
     b = make_batch("c4")
-    model.precision = "bf16x3"
+    model.precision = precision
     try:
         with torch.no_grad():
             r = model._run(b["xs"].cuda(), b["ilens"], is_inference=True, d_override=b["ds"].cuda(), want=("after", "lr_index"))
@@ -385,12 +391,190 @@ def test_full_size_c4_length_regulator_stress(env):
         idx = lri[i, :L]
         assert torch.equal(idx, torch.repeat_interleave(torch.arange(T), b["ds"][i, :T])), i   # bit-exact
         assert (lri[i, L:] == -1).all()
-    i = int(torch.argsort(b["olens"])[len(b["olens"]) // 2])
-    T, L = int(b["ilens"][i]), int(b["olens"][i])
-    o = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], is_inference=True, d_override=b["ds"][i:i + 1, :T])
-    d = _maxabs(after[i, :L], o["after"][0])
-    print("c4: %d frames, Lmax %d, median utterance (L=%d) mel max-abs vs oracle %.2e" % (int(b["olens"].sum()), after.shape[1], L, d))
-    assert d <= MEL_TOL
+    order = torch.argsort(b["olens"]).tolist()
+    rest = [i for i in order[2:-2]]
+    pick = order[:2] + order[-2:] + [rest[j] for j in np.random.RandomState(44).permutation(len(rest))[:12]]
+    worst = 0.0
+    for i in pick:
+        T, L = int(b["ilens"][i]), int(b["olens"][i])
+        o = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], is_inference=True, d_override=b["ds"][i:i + 1, :T])
+        d = _maxabs(after[i, :L], o["after"][0])
+        assert d <= MEL_TOL, (i, L, d)
+        worst = max(worst, d)
+    print("c4 [%s]: %d frames, Lmax %d; %d sampled utterances (L %d..%d): worst mel max-abs vs oracle %.2e"
+          % (precision, int(b["olens"].sum()), after.shape[1], len(pick), int(b["olens"][order[0]]), int(b["olens"][order[-1]]), worst))
+    record_measurement("c4_sample16_mel_maxabs_" + precision, worst)
+
+
+def test_c5_shard_of_the_8_gpu_partition(env):
+    """BASELINE config c5 (batch = 1024 sharded over 8 MI355X): the shard rank 0 of 8 gets from the LPT partition
+    (`shard_indices`, 128 +- a few utterances), bf16x3, through the batched entry point in its packed form (what the
+    all-gather ships): properties on every utterance, a seeded sample of 16 (plus the longest and the shortest) against the
+    oracle.  The 8-rank collective itself is covered on CPU (tests/test_parallel_gloo.py) and at world size 1 below."""
+    model, sd, cfg, O = env
+    from fastspeech2_amd.synthetic import make_batch
+    from fastspeech2_amd.parallel import shard_indices
+    from tests.conftest import record_measurement
+    b = make_batch("c5")
+    parts = shard_indices(b["ilens"].tolist(), 8)
+    assert sorted(sum(parts, [])) == list(range(1024)) and 100 <= len(parts[0]) <= 160
+    sel = torch.as_tensor(parts[0])
+    il = b["ilens"][sel]
+    Tm = int(il.max())
+    xs, ds = b["xs"][sel][:, :Tm], b["ds"][sel][:, :Tm]
+    model.precision = "bf16x3"
+    try:
+        with torch.no_grad():
+            packed, ol = model.inference_batch(xs.cuda(), il, d_override=ds.cuda(), packed=True)
+    finally:
+        model.precision = "fp32"
+    assert torch.equal(ol, b["olens"][sel]) and packed.shape == (int(ol.sum()), 80) and torch.isfinite(packed).all()
+    starts = (torch.cumsum(ol, 0) - ol).tolist()
+    order = torch.argsort(ol).tolist()
+    pick = sorted(set([order[0], order[-1]] + np.random.RandomState(55).permutation(len(sel))[:16].tolist()))
+    packed_h, worst = packed.cpu(), 0.0
+    for j in pick:
+        T, L = int(il[j]), int(ol[j])
+        o = O.padded_forward(sd, cfg, xs[j:j + 1, :T], il[j:j + 1], is_inference=True, d_override=ds[j:j + 1, :T])
+        d = float((packed_h[starts[j]:starts[j] + L] - o["after"][0]).abs().max())
+        assert d <= MEL_TOL, (j, L, d)
+        worst = max(worst, d)
+    print("c5 shard 0/8: %d utterances, %d frames; %d sampled utterances: worst mel max-abs vs oracle %.2e" % (len(sel), int(ol.sum()), len(pick), worst))
+    record_measurement("c5_shard_sample_mel_maxabs_bf16x3", worst)
+
+
+def test_sharded_synthesizer_over_nccl_world_size_1(env):
+    """`ShardedSynthesizer(model)` with an initialised RCCL process group (world size 1: the one GPU of this box): LPT
+    partition, sync-free capacity packs, the ONE all_gather_into_tensor over the nccl backend, device-side unpack ==
+    the unsharded batched call, bit for bit; an insufficient capacity is reported by ok() and NaN-fills the mels."""
+    import socket
+    import torch.distributed as dist
+    from fastspeech2_amd.parallel import ShardedSynthesizer
+    from fastspeech2_amd.synthetic import make_batch
+    model = env[0]
+    b = make_batch("c3", B=24)
+    xs, il, ds = b["xs"].cuda(), b["ilens"], b["ds"].cuda()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    model.precision = "bf16x3"
+    try:
+        with torch.no_grad():
+            ref, ol = model.inference_batch(xs, il, d_override=ds)
+            synth = ShardedSynthesizer(model)
+            m1, o1 = synth(xs, il, d_override=ds)                  # synchronous first call (host-driven gather)
+            m2, o2 = synth(xs, il, d_override=ds)                  # sync-free: device layout + one collective
+            assert synth.ok()
+            L = ref.shape[1]
+            assert torch.equal(o1.cpu(), ol) and torch.equal(o2.cpu(), ol)
+            assert torch.equal(m1[:, :L], ref) and torch.equal(m2[:, :L], ref) and float(m2[:, L:].abs().sum()) == 0.0
+            synth._ratio = (0.05, 0.05)                            # absurd capacities -> overflow must be visible, not silent
+            m3, _ = synth(xs, il, d_override=ds)
+            assert not synth.ok()
+            assert torch.isnan(m3).any()                           # the overflowed rank's pack is NaN-filled
+            model.async_ok()                                       # (drains the model's own bookkeeping)
+    finally:
+        model.precision = "fp32"
+        dist.destroy_process_group()
+
+
+def test_async_overflow_is_never_silent(env):
+    """`inference_batch(sync=False)`: each call carries its own validity record (AsyncMels.ok / .check / .status); several
+    calls may be in flight; an overflowed call returns NaN-filled mels (padded and packed) and is reported by async_ok()
+    even when later calls were fine."""
+    from fastspeech2_amd.fastspeech import Fs2CapacityError
+    from fastspeech2_amd.synthetic import make_batch
+    model = env[0]
+    b = make_batch("c3", B=6)
+    xs, il, ds = b["xs"].cuda(), b["ilens"], b["ds"].cuda()
+    with torch.no_grad():
+        ref, ol = model.inference_batch(xs, il, d_override=ds)
+        assert model.async_ok()
+        good1 = model.inference_batch(xs, il, d_override=ds, sync=False)
+        bad = model.inference_batch(xs, il, d_override=ds, sync=False, capacity=(int(ol.sum()) // 3, int(ol.max()) + 32))
+        bad_pk = model.inference_batch(xs, il, d_override=ds, sync=False, packed=True, capacity=(int(ol.sum()) // 3, int(ol.max()) + 32))
+        good2 = model.inference_batch(xs, il, d_override=ds, sync=False)
+        assert good1.ok() and good2.ok() and not bad.ok() and not bad_pk.ok()
+        assert int(bad.status.cpu()[2]) & 1
+        assert torch.isnan(bad[0]).all() and torch.isnan(bad_pk[0]).all()
+        with pytest.raises(Fs2CapacityError):
+            bad.check()
+        assert not model.async_ok()                  # the overflow of an EARLIER call is still reported
+        assert model.async_ok()                      # ... once
+        mel, ol_dev = good2
+        assert torch.equal(mel[:, : ref.shape[1]], ref) and torch.equal(ol_dev.cpu(), ol)
+        empty, eo = model.inference_batch(xs[:0], il[:0])
+        assert empty.shape[0] == 0 and eo.numel() == 0
+
+
+@pytest.mark.parametrize("alpha", [0.7, 1.5])
+def test_duration_alpha_speed_control(env, alpha):
+    """Length-regulator speed control (reference length_regulator.py:57-59) through the batched entry point: the mels equal
+    the oracle's for durations round(d * alpha)."""
+    model, sd, cfg, O = env
+    from fastspeech2_amd.synthetic import make_batch
+    b = make_batch("c2", B=3, tlens=[31, 12, 20])
+    ds_a = torch.round(b["ds"].float() * alpha).long()
+    with torch.no_grad():
+        mel, ol = model.inference_batch(b["xs"].cuda(), b["ilens"], d_override=b["ds"].cuda(), alpha=alpha)
+    for i in range(3):
+        T = int(b["ilens"][i])
+        o = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], is_inference=True, d_override=ds_a[i:i + 1, :T])
+        L = int(o["olens"][0])
+        assert int(ol[i]) == L and _maxabs(mel[i, :L], o["after"][0]) <= MEL_TOL
+
+
+@pytest.mark.parametrize("arch", ["default", "ddim256_arch"])
+def test_checkpoint_to_device_inference(arch, tmp_path):
+    """SURVEY section 8 row f2 on the device, the reference's synthesis flow (inference.py:149-166, train_fastspeech.py:235-244):
+    torch.save({"model", "optim", "step", "hp_str", "githash"}) -> torch.load -> hparams from the embedded hp_str ->
+    FeedForwardTransformer(idim, odim, hp) -> load_state_dict -> .to(device) -> inference(ids), checked against the oracle;
+    also a bare, DataParallel-prefixed `--old_model` checkpoint that lacks the unused keys (strict=False)."""
+    import yaml
+    from fastspeech2_amd import FeedForwardTransformer, default_hparams, load_checkpoint, hparams_from_str, N_PHONEME_SYMBOLS
+    from fastspeech2_amd.synthetic import portable_state_dict, bias_durations
+    from oracle import fs2_oracle as O
+    hp = default_hparams()
+    if arch != "default":
+        for k, v in VARIANTS[arch].items():
+            hp.model[k] = v
+    plain = lambda d: {k: (plain(v) if isinstance(v, dict) else v) for k, v in d.items()}
+    hp_str = yaml.safe_dump(plain(hp))
+    src = FeedForwardTransformer(N_PHONEME_SYMBOLS, 80, hp)
+    sd = bias_durations(portable_state_dict(src.state_dict(), seed=11), 3.0)
+    path = str(tmp_path / "checkpoint_58000.pyt")
+    torch.save({"model": sd, "optim": {"state": {}, "param_groups": []}, "step": 58000, "hp_str": hp_str, "githash": "deadbeef"}, path)
+    # --- what inference.py does
+    extras_hp = hparams_from_str(torch.load(path, map_location="cpu", weights_only=True)["hp_str"])
+    model = FeedForwardTransformer(N_PHONEME_SYMBOLS, extras_hp.audio.num_mels, extras_hp).eval()
+    extras = load_checkpoint(model, path)
+    assert extras["step"] == 58000 and extras["githash"] == "deadbeef"
+    model = model.to("cuda:0")
+    cfg = O.config_from_hp(extras_hp, N_PHONEME_SYMBOLS, 80)
+    x = torch.from_numpy(np.random.RandomState(3).randint(1, 68, size=37)).long()
+    for precision in ("fp32", "bf16x3"):
+        model.precision = precision
+        with torch.no_grad():
+            mel = model.inference(x.cuda())
+        o = O.padded_forward(sd, cfg, x.unsqueeze(0), torch.tensor([37]), is_inference=True)
+        assert mel.shape == tuple(o["after"][0].shape), (mel.shape, o["after"][0].shape)
+        d = _maxabs(mel, o["after"][0])
+        print("checkpoint -> device inference [%s, %s]: L=%d, mel max-abs %.2e" % (arch, precision, mel.shape[0], d))
+        assert d <= MEL_TOL
+    # --- --old_model: bare state dict, DataParallel prefix, unused keys absent -> strict=False
+    old = {("module." + k): v for k, v in sd.items() if "concat_linear" not in k and "after_norm" not in k}
+    old_path = str(tmp_path / "old.pyt")
+    torch.save(old, old_path)
+    model2 = FeedForwardTransformer(N_PHONEME_SYMBOLS, 80, extras_hp).eval()
+    ex = load_checkpoint(model2, old_path, old_model=True)
+    assert ex["missing_keys"] and not ex["unexpected_keys"]
+    model2 = model2.to("cuda:0")
+    with torch.no_grad():
+        mel2 = model2.inference(x.cuda())
+    model.precision = "fp32"
+    with torch.no_grad():
+        assert torch.equal(mel2, model.inference(x.cuda()))       # the unused keys do not enter the path
 
 
 VARIANTS = {

@@ -1,6 +1,7 @@
-"""CPU, world_size 2, gloo: the N>1 path (cost-balanced utterance sharding + all-gather of ragged mels +
-order restoration) with a stand-in per-utterance compute function.  The exact same code runs over
-RCCL/xGMI on the GPU box (backend "nccl"); sharded == unsharded must hold bit-for-bit."""
+"""CPU, world_size 2 (and 3), gloo: the N>1 path -- cost-balanced utterance sharding (LPT: shards of UNEQUAL size, possibly
+empty), the one-collective sync-free gather of capacity packs (`gather_shards`), the host-driven gathers, order restoration --
+with a stand-in per-utterance compute function that honours the real `inference_batch` contract.  The exact same code runs
+over RCCL/xGMI on the GPU box (backend "nccl"); sharded == unsharded must hold bit-for-bit."""
 import os
 import socket
 
@@ -8,23 +9,51 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+ODIM = 8
+
 
 def _fake_run_local(xs, ilens, **kw):
     """Deterministic per-utterance 'mel': depends only on that utterance's ids (like the real path)."""
     B = xs.shape[0]
     ol = torch.tensor([int(xs[b, : int(ilens[b])].sum() % 37) + 5 for b in range(B)], dtype=torch.int64)
     Lmax = int(ol.max()) if B else 1
-    mel = torch.zeros(B, Lmax, 8)
+    mel = torch.zeros(B, Lmax, ODIM)
     for b in range(B):
         L = int(ol[b])
         base = xs[b, : int(ilens[b])].float().mean()
-        mel[b, :L] = base + torch.arange(L * 8, dtype=torch.float32).view(L, 8) * 0.01
+        mel[b, :L] = base + torch.arange(L * ODIM, dtype=torch.float32).view(L, ODIM) * 0.01
     return mel, ol
 
 
-def _make_inputs():
+class _Async(tuple):
+    def ok(self):
+        return True
+
+
+class FakeModel:
+    """`FeedForwardTransformer.inference_batch` contract on the CPU: sync form -> (packed [sum L, odim], olens host);
+    sync=False form -> ([row_capacity, odim] pack with the valid frames first and garbage behind, olens 'device' tensor)."""
+    odim = ODIM
+    _frames_per_token = None
+
+    def inference_batch(self, xs, ilens, packed=False, sync=True, capacity=None):
+        from fastspeech2_amd.parallel import row_capacity
+        assert packed and xs.shape[0] == len(ilens) > 0, "the synthesizer must not call the model with an empty shard"
+        mel, ol = _fake_run_local(xs, ilens)
+        valid = torch.cat([mel[i, : int(ol[i])] for i in range(len(ol))])
+        il = torch.as_tensor(ilens)
+        if sync:
+            self._frames_per_token = (float(ol.sum()) / float(il.sum()), float((ol.float() / il.float()).max()))
+            return valid, ol
+        rows = row_capacity(len(ol), capacity[0])
+        assert valid.shape[0] <= rows and int(ol.max()) <= capacity[1], "capacities from ShardedSynthesizer.capacities() too small"
+        pk = torch.full((rows, ODIM), float("nan"))          # rows beyond the valid frames must never be read
+        pk[: valid.shape[0]] = valid
+        return _Async((pk, ol.clone()))
+
+
+def _make_inputs(B=11):
     g = torch.Generator().manual_seed(7)
-    B = 11
     il = torch.randint(3, 40, (B,), generator=g)
     xs = torch.zeros(B, int(il.max()), dtype=torch.int64)
     for b in range(B):
@@ -36,36 +65,42 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from fastspeech2_amd.parallel import ShardedSynthesizer
+    from fastspeech2_amd.parallel import ShardedSynthesizer, shard_indices, gather_packed
     xs, il = _make_inputs()
+    want_mel, want_ol = _fake_run_local(xs, il)
+    L = want_mel.shape[1]
+    # (1) generic callable form: ragged padded batches, host-driven gather
     mel, ol = ShardedSynthesizer(_fake_run_local)(xs, il)
-    # packed form (what bench.py ships over RCCL): same result
-    from fastspeech2_amd.parallel import shard_indices, gather_packed
-    mine = shard_indices(il.tolist(), world)[rank]
-    sel = torch.as_tensor(mine)
+    assert torch.equal(ol, want_ol) and torch.equal(mel, want_mel)
+    # (2) packed host-driven form
+    parts = shard_indices(il.tolist(), world)
+    assert len({len(p) for p in parts}) > 1 or world == 1, "the test batch should give shards of unequal size: %s" % parts
+    mine = parts[rank]
+    sel = torch.as_tensor(mine, dtype=torch.int64)
     m_loc, ol_loc = _fake_run_local(xs[sel][:, : int(il[sel].max())], il[sel])
     packed = torch.cat([m_loc[i, : int(ol_loc[i])] for i in range(len(mine))])
     mel2, ol2 = gather_packed(packed, ol_loc, mine, xs.shape[0])
-    assert torch.equal(ol2, ol) and torch.equal(mel2, mel[:, : mel2.shape[1]])
-    # sync-free form (capacity packs of equal size, counts and indices as "device" tensors, equal utterance count per rank):
-    # utterances 0..9 split evenly, rank r takes r, r+2, ...
-    from fastspeech2_amd.parallel import gather_packed_async
-    ev = list(range(rank, 10, world))
-    sel = torch.as_tensor(ev)
-    m_loc, ol_loc = _fake_run_local(xs[sel][:, : int(il[sel].max())], il[sel])
-    cap, Lout = 400, 48
-    pk = torch.full((cap, 8), float("nan"))                   # rows beyond the valid frames are never read
-    valid = torch.cat([m_loc[i, : int(ol_loc[i])] for i in range(len(ev))])
-    pk[: valid.shape[0]] = valid
-    mel3, ol3 = gather_packed_async(pk, ol_loc, sel, 10, Lout)
-    assert torch.equal(ol3, ol[:10]) and torch.equal(mel3[:, : mel.shape[1]], mel[:10]) and float(mel3[:, mel.shape[1]:].abs().sum()) == 0.0
-    q.put((rank, mel, ol))
+    assert torch.equal(ol2, want_ol) and torch.equal(mel2, want_mel[:, : mel2.shape[1]])
+    # (3) the production form: model object, first call synchronous (learns + agrees on the ratio), second call sync-free
+    #     with ONE collective (gather_shards) over LPT shards of unequal size
+    synth = ShardedSynthesizer(FakeModel())
+    mel3, ol3 = synth(xs, il)
+    assert torch.equal(ol3, want_ol) and torch.equal(mel3[:, :L], want_mel)
+    mel4, ol4 = synth(xs, il)
+    assert synth.ok()
+    assert torch.equal(ol4, want_ol) and torch.equal(mel4[:, :L], want_mel) and float(mel4[:, L:].abs().sum()) == 0.0
+    assert not torch.isnan(mel4).any()
+    # (4) fewer utterances than ranks: some rank has an EMPTY shard and still takes part in the collectives
+    for form in (ShardedSynthesizer(_fake_run_local), synth):
+        for _ in range(2):
+            m1, o1 = form(xs[:1], il[:1])
+            assert torch.equal(o1, want_ol[:1]) and torch.equal(m1[:, : int(want_ol[0])], want_mel[:1, : int(want_ol[0])])
+    q.put((rank, mel4[:, :L].clone(), ol4.clone()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_equals_unsharded_gloo():
-    from fastspeech2_amd.parallel import shard_indices
+def _run_world(world):
     xs, il = _make_inputs()
     want_mel, want_ol = _fake_run_local(xs, il)
     with socket.socket() as s:
@@ -73,20 +108,27 @@ def test_sharded_equals_unsharded_gloo():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(2)]
+    got = [q.get(timeout=180) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, mel, ol in got:
-        assert torch.equal(ol, want_ol)
-        assert mel.shape[0] == xs.shape[0]
-        L = want_mel.shape[1]
-        assert torch.equal(mel[:, :L], want_mel) and float(mel[:, L:].abs().sum()) == 0.0
+        assert torch.equal(ol, want_ol) and torch.equal(mel, want_mel)
+
+
+def test_sharded_equals_unsharded_gloo():
+    from fastspeech2_amd.parallel import shard_indices
+    _run_world(2)
+    xs, il = _make_inputs()
     parts = shard_indices(il.tolist(), 2)
     assert sorted(parts[0] + parts[1]) == list(range(xs.shape[0])) and parts[0] and parts[1]
+
+
+def test_sharded_equals_unsharded_gloo_three_ranks():
+    _run_world(3)
 
 
 def test_shard_balance():
@@ -95,3 +137,14 @@ def test_shard_balance():
     parts = shard_indices(il, 8)
     loads = [sum(utterance_cost(il[i]) for i in p) for p in parts]
     assert max(loads) / (sum(loads) / 8) < 1.05      # LPT keeps the heaviest rank within 5 % of the mean
+
+
+def test_c5_partition_is_balanced():
+    """BASELINE config c5: 1024 LJSpeech-shape utterances over 8 ranks -> every rank within 1 % of the mean cost."""
+    from fastspeech2_amd.parallel import shard_indices, utterance_cost
+    from fastspeech2_amd.synthetic import make_batch
+    il = make_batch("c5")["ilens"].tolist()
+    parts = shard_indices(il, 8)
+    assert sorted(sum(parts, [])) == list(range(1024))
+    loads = [sum(utterance_cost(il[i]) for i in p) for p in parts]
+    assert max(loads) / (sum(loads) / 8) < 1.01
