@@ -58,6 +58,9 @@ struct GemmArgs {
     // grid.z accumulates chunks [z, z+1) * Cpad/32/ksplit; split 0 (which also adds bias + residual) writes Y, split z > 0 writes
     // kpart + (z-1) * kpart_stride; the row kernel that follows (ln_rows) adds the partials in a fixed order
     int ksplit; float* kpart; size_t kpart_stride;
+    int regime_rows;                       // row count the kernel-variant choice is based on (0: R).  Frame-level launches pass an estimate derived from
+                                           // the PHONEME count, which the host knows in both layout modes, so that the host- and the device-driven
+                                           // layout of one batch always pick the same variants (-> bit-identical results); see fs2_decode
     const int* Rp;                         // device-driven layout: rows actually used (tiles at or beyond round_up(*Rp, 128) exit at once); nullptr: R
 };
 

@@ -124,6 +124,7 @@ struct fs2_handle {
     int* cum = nullptr;
     int* o32 = nullptr;        // device frame counts (int32) left by the duration scan
     int enc_B = 0, enc_Tmax = 0, enc_compat = 0;
+    long enc_ntok = 0;         // phonemes of the encoded batch (basis of the frame-level kernel-variant choice)
     void* enc_ws = nullptr;
     std::vector<void*> graph_pinned;   // host staging owned by captured graphs (see upload_layout)
     // profiling
@@ -241,7 +242,7 @@ hipError_t launch_qkv8_t(hipStream_t s, const GemmArgs& a) {
 bool use_qkv8(const GemmArgs& a) {
     if (!a.qk_hi || a.ktaps != 1 || (a.att_D != 256 && a.att_D != 384) || a.N != 3 * a.att_D) return false;
     if (opts().qkv8 >= 0) return opts().qkv8 != 0;
-    return (a.Rvt + 127) / 128 >= 128;
+    return ((a.regime_rows ? a.regime_rows : a.Rvt) + 127) / 128 >= 128;
 }
 
 // Row-complete LN-fused kernel (gemm_row8_bf16) for k = 1 GEMMs that end in a row epilogue: one workgroup per CU, so it
@@ -249,7 +250,7 @@ bool use_qkv8(const GemmArgs& a) {
 bool use_row8(const GemmArgs& a) {
     if (a.ktaps != 1 || a.dot_w || a.qk_hi || (a.N != 256 && a.N != 384) || !(a.ln_g || a.pe)) return false;
     if (opts().row8 >= 0) return opts().row8 != 0;
-    return (a.R + 127) / 128 >= 128;
+    return ((a.regime_rows ? a.regime_rows : a.R) + 127) / 128 >= 128;
 }
 
 // Tile height of the planes kernel: the largest one that still gives every CU its 2-3 resident workgroups
@@ -548,7 +549,8 @@ struct StackBufs { float *x0, *x1, *qkv, *ctx, *hid; __bf16 *qkh, *qkl, *vth, *v
 
 // x0 holds the input; returns the buffer holding the output (x0 again).
 int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, int D, int heads, int R,
-              const HostLayout& L, const DevLayout& dl, int mask_q, const StackBufs& b, int prec, bool x0p_ready = false, bool allow_splitk = false) {
+              const HostLayout& L, const DevLayout& dl, int mask_q, const StackBufs& b, int prec, bool x0p_ready = false, bool allow_splitk = false,
+              int regime_rows = 0) {
     char nm[96];
     double att_flops = 0;
     for (size_t i = 0; i < L.klen.size(); ++i) att_flops += 4.0 * D * (double)L.klen[i] * std::min(L.len[i], mask_q ? L.klen[i] : L.len[i]);
@@ -567,7 +569,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         int rc;
         snprintf(nm, sizeof nm, "%s.qkv", tag);
         GemmArgs a = gemm_args(ly.qkv, b.x0, D, R, dl.row_pos, b.qkv, 3 * D);
-        a.Rp = dl.dims;
+        a.Rp = dl.dims; a.regime_rows = regime_rows;
         if (pl) a.Xp = b.x0p;
         const bool fused_split = prec != FS2_PREC_FP32 && D % kB16BN == 0;
         if (fused_split) {   // bf16 attention operands straight from the GEMM epilogue (no fp32 QKV round trip)
@@ -581,7 +583,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         if (rc) return rc;
         snprintf(nm, sizeof nm, "%s.out_ln", tag);
         a = gemm_args(ly.out, b.ctx, D, R, dl.row_pos, b.x1, D);
-        a.Rp = dl.dims;
+        a.Rp = dl.dims; a.regime_rows = regime_rows;
         a.resid = b.x0; a.ldr = D; a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
         if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; }
         // split-K partials go to the fp32 QKV buffer, idle from here on.  Only where the row count is the same in the host- and the
@@ -596,7 +598,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.ffn2_ln", tag);
         a = gemm_args(ly.w2, b.hid, ly.w1.N, R, dl.row_pos, b.x0, D);
-        a.Rp = dl.dims;
+        a.Rp = dl.dims; a.regime_rows = regime_rows;
         a.resid = b.x1; a.ldr = D; a.ln_g = ly.ln2g; a.ln_b = ly.ln2b; a.ln_eps = 1e-5f;
         if (pl) { a.Xp = hidp; a.Yp = b.x0p; a.yp_chunks = D / 32; }
         if (pl && allow_splitk) { a.kpart = b.qkv; a.ksplit = 3; }
@@ -1052,6 +1054,8 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
         if ((rc = unpack<float>(h, s, sb.x0, c.adim, dl.start, dl.vlen, b.B, b.Tmax, io->enc_out, 0.f))) return rc;
     }
     h->enc_final = sb.x0; h->cum = cum; h->o32 = o32; h->enc_B = b.B; h->enc_Tmax = b.Tmax; h->enc_compat = b.compat_padded;
+    h->enc_ntok = 0;
+    for (int i = 0; i < b.B; ++i) h->enc_ntok += (long)b.ilens[i];
     h->enc_ws = io->workspace;
     h->encoded = true;
     return FS2_OK;
@@ -1122,6 +1126,11 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         HIP_TRY(h, hipMemcpyAsync(io->status, dl.dims, 8 * sizeof(int), hipMemcpyDeviceToDevice, s));
     } else if ((rc = upload_layout(h, s, L, f.meta, dl))) return rc;
     const int R = L.R;
+    // Kernel variants with different summation orders (LayerNorm fused into the row-complete GEMM or not) are chosen from a row
+    // count.  The exact one is unknown to the host in the device-driven mode, and the capacity differs from it, so both modes use
+    // the same ESTIMATE instead: 8 frames per phoneme (LJSpeech: 7.9) plus the per-utterance alignment rows.  Any value gives
+    // correct results; using the same one in both modes makes them bit-identical.
+    const int regime_rows = (int)std::min<long>(8 * h->enc_ntok + (long)b.B * (kGap + kAttAlign) + kGap, INT32_MAX - 256);
     // bf16 modes: the length-regulator output (and later its sum with the pitch / energy embeddings) is also written as planes,
     // in x1p (free until the decoder stack's first LayerNorm): the A operand of both variance predictors and of the decoder input layer
     void* hfr_planes = (b.precision != FS2_PREC_FP32 && c.adim % 32 == 0) ? f.sb.x1p : nullptr;
@@ -1143,7 +1152,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     const bool dec_pl = b.precision != FS2_PREC_FP32;
     if (c.decoder_input_layer) {   // decoder input layer: Linear -> LN -> ReLU -> + alpha * pe   (reference encoder.py:118-125)
         GemmArgs a = gemm_args(h->dec_in, f.hfr, c.adim, R, dl.row_pos, f.sb.x0, c.ddim);
-        a.Rp = dl.dims;
+        a.Rp = dl.dims; a.regime_rows = regime_rows;
         a.ln_g = h->dec_in_lng; a.ln_b = h->dec_in_lnb; a.ln_eps = 1e-5f; a.act_post = 1;
         a.pe = h->dec.pe; a.pe_ld = c.ddim; a.pe_alpha = h->dec.alpha; a.x_scale = c.use_scaled_pos_enc ? 1.f : sqrtf((float)c.ddim);
         a.Xp = hfr_planes; a.xp_scratch = f.sb.xps;
@@ -1161,7 +1170,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         HIP_TRY(h, hipGetLastError());
     }
     const int mask_q = (b.compat_padded && io->masked) ? 1 : 0;
-    if ((rc = run_stack(h, s, "dec", h->dec, c.ddim, c.aheads, R, L, dl, mask_q, f.sb, b.precision, /*x0p_ready=*/dec_pl))) return rc;
+    if ((rc = run_stack(h, s, "dec", h->dec, c.ddim, c.aheads, R, L, dl, mask_q, f.sb, b.precision, /*x0p_ready=*/dec_pl, /*allow_splitk=*/false, regime_rows))) return rc;
     // planes hand-off through the tail: decoder -> feat_out (fp32 mel + planes of it) -> Postnet convs ping-pong x0p / x1p
     const bool post_pl = dec_pl && c.postnet_layers > 1;
     {

@@ -1,6 +1,6 @@
 """Per-kernel parity tests through the C ABI (fs2_op_*), each against a plain fp32 PyTorch statement of
-the same reference op computed on the CPU.  Tolerances: fp32 kernels 2e-4 absolute on O(1) data (the
-MFMA fp32 chain and the CPU sum differ only in summation order); integer outputs bit-exact."""
+the same reference op computed on the CPU.  Tolerances: 5 x the worst error measured on MI355X per arithmetic mode (GEMM_TOL / ATT_TOL below); integer
+outputs bit-exact."""
 import numpy as np
 import pytest
 import torch
@@ -44,7 +44,9 @@ CASES = [
 
 # fp32: exact-fp32 MFMA chain vs CPU sum order.  bf16x3: operands carry ~16 mantissa bits.  bf16: 8 bits
 # (reported, not a parity mode).
-GEMM_TOL = {"fp32": 2e-4, "bf16x3": 6e-4, "bf16": 8e-2}
+# Tolerances = 5 x the worst error measured on MI355X over all cases (gpurun_out/measured_errors.jsonl, round 2: fp32 5.3e-6,
+# bf16x3 2.8e-5, bf16 1.4e-2), so that a regression of the arithmetic cannot hide below the 1e-3 end-to-end bar.
+GEMM_TOL = {"fp32": 2.5e-5, "bf16x3": 1.5e-4, "bf16": 7e-2}
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
@@ -129,7 +131,8 @@ def test_conv_gemm_transpose_detecting():
     assert torch.allclose(y.cpu(), w.t(), atol=1e-6)
 
 
-ATT_TOL = {"fp32": 2e-5, "bf16x3": 2e-4, "bf16": 5e-2}
+# 5 x measured (round 2: fp32 9.7e-7, bf16x3 1.4e-5, bf16 6.7e-3)
+ATT_TOL = {"fp32": 5e-6, "bf16x3": 7e-5, "bf16": 3.5e-2}
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
@@ -275,9 +278,10 @@ def test_duration_postop_known_answers_and_ties(golden_dir):
     exact_tie = (torch.exp(yt.double()).float() - 1.0).double() == (k + 0.5)      # fp32 exp lands on the tie exactly
     print("ties: %d / 41 resolved to the even neighbour (%d are exact ties in fp32)" % (int((got == even).sum()), int(exact_tie.sum())))
     # special values
-    sp = torch.tensor([float("-inf"), -100.0, 0.0, 88.0, 100.0, float("inf"), float("nan")])
+    sp = torch.tensor([float("-inf"), -100.0, 0.0, 40.0, 100.0, float("inf"), float("nan")])
     got = ops.duration(sp.to(dev)).cpu().tolist()
-    assert got[:3] == [0, 0, 0] and got[3] == int(torch.round(torch.tensor(88.0).exp() - 1.0).item()) and got[6] == 0
+    assert got[:3] == [0, 0, 0] and got[6] == 0
+    assert abs(got[3] - float(torch.tensor(40.0).double().exp())) < 2.0 ** 35      # e^40 = 2.35e17: fp32 spacing there is 2^34
     assert got[4] == got[5] == 2 ** 63 - 1                # saturates like .long() of +inf does not: documented (fs2.h)
 
 
