@@ -31,8 +31,9 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "mixed": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
-DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3", "bf16": "bf16", "mixed": "bf16x3+f16x2"}
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "mix_f16x2": 2500.0, "mix_f16x1": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
+DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3", "bf16": "bf16", "mix_f16x2": "bf16x3 (FFN conv: f16x2)", "mix_f16x1": "bf16x3 (FFN conv: f16)"}
+MFMA_PER_PRODUCT = {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1}       # MFMAs issued per algorithmic product in the dominant kernel (the FFN conv)
 HBM_PEAK_GBPS = 8000.0
 WORKLOAD_TEXT = {
     "c1": "c1: 1 utterance, 80 phonemes",
@@ -264,9 +265,10 @@ def main():
             roofline["traffic_note"] = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r02_traffic.json (separate --pmc passes of this command); algorithmic HBM bytes %d" % tr["algorithmic_bytes"]
     except (OSError, KeyError, ValueError):
         pass
-    if args.precision == "bf16x3":   # three MFMAs are issued per algorithmic product
-        roofline["issued_tflops"] = round(3 * achieved, 1)
-        roofline["issued_frac"] = round(3 * achieved / peak, 4)
+    if args.precision in MFMA_PER_PRODUCT and dom_name.endswith("ffn1"):   # split operands: several MFMAs are issued per algorithmic product
+        m = MFMA_PER_PRODUCT[args.precision]
+        roofline["issued_tflops"] = round(m * achieved, 1)
+        roofline["issued_frac"] = round(m * achieved / peak, 4)
     # HBM-bound kernels of the path against the 8 TB/s roofline: algorithmic bytes of the valid rows / time
     ad, dd, od = c["adim"], c["ddim"], c["odim"]
     pl = 2 if args.precision != "fp32" else 1          # fp32 tensor + split-bf16 planes of the same size

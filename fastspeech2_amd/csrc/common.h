@@ -54,6 +54,10 @@ struct GemmArgs {
     // build them from X when the producer did not; Yp: output planes (yp_chunks 32-channel chunks per row), written
     // by the epilogue next to / instead of Y.
     const void* Xp; void* xp_scratch; void* Yp; int yp_chunks;
+    // fp16 variant of the planes / weight image (same layout, [hi 32 | lo 32] _Float16): the two- and one-term arithmetic of the FFN
+    // convolution.  yp_f16: write Yp as fp16 planes; f16_terms: 0 = bf16 arithmetic, else Xp / W are fp16 images and
+    // the kernel issues f16_terms MFMAs per fragment pair (3: lo*hi + hi*lo + hi*hi, 2: lo*hi + hi*hi = weights rounded once, 1: hi*hi)
+    int yp_f16; int f16_terms;
     // deterministic split-K of the k = 1 form (small grids with a long K: the loop is a serial chain of k-steps): workgroup z of
     // grid.z accumulates chunks [z, z+1) * Cpad/32/ksplit; split 0 (which also adds bias + residual) writes Y, split z > 0 writes
     // kpart + (z-1) * kpart_stride; the row kernel that follows (ln_rows) adds the partials in a fixed order
@@ -105,9 +109,22 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2& hi, uint2& lo) {
     hi = *reinterpret_cast<uint2*>(&h);
     lo = *reinterpret_cast<uint2*>(&l);
 }
-__device__ __forceinline__ void store_planes4(void* planes, size_t row, int nchunks, int c, const f32x4 v) {
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4_f16(const f32x4 v, uint2& hi, uint2& lo) {
+    f16x4_t h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x = fminf(fmaxf(v[j], -65504.f), 65504.f);      // fp16 range (activations of this network are O(1); no inf / NaN lo parts)
+        const _Float16 hb = (_Float16)x;
+        h[j] = hb;
+        l[j] = (_Float16)(x - (float)hb);
+    }
+    hi = *reinterpret_cast<uint2*>(&h);
+    lo = *reinterpret_cast<uint2*>(&l);
+}
+__device__ __forceinline__ void store_planes4(void* planes, size_t row, int nchunks, int c, const f32x4 v, bool f16 = false) {
     uint2 hi, lo;
-    split4(v, hi, lo);
+    if (f16) split4_f16(v, hi, lo); else split4(v, hi, lo);
     char* p = reinterpret_cast<char*>(planes) + plane_byte(row, nchunks, c);
     *reinterpret_cast<uint2*>(p) = hi;
     *reinterpret_cast<uint2*>(p + 64) = lo;

@@ -32,6 +32,7 @@ std::string g_create_error;
 struct Gemm {          // one repacked Linear / Conv1d
     float* w = nullptr;      // [Npad][ktaps][Cpad]
     void* wb = nullptr;      // split-bf16 image [Npad][ktaps][Cpad/32][hi 32 | lo 32]
+    void* wf = nullptr;      // the same image in fp16 (FFN w_1 only): operand of the two- / one-term arithmetic modes
     float* bias = nullptr;   // [N] or null
     int N = 0, C = 0, Cpad = 0, ktaps = 1;
 };
@@ -74,6 +75,10 @@ Options& opts() {
     }();
     return o;
 }
+
+// Mixed modes: everything as bf16x3 except the FFN convolution w_1, which runs on fp16 operands with 2 or 1 MFMA per fragment pair.
+inline int base_precision(int p) { return (p == FS2_PREC_MIX_F16X2 || p == FS2_PREC_MIX_F16X1) ? FS2_PREC_BF16X3 : p; }
+inline int ffn_f16_terms(int p) { return p == FS2_PREC_MIX_F16X2 ? 2 : (p == FS2_PREC_MIX_F16X1 ? 1 : 0); }
 
 // Every entry point that takes a handle runs on the handle's device and leaves the caller's current device as it found it.
 struct DeviceGuard {
@@ -210,13 +215,13 @@ hipError_t launch_tile(hipStream_t s, const GemmArgs& a) {
 
 bool rows_supported(int N) { return N == 80 || N == 256 || N == 384; }
 
-template <int NSPLIT, int BM, bool K1>
+template <int NSPLIT, int BM, bool K1, bool F16 = false>
 hipError_t launch_pl_t(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
     constexpr size_t lds = pl_lds_bytes<BM, K1>();
-    allow_lds(reinterpret_cast<const void*>(&gemm_pl_bf16<NSPLIT, BM, K1>), lds, attr);
+    allow_lds(reinterpret_cast<const void*>(&gemm_pl_bf16<NSPLIT, BM, K1, F16>), lds, attr);
     dim3 grid((a.N + kB16BN - 1) / kB16BN, ((a.qk_hi ? a.Rvt : a.R) + BM - 1) / BM, (K1 && a.ksplit > 1) ? a.ksplit : 1);
-    hipLaunchKernelGGL((gemm_pl_bf16<NSPLIT, BM, K1>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_pl_bf16<NSPLIT, BM, K1, F16>), grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -270,6 +275,16 @@ hipError_t launch_pl(hipStream_t s, const GemmArgs& a) {
     return bm == 128 ? launch_pl_t<NSPLIT, 128, false>(s, a) : launch_pl_t<NSPLIT, 64, false>(s, a);
 }
 
+// fp16-operand form of the conv kernel (FFN w_1 in the mixed modes): NSPLIT MFMAs per fragment pair
+template <int NSPLIT>
+hipError_t launch_pl_f16(hipStream_t s, const GemmArgs& a) {
+    const int force = opts().bm > 0 ? opts().bm : 0;
+    const long nN = (a.N + kB16BN - 1) / kB16BN;
+    const int bm = force ? force : (nN * ((a.R + 255) / 256) >= 512 ? 256 : (nN * ((a.R + 127) / 128) >= 400 ? 128 : 64));
+    if (bm == 256) return launch_pl_t<NSPLIT, 256, false, true>(s, a);
+    return bm == 128 ? launch_pl_t<NSPLIT, 128, false, true>(s, a) : launch_pl_t<NSPLIT, 64, false, true>(s, a);
+}
+
 // Picks the kernel.  fp32: row-complete tiles when the epilogue needs whole rows and N is small, 128x128 tiles (+ ln_rows) otherwise.
 // bf16 / bf16x3 (activation planes in, gemm_planes.h): the row-complete LayerNorm-fused kernel for big k = 1 GEMMs that end in
 // a row epilogue, else the BM x 128 tile kernel followed by ln_rows when a row epilogue is needed.
@@ -306,17 +321,20 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
             t.ksplit = ksp;
             t.kpart_stride = (size_t)a.R * t.ldy;
         }
+        if (a.f16_terms && (a.ktaps == 1 || need_rows || a.qk_hi)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: the fp16 arithmetic exists for plain convolutions only", name);
         if (!a.Xp) {
             char nm[112];
             snprintf(nm, sizeof nm, "%s.planes", name);
             Scope sc(h, s, nm, 0.0, 8.0 * a.R * a.Cpad);
             const int64_t n = (int64_t)a.R * (a.Cpad / 4);
-            hipLaunchKernelGGL(to_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.X, a.ldx, a.C, a.R, a.Cpad / 32, a.xp_scratch);
+            hipLaunchKernelGGL(to_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.X, a.ldx, a.C, a.R, a.Cpad / 32, a.xp_scratch, a.f16_terms ? 1 : 0);
             t.Xp = a.xp_scratch;
         }
         {
             Scope sc(h, s, name, flops, bytes);
-            if (use_qkv8(t)) {
+            if (a.f16_terms) {
+                e = a.f16_terms == 3 ? launch_pl_f16<3>(s, t) : (a.f16_terms == 2 ? launch_pl_f16<2>(s, t) : launch_pl_f16<1>(s, t));
+            } else if (use_qkv8(t)) {
                 if (a.att_D == 384) e = (precision == FS2_PREC_BF16X3) ? launch_qkv8_t<3, 3>(s, t) : launch_qkv8_t<1, 3>(s, t);
                 else e = (precision == FS2_PREC_BF16X3) ? launch_qkv8_t<3, 2>(s, t) : launch_qkv8_t<1, 2>(s, t);
             } else if (row8) {
@@ -550,7 +568,7 @@ struct StackBufs { float *x0, *x1, *qkv, *ctx, *hid; __bf16 *qkh, *qkl, *vth, *v
 // x0 holds the input; returns the buffer holding the output (x0 again).
 int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, int D, int heads, int R,
               const HostLayout& L, const DevLayout& dl, int mask_q, const StackBufs& b, int prec, bool x0p_ready = false, bool allow_splitk = false,
-              int regime_rows = 0) {
+              int regime_rows = 0, int ffn_terms = 0) {
     char nm[96];
     double att_flops = 0;
     for (size_t i = 0; i < L.klen.size(); ++i) att_flops += 4.0 * D * (double)L.klen[i] * std::min(L.len[i], mask_q ? L.klen[i] : L.len[i]);
@@ -585,7 +603,8 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         a = gemm_args(ly.out, b.ctx, D, R, dl.row_pos, b.x1, D);
         a.Rp = dl.dims; a.regime_rows = regime_rows;
         a.resid = b.x0; a.ldr = D; a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
-        if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; }
+        const int f16t = (pl && ffn_terms && ly.w1.ktaps > 1 && ly.w1.wf) ? ffn_terms : 0;      // this layer's FFN conv on fp16 operands?
+        if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; a.yp_f16 = f16t ? 1 : 0; }       // x1p feeds only that conv
         // split-K partials go to the fp32 QKV buffer, idle from here on.  Only where the row count is the same in the host- and the
         // device-driven layout (the token-level stack): the choice of the split depends on it, and the two layouts must agree bit for bit
         if (pl && allow_splitk) { a.kpart = b.qkv; a.ksplit = 3; }
@@ -595,6 +614,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         a.Rp = dl.dims;
         a.act_post = 1;
         if (pl) { a.Xp = b.x1p; a.Yp = hidp; a.yp_chunks = round_up(ly.w1.N, 32) / 32; }
+        if (f16t) { a.f16_terms = f16t; a.Wb = ly.w1.wf; }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.ffn2_ln", tag);
         a = gemm_args(ly.w2, b.hid, ly.w1.N, R, dl.row_pos, b.x0, D);
@@ -667,7 +687,7 @@ struct Loader {
     }
     // parts: weights stacked along N (q|k|v); each [n_i, C, k] (k omitted for Linear)
     Gemm gemm(std::vector<std::string> wnames, std::vector<std::string> bnames, int Neach, int C, int k, bool linear,
-              const std::string& bn_prefix = "") {
+              const std::string& bn_prefix = "", bool f16_image = false) {
         Gemm g;
         const int parts = (int)wnames.size();
         g.N = Neach * parts; g.C = C; g.ktaps = k; g.Cpad = round_up(C, kBK);
@@ -691,13 +711,23 @@ struct Loader {
             g.wb = pb;
             hipMemsetAsync(pb, 0, wb_elems * 2, s);
         }
+        if (f16_image) {
+            void* pf = nullptr;
+            if (hipMalloc(&pf, wb_elems * 2) != hipSuccess) { if (!rc) rc = fail(h, FS2_ERR_HIP, "hipMalloc of fp16 weights failed"); return g; }
+            h->allocs.push_back(pf);
+            g.wf = pf;
+            hipMemsetAsync(pf, 0, wb_elems * 2, s);
+        }
         for (int p = 0; p < parts; ++p) {
             const fs2_tensor_desc* d = linear ? get(wnames[p], {Neach, C}) : get(wnames[p], {Neach, C, k});
             if (!d) return g;
             {
                 const int64_t tb = (int64_t)Neach * k * nchunks * 32;
                 hipLaunchKernelGGL(repack_weight_bf16, dim3((unsigned)((tb + 255) / 256)), dim3(256), 0, s, (const float*)d->data, Neach, C, k,
-                                   Neach, nchunks, bg, bv, 1e-5f, reinterpret_cast<__bf16*>(g.wb) + (size_t)p * Neach * k * nchunks * 64);
+                                   Neach, nchunks, bg, bv, 1e-5f, reinterpret_cast<__bf16*>(g.wb) + (size_t)p * Neach * k * nchunks * 64, 0);
+                if (g.wf)
+                    hipLaunchKernelGGL(repack_weight_bf16, dim3((unsigned)((tb + 255) / 256)), dim3(256), 0, s, (const float*)d->data, Neach, C, k,
+                                       Neach, nchunks, bg, bv, 1e-5f, reinterpret_cast<__bf16*>(g.wf) + (size_t)p * Neach * k * nchunks * 64, 1);
             }
             const int64_t total = (int64_t)Neach * k * g.Cpad;
             hipLaunchKernelGGL(repack_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)d->data, Neach, C, k,
@@ -729,7 +759,8 @@ void load_stack(Loader& L, Stack& st, const std::string& pre, int nlayers, int D
         ly.qkv = L.gemm({p + ".self_attn.linear_q.weight", p + ".self_attn.linear_k.weight", p + ".self_attn.linear_v.weight"},
                         {p + ".self_attn.linear_q.bias", p + ".self_attn.linear_k.bias", p + ".self_attn.linear_v.bias"}, D, D, 1, true);
         ly.out = L.gemm({p + ".self_attn.linear_out.weight"}, {p + ".self_attn.linear_out.bias"}, D, D, 1, true);
-        ly.w1 = L.gemm({p + ".feed_forward.w_1.weight"}, {p + ".feed_forward.w_1.bias"}, units, D, k, L.h->cfg.ffn_kernel == 1 && L.m.count(p + ".feed_forward.w_1.weight") && L.m[p + ".feed_forward.w_1.weight"]->ndim == 2);
+        ly.w1 = L.gemm({p + ".feed_forward.w_1.weight"}, {p + ".feed_forward.w_1.bias"}, units, D, k, L.h->cfg.ffn_kernel == 1 && L.m.count(p + ".feed_forward.w_1.weight") && L.m[p + ".feed_forward.w_1.weight"]->ndim == 2,
+                        "", /*f16_image=*/k > 1);
         {
             const bool lin2 = L.m.count(p + ".feed_forward.w_2.weight") && L.m[p + ".feed_forward.w_2.weight"]->ndim == 2;
             ly.w2 = L.gemm({p + ".feed_forward.w_2.weight"}, {p + ".feed_forward.w_2.bias"}, D, units, 1, lin2);
@@ -769,7 +800,7 @@ int check_batch(fs2_handle* h, const fs2_batch& b) {
     if (b.B <= 0 || b.Tmax <= 0 || !b.ilens) return fail(h, FS2_ERR_ARG, "batch: B=%d Tmax=%d ilens=%p", b.B, b.Tmax, (const void*)b.ilens);
     for (int i = 0; i < b.B; ++i)
         if (b.ilens[i] <= 0 || b.ilens[i] > b.Tmax) return fail(h, FS2_ERR_ARG, "ilens[%d]=%lld outside [1,%d]", i, (long long)b.ilens[i], b.Tmax);
-    if (b.precision < FS2_PREC_FP32 || b.precision > FS2_PREC_BF16) return fail(h, FS2_ERR_ARG, "unknown precision mode %d", b.precision);
+    if (b.precision < FS2_PREC_FP32 || b.precision > FS2_PREC_MIX_F16X1) return fail(h, FS2_ERR_ARG, "unknown precision mode %d", b.precision);
     return FS2_OK;
 }
 
@@ -1020,6 +1051,7 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
     hipStream_t s = (hipStream_t)stream;
     const fs2_config& c = h->cfg;
     const fs2_batch& b = io->batch;
+    const int prec = base_precision(b.precision), ffn_terms = ffn_f16_terms(b.precision);
     h->encoded = false;
     token_layout(b, h->tok);
     const HostLayout& L = h->tok;
@@ -1030,7 +1062,7 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
     if (!ok) return fail(h, FS2_ERR_WORKSPACE, "fs2_encode: workspace too small");
     if ((rc = upload_layout(h, s, L, meta, h->dtok))) return rc;
     const DevLayout& dl = h->dtok;
-    const bool enc_pl = b.precision != FS2_PREC_FP32;   // activations also travel as planes (x0p holds those of x0 before and after the stack)
+    const bool enc_pl = prec != FS2_PREC_FP32;   // activations also travel as planes (x0p holds those of x0 before and after the stack)
     {
         Scope sc(h, s, "enc.embed", 0, 4.0 * L.R * c.adim * 2);
         hipLaunchKernelGGL(embed_pe, dim3((L.R + 3) / 4), dim3(256), 0, s, io->xs, b.Tmax, h->enc_embed, c.idim, c.adim, h->enc.pe,
@@ -1038,8 +1070,8 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
                            enc_pl && c.adim % 32 == 0 ? sb.x0p : nullptr);
         HIP_TRY(h, hipGetLastError());
     }
-    if ((rc = run_stack(h, s, "enc", h->enc, c.adim, c.aheads, L.R, L, dl, /*mask_q=*/1, sb, b.precision, /*x0p_ready=*/enc_pl && c.adim % 32 == 0, /*allow_splitk=*/true))) return rc;
-    if ((rc = run_predictor(h, s, "dur", h->dur, sb.x0, c.adim, L.R, dl.row_pos, p0, p1, dlog_rows, b.precision, enc_pl ? sb.x0p : nullptr, sb.xps))) return rc;
+    if ((rc = run_stack(h, s, "enc", h->enc, c.adim, c.aheads, L.R, L, dl, /*mask_q=*/1, sb, prec, /*x0p_ready=*/enc_pl && c.adim % 32 == 0, /*allow_splitk=*/true, /*regime_rows=*/0, ffn_terms))) return rc;
+    if ((rc = run_predictor(h, s, "dur", h->dur, sb.x0, c.adim, L.R, dl.row_pos, p0, p1, dlog_rows, prec, enc_pl ? sb.x0p : nullptr, sb.xps))) return rc;
     {
         Scope sc(h, s, "dur.post", 0, 0);
         const int n = b.B * b.Tmax;
@@ -1114,6 +1146,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     DeviceGuard g(c.device);
     HIP_TRY(h, g.err);
     hipStream_t s = (hipStream_t)stream;
+    const int prec = base_precision(b.precision), ffn_terms = ffn_f16_terms(b.precision);
     HostLayout L;
     if (devlay) capacity_layout(b, io->row_capacity, io->Lmax, L);
     else frame_layout(b, io->olens, io->masked, L);
@@ -1133,7 +1166,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     const int regime_rows = (int)std::min<long>(8 * h->enc_ntok + (long)b.B * (kGap + kAttAlign) + kGap, INT32_MAX - 256);
     // bf16 modes: the length-regulator output (and later its sum with the pitch / energy embeddings) is also written as planes,
     // in x1p (free until the decoder stack's first LayerNorm): the A operand of both variance predictors and of the decoder input layer
-    void* hfr_planes = (b.precision != FS2_PREC_FP32 && c.adim % 32 == 0) ? f.sb.x1p : nullptr;
+    void* hfr_planes = (prec != FS2_PREC_FP32 && c.adim % 32 == 0) ? f.sb.x1p : nullptr;
     {   // length regulator
         Scope sc(h, s, "lr.expand", 0, 4.0 * R * c.adim * 2);
         hipLaunchKernelGGL(lr_expand, dim3((R + 3) / 4), dim3(256), 0, s, h->enc_final, c.adim, h->dtok.start, h->dtok.vlen, h->cum, b.Tmax,
@@ -1141,15 +1174,15 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         HIP_TRY(h, hipGetLastError());
     }
     const bool need_e = (io->es == nullptr) || io->e_out, need_p = (io->ps == nullptr) || io->p_out;
-    if (need_e && (rc = run_predictor(h, s, "energy", h->energy, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.e_rows, b.precision, hfr_planes, f.sb.xps, dl.dims))) return rc;
-    if (need_p && (rc = run_predictor(h, s, "pitch", h->pitch, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.p_rows, b.precision, hfr_planes, f.sb.xps, dl.dims))) return rc;
+    if (need_e && (rc = run_predictor(h, s, "energy", h->energy, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.e_rows, prec, hfr_planes, f.sb.xps, dl.dims))) return rc;
+    if (need_p && (rc = run_predictor(h, s, "pitch", h->pitch, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.p_rows, prec, hfr_planes, f.sb.xps, dl.dims))) return rc;
     {
         Scope sc(h, s, "var.embed", 0, 4.0 * R * c.adim * 4);
         hipLaunchKernelGGL(bucket_embed, dim3((R + 3) / 4), dim3(256), 0, s, f.hfr, c.adim, dl.row_pos, dl.row_seq, R, io->es, io->es_stride,
                            io->ps, io->ps_stride, f.e_rows, f.p_rows, h->ebins, h->pbins, c.n_bins - 1, h->Te, h->Tp, f.qe, f.qp, hfr_planes);
         HIP_TRY(h, hipGetLastError());
     }
-    const bool dec_pl = b.precision != FS2_PREC_FP32;
+    const bool dec_pl = prec != FS2_PREC_FP32;
     if (c.decoder_input_layer) {   // decoder input layer: Linear -> LN -> ReLU -> + alpha * pe   (reference encoder.py:118-125)
         GemmArgs a = gemm_args(h->dec_in, f.hfr, c.adim, R, dl.row_pos, f.sb.x0, c.ddim);
         a.Rp = dl.dims; a.regime_rows = regime_rows;
@@ -1157,7 +1190,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         a.pe = h->dec.pe; a.pe_ld = c.ddim; a.pe_alpha = h->dec.alpha; a.x_scale = c.use_scaled_pos_enc ? 1.f : sqrtf((float)c.ddim);
         a.Xp = hfr_planes; a.xp_scratch = f.sb.xps;
         if (dec_pl) { a.Yp = f.sb.x0p; a.yp_chunks = c.ddim / 32; }
-        if ((rc = launch_gemm(h, s, "dec.in", a, b.precision))) return rc;
+        if ((rc = launch_gemm(h, s, "dec.in", a, prec))) return rc;
     } else {                       // TorchScript twin: the decoder input is just x (* sqrt(d)) + alpha * pe   (encoder.py:138-141)
         Scope sc(h, s, "dec.in.pe", 0.0, 8.0 * R * c.ddim);
         HIP_TRY(h, hipMemcpyAsync(f.sb.x0, f.hfr, (size_t)R * c.ddim * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1170,7 +1203,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         HIP_TRY(h, hipGetLastError());
     }
     const int mask_q = (b.compat_padded && io->masked) ? 1 : 0;
-    if ((rc = run_stack(h, s, "dec", h->dec, c.ddim, c.aheads, R, L, dl, mask_q, f.sb, b.precision, /*x0p_ready=*/dec_pl, /*allow_splitk=*/false, regime_rows))) return rc;
+    if ((rc = run_stack(h, s, "dec", h->dec, c.ddim, c.aheads, R, L, dl, mask_q, f.sb, prec, /*x0p_ready=*/dec_pl, /*allow_splitk=*/false, regime_rows, ffn_terms))) return rc;
     // planes hand-off through the tail: decoder -> feat_out (fp32 mel + planes of it) -> Postnet convs ping-pong x0p / x1p
     const bool post_pl = dec_pl && c.postnet_layers > 1;
     {
@@ -1178,7 +1211,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         a.Rp = dl.dims;
         if (dec_pl) a.Xp = f.sb.x0p;
         if (post_pl) { a.Yp = f.sb.xps; a.yp_chunks = round_up(c.odim, 32) / 32; }
-        if ((rc = launch_gemm(h, s, "feat_out", a, b.precision))) return rc;
+        if ((rc = launch_gemm(h, s, "feat_out", a, prec))) return rc;
     }
     const float* mel_after = f.before;
     if (c.postnet_layers > 0) {
@@ -1198,7 +1231,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
                 a.xp_scratch = f.sb.xps;
             }
             char nm[32]; snprintf(nm, sizeof nm, "postnet.%d", l);
-            if ((rc = launch_gemm(h, s, nm, a, b.precision))) return rc;
+            if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
             in = out; ld = h->post[l].N;
         }
         mel_after = f.after;
@@ -1263,7 +1296,8 @@ struct DevTmp {
 
 int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
     if (!o || !o->x || !o->w || o->R <= 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_conv_gemm: bad arguments");
-    if (o->precision < FS2_PREC_FP32 || o->precision > FS2_PREC_BF16) return fail(nullptr, FS2_ERR_ARG, "unknown precision %d", o->precision);
+    if (o->precision < FS2_PREC_FP32 || o->precision > FS2_PREC_MIX_F16X1) return fail(nullptr, FS2_ERR_ARG, "unknown precision %d", o->precision);
+    const int f16t = ffn_f16_terms(o->precision);      // mixed modes: THIS operator on fp16 operands with 2 / 1 MFMAs per fragment pair
     hipStream_t s = (hipStream_t)stream;
     Gemm g; g.N = o->N; g.C = o->C; g.ktaps = o->ktaps; g.Cpad = round_up(o->C, kBK);
     const int Npad = round_up(o->N, 128);
@@ -1284,7 +1318,7 @@ int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
                        (const float*)nullptr, (const float*)nullptr, 0.f, g.w);
     const int64_t tb = (int64_t)o->N * o->ktaps * nchunks * 32;
     hipLaunchKernelGGL(repack_weight_bf16, dim3((unsigned)((tb + 255) / 256)), dim3(256), 0, s, o->w, o->N, o->C, o->ktaps, o->N, nchunks,
-                       (const float*)nullptr, (const float*)nullptr, 0.f, reinterpret_cast<__bf16*>(g.wb));
+                       (const float*)nullptr, (const float*)nullptr, 0.f, reinterpret_cast<__bf16*>(g.wb), f16t ? 1 : 0);
     g.bias = const_cast<float*>(o->bias);
     GemmArgs a = gemm_args(g, o->x, o->C, o->R, nullptr, o->y, o->N);
     a.scratch = scratch;
@@ -1300,7 +1334,8 @@ int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
     a.resid = o->resid; a.ldr = o->N; a.relu_pre = o->relu_pre; a.ln_g = o->ln_gamma; a.ln_b = o->ln_beta; a.ln_eps = o->ln_eps;
     a.act_post = o->act_post; a.dot_w = o->dot_w; a.dot_b = o->dot_b; a.dot_out = o->dot_out;
     a.xp_scratch = xps;
-    return launch_gemm(nullptr, s, "op.conv_gemm", a, o->precision);      // (tmp drains the stream and frees)
+    a.f16_terms = f16t;
+    return launch_gemm(nullptr, s, "op.conv_gemm", a, base_precision(o->precision));      // (tmp drains the stream and frees)
 }
 
 int fs2_op_attention(void* stream, const float* qkv, float* ctx, int32_t D, int32_t heads, int32_t B, const int32_t* seq_start,

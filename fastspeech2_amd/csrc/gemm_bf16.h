@@ -17,6 +17,14 @@
 namespace fs2 {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+// one 16x16x32 MFMA on fragments held as raw 16-byte vectors: bf16 or (F16) fp16 operands, fp32 accumulate, same rate
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const bf16x8_t a, const bf16x8_t b, const f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 // Barrier that also covers this wave's outstanding LDS-DMA (global_load_lds counts on vmcnt).  hipcc normally emits the
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
     const int pc = a.Yp ? a.yp_chunks * 32 : 0;      // channels of the output planes (>= N, zero padded)
     if (pos < 0) {
         for (int c = lane * 4; c < a.N; c += 256) *reinterpret_cast<float4*>(y + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c = lane * 4; c < pc; c += 256) store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int c = lane * 4; c < pc; c += 256) store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{0.f, 0.f, 0.f, 0.f}, a.yp_f16 != 0);
         if (a.dot_w && lane == 0) a.dot_out[row] = 0.f;
         return;
     }
@@ -177,9 +185,9 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
                 d += (t.x * w.x + t.y * w.y) + (t.z * w.z + t.w * w.w);
             }
             *reinterpret_cast<float4*>(y + c) = t;
-            if (a.Yp) store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{t.x, t.y, t.z, t.w});
+            if (a.Yp) store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{t.x, t.y, t.z, t.w}, a.yp_f16 != 0);
         } else if (c < pc) {
-            store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{0.f, 0.f, 0.f, 0.f});
+            store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{0.f, 0.f, 0.f, 0.f}, a.yp_f16 != 0);
         }
     }
     if (a.dot_w) {
@@ -189,8 +197,9 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
 }
 
 // weights [N][C][k] fp32 -> split bf16 LDS image [Npad][nchunks][k][hi 32 | lo 32]; optional BatchNorm fold.
+// f16 != 0: the same image in _Float16 (fp16 hi + fp16 lo), the operand of the two- / one-term FFN arithmetic.
 __global__ void repack_weight_bf16(const float* w, int N, int C, int k, int Npad, int nchunks, const float* bn_g,
-                                   const float* bn_v, float bn_eps, __bf16* out) {
+                                   const float* bn_v, float bn_eps, __bf16* out, int f16 = 0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)Npad * k * nchunks * 32;
     if (i >= total) return;
@@ -204,9 +213,16 @@ __global__ void repack_weight_bf16(const float* w, int N, int C, int k, int Npad
         v = w[((size_t)n * C + c) * k + tap];
         if (bn_g) v *= bn_g[n] / sqrtf(bn_v[n] + bn_eps);
     }
+    const size_t base = (((size_t)n * nchunks + chunk) * k + tap) * 64;     // k-step order: it = chunk * k + tap
+    if (f16) {
+        _Float16* o16 = reinterpret_cast<_Float16*>(out);
+        const _Float16 hi = (_Float16)v;
+        o16[base + kk] = hi;
+        o16[base + 32 + kk] = (_Float16)(v - (float)hi);
+        return;
+    }
     const __bf16 hi = (__bf16)v;
     const __bf16 lo = (__bf16)(v - (float)hi);
-    const size_t base = (((size_t)n * nchunks + chunk) * k + tap) * 64;     // k-step order: it = chunk * k + tap
     out[base + kk] = hi;
     out[base + 32 + kk] = lo;
 }

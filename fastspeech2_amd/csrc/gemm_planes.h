@@ -31,14 +31,14 @@ constexpr size_t pl_lds_bytes() {
 template <int BM, bool K1> constexpr int pl_occ() { return pl_lds_bytes<BM, K1>() > 53 * 1024 ? 2 : 3; }
 
 // fp32 [R, ldx] -> planes (for activations whose producer is not plane-aware); channels >= C are zero
-__global__ void to_planes(const float* __restrict__ X, int ldx, int C, int R, int nchunks, void* __restrict__ Xp) {
+__global__ void to_planes(const float* __restrict__ X, int ldx, int C, int R, int nchunks, void* __restrict__ Xp, int f16 = 0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int per_row = nchunks * 8;
     if (i >= (int64_t)R * per_row) return;
     const int row = (int)(i / per_row), c = (int)(i - (int64_t)row * per_row) * 4;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < C) v = *reinterpret_cast<const f32x4*>(X + (size_t)row * ldx + c);
-    store_planes4(Xp, row, nchunks, c, v);
+    store_planes4(Xp, row, nchunks, c, v, f16 != 0);
 }
 
 // Elementwise epilogue on 4-channel pieces (bias and residual are already in the accumulators): ReLU, activation,
@@ -72,7 +72,7 @@ __device__ __forceinline__ void pl_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][
                 v[j] = (valid[r] && colok) ? t : 0.f;
             }
             if (Y && inb[r] && colok) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
-            if (pcol && inb[r]) store_planes4(Yp, row, a.yp_chunks, col, v);
+            if (pcol && inb[r]) store_planes4(Yp, row, a.yp_chunks, col, v, a.yp_f16 != 0);
         }
     }
 }
@@ -86,7 +86,8 @@ __device__ long long g_gemm_phase[8];
 #define FS2_GT(i)
 #endif
 
-template <int NSPLIT, int BM, bool K1>
+// F16: operands are fp16 images; NSPLIT = 3: lo*hi + hi*lo + hi*hi, 2: lo*hi + hi*hi (the weight's lo half is never read), 1: hi*hi.
+template <int NSPLIT, int BM, bool K1, bool F16 = false>
 __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs a) {
     constexpr int MT = BM / 32;               // 16-row MFMA tiles per wave (wave tile = BM/2 x 64)
     constexpr int AROWS = pl_arows<BM, K1>();
@@ -201,15 +202,17 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
             for (int mt = 0; mt < MT; ++mt) {
                 const int r = wm * (BM / 2) + mt * 16 + lp + tap;
                 const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
-                if (NSPLIT == 3) {
+                if (NSPLIT >= 2) {
                     const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nt], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(al, bh[nt], acc[mt][nt]);
+                }
+                if (NSPLIT == 3) {
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(ah, bl[nt], acc[mt][nt]);
                 }
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(ah, bh[nt], acc[mt][nt]);
             }
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
             FS2_GT(2)
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
                     }
                 }
                 if (Y) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
-                if (Yp) store_planes4(Yp, row, a.yp_chunks, col, v);
+                if (Yp) store_planes4(Yp, row, a.yp_chunks, col, v, a.yp_f16 != 0);
             }
     }
 }

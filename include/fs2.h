@@ -43,6 +43,11 @@ extern "C" {
 #define FS2_PREC_FP32 0   /* f32-input MFMA (v_mfma_f32_16x16x4_f32), exact fp32            */
 #define FS2_PREC_BF16X3 1 /* split-bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 */
 #define FS2_PREC_BF16 2   /* plain bf16 inputs, fp32 accumulate                             */
+/* mixed modes: as FS2_PREC_BF16X3, except that the FFN convolution w_1 (the dominant kernel) runs on fp16
+ * operands (v_mfma_f32_16x16x32_f16): activations split hi + lo, weights rounded to fp16 once (2 MFMAs per
+ * fragment pair), or both operands rounded once (1 MFMA).  Measured error / speed: BASELINE.md section 4. */
+#define FS2_PREC_MIX_F16X2 3
+#define FS2_PREC_MIX_F16X1 4
 
 typedef struct fs2_handle fs2_handle;
 

@@ -120,6 +120,34 @@ def test_conv_gemm_row_complete_ln_fused_kernel(case, precision, fs2_option):
     test_conv_gemm(case, precision)
 
 
+F16_CASES = [c for c in CASES if c[3] > 1 and c[7] is None and not c[5]]      # plain convolutions (bias / activation only)
+F16_TOL = {"mix_f16x2": 2e-3, "mix_f16x1": 3e-3}       # one / both operands rounded to fp16 once (11 bits): ~2^-12 relative per product
+
+
+@pytest.mark.parametrize("bm", ["64", "128", "256"])
+@pytest.mark.parametrize("precision", ["mix_f16x2", "mix_f16x1"])
+@pytest.mark.parametrize("case", F16_CASES, ids=[c[-1] for c in F16_CASES])
+def test_conv_gemm_fp16_two_and_one_term(case, precision, bm, fs2_option):
+    """The fp16-operand forms of the conv kernel (FFN w_1 in the mixed modes): activations hi + lo, weights rounded once (2 MFMAs
+    per fragment pair) / both rounded once (1 MFMA), at every tile height."""
+    fs2_option("FS2_BM", bm)
+    from tests import ops_binding as ops
+    from tests.conftest import record_measurement
+    R, C, N, k, has_bias, _, _, _, act, _, _ = case
+    rs = np.random.RandomState(R + C + N + k)
+    dev = _dev()
+    x = _rand(rs, R, C)
+    w = _rand(rs, N, C, k, scale=1.0 / np.sqrt(C * k))
+    bias = _rand(rs, N, scale=0.5)
+    y = _ref_conv(x, w, bias)
+    y = torch.relu(y) if act == 1 else (torch.tanh(y) if act == 2 else y)
+    yo, _ = ops.conv_gemm(x.to(dev), w.to(dev), bias.to(dev), None, False, None, 1e-5, act, None, None, precision=precision)
+    err = float((yo.cpu() - y).abs().max())
+    print("%s max-abs %.2e" % (precision, err))
+    record_measurement("gemm_%s" % precision, err)
+    assert torch.isfinite(yo).all() and err < F16_TOL[precision]
+
+
 def test_conv_gemm_transpose_detecting():
     """A = identity-like with an ASYMMETRIC weight: catches a swapped C/D row<->col mapping."""
     from tests import ops_binding as ops

@@ -118,6 +118,32 @@ def test_c2_batch_vs_oracle(env, precision):
         model.precision = "fp32"
 
 
+@pytest.mark.parametrize("precision", ["mix_f16x2", "mix_f16x1"])
+def test_c2_mixed_modes_vs_oracle(env, precision):
+    """The mixed arithmetic modes (bf16x3 everywhere except the FFN convolution w_1, which runs on fp16 operands with 2 / 1 MFMAs
+    per fragment pair): c2 against the oracle within the 1e-3 mel tolerance; integer decisions still exact.  Measured errors
+    and speed-ups: BASELINE.md section 4 (they are NOT the default: they use up a third to a half of the tolerance)."""
+    model, sd, cfg, O = env
+    from fastspeech2_amd.synthetic import make_batch
+    from tests.conftest import record_measurement
+    model.precision = precision
+    try:
+        b = make_batch("c2")
+        with torch.no_grad():
+            r = model._run(b["xs"].cuda(), b["ilens"], b["olens"], b["ds"].cuda(), b["es"].cuda(), b["ps"].cuda(),
+                           is_inference=False, want=("before", "after", "lr_index"))
+        o = O.per_utterance_forward(sd, cfg, b["xs"], b["ilens"], b["ds"], b["es"], b["ps"])
+        for i in range(b["xs"].shape[0]):
+            L = int(o["olens"][i])
+            assert torch.equal(r["lr_index"][i, :L].cpu().long(), o["lr_index"][i])
+        d = max(_maxabs(r["before"], o["before"]), _maxabs(r["after"], o["after"]))
+        print("c2 [%s] mel max-abs vs oracle %.2e" % (precision, d))
+        record_measurement("c2_mel_maxabs_" + precision, d)
+        assert d <= MEL_TOL
+    finally:
+        model.precision = "fp32"
+
+
 @pytest.mark.parametrize("row8", ["0", "1"])
 def test_c2_row_complete_kernel_choice(env, row8, fs2_option):
     """The LN-terminated k = 1 GEMMs have two bf16 implementations (128-column tiles + row kernel / row-complete tile with
