@@ -58,10 +58,12 @@ struct GemmArgs {
     // convolution.  yp_f16: write Yp as fp16 planes; f16_terms: 0 = bf16 arithmetic, else Xp / W are fp16 images and
     // the kernel issues f16_terms MFMAs per fragment pair (3: lo*hi + hi*lo + hi*hi, 2: lo*hi + hi*hi = weights rounded once, 1: hi*hi)
     int yp_f16; int f16_terms;
-    // deterministic split-K of the k = 1 form (small grids with a long K: the loop is a serial chain of k-steps): workgroup z of
-    // grid.z accumulates chunks [z, z+1) * Cpad/32/ksplit; split 0 (which also adds bias + residual) writes Y, split z > 0 writes
-    // kpart + (z-1) * kpart_stride; the row kernel that follows (ln_rows) adds the partials in a fixed order
+    // deterministic split-K (small grids with a long K: the loop is a serial chain of k-steps): workgroup z of grid.z accumulates the
+    // 32-channel chunks [z, z+1) * Cpad/32/ksplit (all taps of them); split 0 (which also adds bias + residual) writes Y, split z > 0
+    // writes kpart + (z-1) * kpart_stride; the row kernel that follows (ln_rows) adds the partials in a fixed order and applies the
+    // whole epilogue (ReLU, LayerNorm, activation, planes)
     int ksplit; float* kpart; size_t kpart_stride;
+    size_t kpart_cap;                      // floats available at kpart (launch_gemm picks a split that fits)
     int regime_rows;                       // row count the kernel-variant choice is based on (0: R).  Frame-level launches pass an estimate derived from
                                            // the PHONEME count, which the host knows in both layout modes, so that the host- and the device-driven
                                            // layout of one batch always pick the same variants (-> bit-identical results); see fs2_decode

@@ -51,6 +51,10 @@ struct Stack {
     float* alpha = nullptr;
 };
 
+// Split-K serves small batches (regime_rows <= kSplitRegime: beyond, the grids fill the chip anyway).  Its scratch holds up to 4 slabs of
+// kSplitRows x 1024 floats, enough for every launch with R <= kSplitRows, so that the decision is a function of regime_rows alone (the same
+// in the host- and the device-driven layout) as long as the row capacity stays below twice the estimate.
+constexpr int kSplitRegime = 8192, kSplitRows = 16384;
 constexpr int kXcds = 8;      // MI355X: 8 accelerator dies, workgroups of a launch are dealt to them round-robin
 
 // A/B switches of the kernel choice.  Read from the environment ONCE, when the library is first used, and
@@ -130,6 +134,8 @@ struct fs2_handle {
     int* o32 = nullptr;        // device frame counts (int32) left by the duration scan
     int enc_B = 0, enc_Tmax = 0, enc_compat = 0;
     long enc_ntok = 0;         // phonemes of the encoded batch (basis of the frame-level kernel-variant choice)
+    float* kp = nullptr; size_t kp_cap = 0;   // split-K scratch of the call in progress (carved from its workspace)
+    int cur_regime = 0;        // regime_rows of the call in progress (0: the launch's own row count)
     void* enc_ws = nullptr;
     std::vector<void*> graph_pinned;   // host staging owned by captured graphs (see upload_layout)
     // profiling
@@ -220,7 +226,7 @@ hipError_t launch_pl_t(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
     constexpr size_t lds = pl_lds_bytes<BM, K1>();
     allow_lds(reinterpret_cast<const void*>(&gemm_pl_bf16<NSPLIT, BM, K1, F16>), lds, attr);
-    dim3 grid((a.N + kB16BN - 1) / kB16BN, ((a.qk_hi ? a.Rvt : a.R) + BM - 1) / BM, (K1 && a.ksplit > 1) ? a.ksplit : 1);
+    dim3 grid((a.N + kB16BN - 1) / kB16BN, ((a.qk_hi ? a.Rvt : a.R) + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : 1);
     hipLaunchKernelGGL((gemm_pl_bf16<NSPLIT, BM, K1, F16>), grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }
@@ -291,6 +297,10 @@ hipError_t launch_pl_f16(hipStream_t s, const GemmArgs& a) {
 int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int precision = FS2_PREC_FP32) {
     if (a.ktaps - 1 > kMaxHalo) return fail(h, FS2_ERR_UNSUPPORTED, "%s: kernel size %d > %d", name, a.ktaps, kMaxHalo + 1);
     if (a.C % 4 != 0 || a.ldx % 4 != 0) return fail(h, FS2_ERR_UNSUPPORTED, "%s: channels %d / ld %d must be multiples of 4", name, a.C, a.ldx);
+    if (h && !a.kpart && h->kp) { a.kpart = h->kp; a.kpart_cap = h->kp_cap; a.ksplit = 3; }
+    if (h && !a.regime_rows) a.regime_rows = h->cur_regime;
+    const int max_extra_splits = a.ksplit;      // on entry: how many partial buffers the caller allows; from here on a.ksplit = splits in use
+    a.ksplit = 1;
     const bool need_rows = a.ln_g || a.dot_w || a.pe;
     const double flops = 2.0 * a.R * (double)a.N * a.C * a.ktaps;
     const double bytes = 4.0 * ((double)a.R * a.C + (double)a.N * a.C * a.ktaps + (double)a.R * a.N);
@@ -308,17 +318,29 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         if (!t.Y && y_needed) { t.Y = a.scratch; t.ldy = a.N; }
         if (!t.Y && y_needed) return fail(h, FS2_ERR_ARG, "%s: no output or scratch buffer", name);
         if (t.qk_hi && (a.ktaps != 1 || a.att_D % kB16BN != 0 || a.N != 3 * a.att_D)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: fused QKV split needs D %% 128 == 0", name);
-        if (need_rows && !row8) { t.act_post = 0; t.Yp = nullptr; }      // the row kernel writes the planes
-        // split-K: a k = 1 GEMM with a long K on a grid that leaves CUs idle is a serial chain of k-steps; 2-4 workgroups share it and
-        // ln_rows (which follows anyway) adds their partial sums in a fixed order (deterministic, unlike atomics)
+        // split-K: on a grid that leaves most CUs idle the kernel is a serial chain of k-steps (one utterance: 108 steps of the FFN
+        // conv on 88 workgroups); 2-4 workgroups share the chunks and ln_rows adds their partial sums in a fixed order
+        // (deterministic, unlike atomics) and applies the epilogue.  The choice depends on regime_rows (the same number in the host-
+        // and the device-driven layout), never on the capacity.
         t.ksplit = 1;
-        if (need_rows && !row8 && a.ktaps == 1 && a.kpart && !opts().nosplitk) {
+        size_t y_slab = 0;       // 1: Y lives in the first slab of kpart (no fp32 output buffer of the caller's)
+        const long rr = a.regime_rows ? a.regime_rows : a.R;
+        if (!row8 && !a.qk_hi && a.kpart && !opts().nosplitk && a.N <= 1024 && rr <= kSplitRegime && a.R <= kSplitRows) {
             const int nchunks = a.Cpad / 32;
-            const long wgs = (long)((a.N + kB16BN - 1) / kB16BN) * ((a.R + 63) / 64);
-            int ksp = 1;
+            const long wgs = (long)((a.N + kB16BN - 1) / kB16BN) * ((rr + 63) / 64);
+            const bool own_y = t.Y != nullptr;
+            const size_t ld = own_y ? (size_t)t.ldy : (size_t)a.N;
             for (int cand = 4; cand >= 2; --cand)
-                if (nchunks % cand == 0 && nchunks / cand >= 4 && wgs * cand <= 1024 && cand - 1 <= a.ksplit) { ksp = cand; break; }
-            t.ksplit = ksp;
+                if (nchunks % cand == 0 && (nchunks / cand) * a.ktaps >= 4 && wgs * cand <= 1024 && cand - 1 <= max_extra_splits &&
+                    (size_t)(cand - (own_y ? 1 : 0)) * a.R * ld <= a.kpart_cap) { t.ksplit = cand; break; }
+            if (t.ksplit > 1 && !own_y) y_slab = 1;
+        }
+        const bool rows_pass = (need_rows && !row8) || t.ksplit > 1;
+        if (y_slab) { t.Y = a.kpart; t.ldy = a.N; }
+        if (rows_pass) { t.act_post = 0; t.Yp = nullptr; }      // the row kernel applies the epilogue and writes the planes
+        if (t.ksplit > 1) {
+            t.relu_pre = 0;                                      // partial sums: ReLU only after they are added (ln_rows)
+            t.kpart = a.kpart + y_slab * (size_t)a.R * a.N;
             t.kpart_stride = (size_t)a.R * t.ldy;
         }
         if (a.f16_terms && (a.ktaps == 1 || need_rows || a.qk_hi)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: the fp16 arithmetic exists for plain convolutions only", name);
@@ -342,12 +364,12 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
                 else e = (precision == FS2_PREC_BF16X3) ? launch_row8_t<3, 2>(s, t) : launch_row8_t<1, 2>(s, t);
             } else e = (precision == FS2_PREC_BF16X3) ? launch_pl<3>(s, t) : launch_pl<1>(s, t);
         }
-        if (e == hipSuccess && need_rows && !row8) {
+        if (e == hipSuccess && rows_pass) {
             char nm[112];
             snprintf(nm, sizeof nm, "%s.rows", name);
             Scope sc(h, s, nm, 0.0, 8.0 * a.R * a.N);
             GemmArgs r = a;
-            r.Y = t.Y; r.ldy = t.ldy; r.ksplit = t.ksplit; r.kpart_stride = t.kpart_stride;
+            r.Y = t.Y; r.ldy = t.ldy; r.ksplit = t.ksplit; r.kpart = t.kpart; r.kpart_stride = t.kpart_stride;
             hipLaunchKernelGGL(ln_rows, dim3((a.R + 3) / 4), dim3(256), 0, s, r);
             e = hipGetLastError();
         }
@@ -605,9 +627,6 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         a.resid = b.x0; a.ldr = D; a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
         const int f16t = (pl && ffn_terms && ly.w1.ktaps > 1 && ly.w1.wf) ? ffn_terms : 0;      // this layer's FFN conv on fp16 operands?
         if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; a.yp_f16 = f16t ? 1 : 0; }       // x1p feeds only that conv
-        // split-K partials go to the fp32 QKV buffer, idle from here on.  Only where the row count is the same in the host- and the
-        // device-driven layout (the token-level stack): the choice of the split depends on it, and the two layouts must agree bit for bit
-        if (pl && allow_splitk) { a.kpart = b.qkv; a.ksplit = 3; }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.ffn1", tag);
         a = gemm_args(ly.w1, b.x1, D, R, dl.row_pos, pl ? nullptr : b.hid, ly.w1.N);
@@ -621,7 +640,6 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         a.Rp = dl.dims; a.regime_rows = regime_rows;
         a.resid = b.x1; a.ldr = D; a.ln_g = ly.ln2g; a.ln_b = ly.ln2b; a.ln_eps = 1e-5f;
         if (pl) { a.Xp = hidp; a.Yp = b.x0p; a.yp_chunks = D / 32; }
-        if (pl && allow_splitk) { a.kpart = b.qkv; a.ksplit = 3; }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
     }
     return FS2_OK;
@@ -819,7 +837,7 @@ struct TokenPlan {   // offsets inside the token workspace
 
 // carve the token workspace; if ws == nullptr only sizes it
 size_t carve_tokens(const fs2_config& c, const fs2_batch& b, const HostLayout& L, void* ws, size_t cap, int** meta, StackBufs* sb,
-                    float** p0, float** p1, float** dlog_rows, int64_t** dint, int** cum, int** olens32, bool* ok) {
+                    float** p0, float** p1, float** dlog_rows, int64_t** dint, int** cum, int** olens32, bool* ok, float** kp = nullptr, size_t* kp_cap = nullptr) {
     Bump bp(ws, cap);
     const size_t R = L.Rpad;
     int* m = bp.take<int>(layout_dev_ints(L));
@@ -842,6 +860,10 @@ size_t carve_tokens(const fs2_config& c, const fs2_batch& b, const HostLayout& L
     int64_t* di = bp.take<int64_t>((size_t)b.B * b.Tmax);
     int* cu = bp.take<int>((size_t)b.B * b.Tmax);
     int* o32 = bp.take<int>(b.B);
+    const size_t kcap = (size_t)4 * std::min<size_t>(R, kSplitRows) * 1024;
+    float* kpb = bp.take<float>(kcap);
+    if (kp) *kp = kpb;
+    if (kp_cap) *kp_cap = kcap;
     if (meta) *meta = m;
     if (sb) { sb->x0 = x0; sb->x1 = x1; sb->qkv = qkv; sb->ctx = ctx; sb->hid = hid; sb->qkh = qkh; sb->qkl = qkl; sb->vth = vth; sb->vtl = vtl; sb->x0p = x0p; sb->x1p = x1p; sb->xps = xps; }
     if (p0) *p0 = q0;
@@ -856,6 +878,7 @@ size_t carve_tokens(const fs2_config& c, const fs2_batch& b, const HostLayout& L
 
 struct FrameBufs {
     int* meta; float* hfr; float *t0, *t1, *e_rows, *p_rows; StackBufs sb; float *before, *after; int *qe, *qp, *lri;
+    float* kp; size_t kp_cap;
 };
 
 size_t carve_frames(const fs2_config& c, const HostLayout& L, void* ws, size_t cap, FrameBufs* fb, bool* ok) {
@@ -885,6 +908,8 @@ size_t carve_frames(const fs2_config& c, const HostLayout& L, void* ws, size_t c
     f.qe = bp.take<int>(R);
     f.qp = bp.take<int>(R);
     f.lri = bp.take<int>(R);
+    f.kp_cap = (size_t)4 * std::min<size_t>(R, kSplitRows) * 1024;
+    f.kp = bp.take<float>(f.kp_cap);
     if (fb) *fb = f;
     if (ok) *ok = bp.ok();
     return align_up(bp.off, 256);
@@ -1058,8 +1083,9 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
     if (L.len.size() && *std::max_element(L.len.begin(), L.len.end()) > h->enc.pe_rows)
         return fail(h, FS2_ERR_ARG, "sequence longer than the positional table (%d rows): extend `pe` and reload", h->enc.pe_rows);
     int* meta; StackBufs sb; float *p0, *p1, *dlog_rows; int64_t* dint; int* cum; int* o32; bool ok;
-    carve_tokens(c, b, L, io->workspace, io->workspace_bytes, &meta, &sb, &p0, &p1, &dlog_rows, &dint, &cum, &o32, &ok);
+    carve_tokens(c, b, L, io->workspace, io->workspace_bytes, &meta, &sb, &p0, &p1, &dlog_rows, &dint, &cum, &o32, &ok, &h->kp, &h->kp_cap);
     if (!ok) return fail(h, FS2_ERR_WORKSPACE, "fs2_encode: workspace too small");
+    h->cur_regime = 0;
     if ((rc = upload_layout(h, s, L, meta, h->dtok))) return rc;
     const DevLayout& dl = h->dtok;
     const bool enc_pl = prec != FS2_PREC_FP32;   // activations also travel as planes (x0p holds those of x0 before and after the stack)
@@ -1153,6 +1179,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     FrameBufs f; bool ok;
     carve_frames(c, L, io->workspace, io->workspace_bytes, &f, &ok);
     if (!ok) return fail(h, FS2_ERR_WORKSPACE, "fs2_decode: workspace too small");
+    h->kp = f.kp; h->kp_cap = f.kp_cap;
     DevLayout dl;
     if (devlay) {
         if ((rc = device_layout(h, s, L, f.meta, dl, h->o32, b.compat_padded, io->masked, io->Lmax, h->dec.pe_rows))) return rc;
@@ -1164,6 +1191,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     // the same ESTIMATE instead: 8 frames per phoneme (LJSpeech: 7.9) plus the per-utterance alignment rows.  Any value gives
     // correct results; using the same one in both modes makes them bit-identical.
     const int regime_rows = (int)std::min<long>(8 * h->enc_ntok + (long)b.B * (kGap + kAttAlign) + kGap, INT32_MAX - 256);
+    h->cur_regime = regime_rows;
     // bf16 modes: the length-regulator output (and later its sum with the pitch / energy embeddings) is also written as planes,
     // in x1p (free until the decoder stack's first LayerNorm): the A operand of both variance predictors and of the decoder input layer
     void* hfr_planes = (prec != FS2_PREC_FP32 && c.adim % 32 == 0) ? f.sb.x1p : nullptr;

@@ -137,6 +137,9 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
                 const float4 q = *reinterpret_cast<const float4*>(a.kpart + (size_t)(z - 1) * a.kpart_stride + (size_t)row * a.ldy + c);
                 v[j].x += q.x; v[j].y += q.y; v[j].z += q.z; v[j].w += q.w;
             }
+        if (a.relu_pre) {      // ReLU in front of the LayerNorm (predictors); idempotent when the GEMM epilogue already applied it
+            v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f); v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f);
+        }
         s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
     }
     if (a.ln_g) {

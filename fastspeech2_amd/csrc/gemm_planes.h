@@ -150,10 +150,10 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
             dma16(src + (u & 1) * b_o1 + (u >> 1) * b_o2, dst + u * 4096);
     };
 
-    // split-K (k = 1 form only): this workgroup's share of the 32-channel chunks
-    const int ks = (K1 && a.ksplit > 1) ? (int)blockIdx.z : 0;
-    const int c_begin = (K1 && a.ksplit > 1) ? ks * (nchunks / a.ksplit) : 0;
-    const int c_end = (K1 && a.ksplit > 1) ? c_begin + nchunks / a.ksplit : nchunks;
+    // split-K: this workgroup's share of the 32-channel chunks
+    const int ks = (a.ksplit > 1) ? (int)blockIdx.z : 0;
+    const int c_begin = (a.ksplit > 1) ? ks * (nchunks / a.ksplit) : 0;
+    const int c_end = (a.ksplit > 1) ? c_begin + nchunks / a.ksplit : nchunks;
     const int it_end = c_end * ktaps;
     dma_A(c_begin, K1 ? (c_begin & 1) : 0);
     dma_B(c_begin * ktaps, (c_begin * ktaps) & 1);
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
             return;
         }
     }
-    if (K1 && ks > 0) {          // split-K partial: raw sums into this split's buffer (same row stride as Y)
+    if (ks > 0) {                // split-K partial: raw sums into this split's buffer (same row stride as Y)
         GemmArgs p = a;
         p.Y = a.kpart + (size_t)(ks - 1) * a.kpart_stride;
         p.Yp = nullptr; p.relu_pre = 0; p.act_post = 0;
