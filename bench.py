@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--profile-kernels", action="store_true", help="print the per-kernel hipEvent table to stderr")
     ap.add_argument("--graph", action="store_true", help="replay the forward as one captured HIP graph (single GPU; the launch-bound small configs)")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON record: whatever a library prints there (RCCL's version banner, ...) goes to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -162,7 +165,8 @@ def main():
     B = xs.shape[0]
     parts = shard_indices(il.tolist(), world)
     mine = parts[rank]
-    synth = ShardedSynthesizer(model) if use_dist else None
+    # throughput mode: the all-gather of step i (side stream) overlaps the forward of step i + 1; FS2_DIST_SERIAL=1 keeps everything on one stream
+    synth = ShardedSynthesizer(model, overlap=os.environ.get("FS2_DIST_SERIAL") != "1") if use_dist else None
 
     graph_run = None
 
@@ -191,6 +195,8 @@ def main():
             graph_run = model.capture_graph(xs, il)
         for _ in range(max(args.warmup, 1)):
             mel, olens_all = step()
+        if synth is not None:
+            synth.wait()
         assert all_ok(), "capacities of the asynchronous path were exceeded during warm-up"
         total_frames = int(olens_all.sum())
         local_frames = int(olens_all.cpu()[torch.as_tensor(mine, dtype=torch.int64)].sum()) if mine else 0
@@ -220,6 +226,8 @@ def main():
         for i in range(args.steps):
             mel, olens_all = step()
             ev[i + 1].record()
+        if synth is not None:
+            synth.wait()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -308,7 +316,8 @@ def main():
                        "utterances": B, "utterances_per_gpu": [len(p) for p in parts], "valid_frames_per_step": total_frames,
                        "phonemes": int(il.sum()),
                        "algorithmic_gflop_per_step": round(sum(path_flops(int(t), int(l)) for t, l in zip(il, ol_host)) / 1e9, 1),
-                       "parallelism": ("LPT utterance-sharded x%d (unequal shards), one all-gather(packed mels + frame counts) over RCCL" % world)
+                       "parallelism": ("LPT utterance-sharded x%d (unequal shards), one all-gather(packed mels + frame counts) over RCCL%s"
+                                       % (world, ", overlapped with the next step's forward (side stream)" if synth.overlap else ""))
                                       if use_dist else "single GPU",
                        "launch": launch},
             "roofline": roofline,
@@ -325,7 +334,7 @@ def main():
             line["vs_cpu"] = round(line["value"] / cb["value"], 1)
             line["mel_max_abs_diff"] = worst
             line["decision_agreement"] = flips
-        print(json.dumps(line))
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 

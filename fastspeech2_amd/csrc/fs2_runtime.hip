@@ -1155,7 +1155,8 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     if (b.B != h->enc_B || b.Tmax != h->enc_Tmax || b.compat_padded != h->enc_compat || io->token_workspace != h->enc_ws)
         return fail(h, FS2_ERR_STATE, "fs2_decode: batch does not match the preceding fs2_encode");
     const bool devlay = io->olens == nullptr && io->row_capacity > 0;
-    if ((!io->olens && !devlay) || !io->workspace || !io->after) return fail(h, FS2_ERR_ARG, "fs2_decode: olens (or row_capacity) / workspace / after must be given");
+    if ((!io->olens && !devlay) || !io->workspace || (!io->after && !io->after_packed))
+        return fail(h, FS2_ERR_ARG, "fs2_decode: olens (or row_capacity) / workspace / after (or after_packed) must be given");
     const fs2_config& c = h->cfg;
     if (devlay) {
         if (!io->status) return fail(h, FS2_ERR_ARG, "fs2_decode: the device-driven layout needs a status buffer");
@@ -1268,7 +1269,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         Scope sc(h, s, "unpack", 0, 4.0 * R * c.odim * 4);
         const int* lim_len = dl.len;    // every stored row (pads carry real values in compat mode)
         const int* lim_msk = (b.compat_padded && !io->masked) ? dl.len : dl.vlen;
-        if ((rc = unpack<float>(h, s, mel_after, c.odim, dl.start, lim_len, b.B, io->Lmax, io->after, 0.f))) return rc;
+        if (io->after && (rc = unpack<float>(h, s, mel_after, c.odim, dl.start, lim_len, b.B, io->Lmax, io->after, 0.f))) return rc;
         if (io->before && (rc = unpack<float>(h, s, f.before, c.odim, dl.start, lim_len, b.B, io->Lmax, io->before, 0.f))) return rc;
         if (io->e_out && (rc = unpack<float>(h, s, f.e_rows, 1, dl.start, lim_msk, b.B, io->Lmax, io->e_out, 0.f))) return rc;
         if (io->p_out && (rc = unpack<float>(h, s, f.p_rows, 1, dl.start, lim_msk, b.B, io->Lmax, io->p_out, 0.f))) return rc;
@@ -1296,7 +1297,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         if (devlay) {
             // a capacity was too small: the mels of this call do not exist.  NaN-fill them so that a caller who forgets to look at
             // `status` cannot mistake the (empty-layout) zeros or uninitialised rows for silence
-            hipLaunchKernelGGL(poison_on_overflow, dim3(256), dim3(256), 0, s, dl.dims, io->after, (int64_t)b.B * io->Lmax * c.odim,
+            hipLaunchKernelGGL(poison_on_overflow, dim3(256), dim3(256), 0, s, dl.dims, io->after, io->after ? (int64_t)b.B * io->Lmax * c.odim : (int64_t)0,
                                io->after_packed, io->after_packed ? io->row_capacity * c.odim : (int64_t)0, io->before,
                                io->before ? (int64_t)b.B * io->Lmax * c.odim : (int64_t)0);
             HIP_TRY(h, hipGetLastError());

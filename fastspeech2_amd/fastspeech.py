@@ -366,7 +366,7 @@ class FeedForwardTransformer(nn.Module):
 
     # ------------------------------------------------------------------ the path
     def _run(self, xs, ilens, olens=None, ds=None, es=None, ps=None, is_inference=False, compat=False,
-             want=("before", "after"), d_override=None, capacity=None, alpha=1.0):
+             want=("before", "after"), d_override=None, capacity=None, alpha=1.0, packed_out=None):
         """Runs fs2_encode -> (olens readback) -> fs2_decode.  Returns a dict of device tensors.
 
         ``capacity=(total_frames_bound, per_utterance_bound)`` selects the device-driven frame layout instead: no host
@@ -374,7 +374,8 @@ class FeedForwardTransformer(nn.Module):
         ``per_utterance_bound`` frames, ``out["olens"]`` is the DEVICE int64 tensor and ``out["status"]`` a device
         int32[8] = {rows used, attention work items, overflow flags, longest utterance, valid frames, ...}: the results are
         valid only if ``status[2] == 0`` (see ``inference_batch(sync=False)``); ``after_packed`` then has
-        ``fs2_row_capacity(total_frames_bound)`` rows, of which the first ``status[4]`` are filled."""
+        ``fs2_row_capacity(total_frames_bound)`` rows, of which the first ``status[4]`` are filled; ``packed_out`` (a contiguous
+        float32 [>= that many rows, odim] tensor) receives them in place instead of a new allocation."""
         _require_device(xs)
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
@@ -436,9 +437,18 @@ class FeedForwardTransformer(nn.Module):
                     cbuf("e_outs", (B, Lcap)), cbuf("p_outs", (B, Lcap)),
                     cbuf("qe", (B, Lcap), torch.int32), cbuf("qp", (B, Lcap), torch.int32),
                     cbuf("lr_index", (B, Lcap), torch.int32), cbuf("decoder_out", (B, Lcap, self._cfg["ddim"])),
-                    tok_ws.data_ptr(), frm_ws.data_ptr(), frm_ws.numel(), cbuf("after_packed", (rows, odim)), rows, status.data_ptr())
-                if dio.after is None:
-                    raise ValueError("'after' must be requested")
+                    tok_ws.data_ptr(), frm_ws.data_ptr(), frm_ws.numel(), None, rows, status.data_ptr())
+                if "after_packed" in want:
+                    if packed_out is not None:
+                        if (not packed_out.is_contiguous() or packed_out.dtype != torch.float32 or packed_out.device != dev
+                                or packed_out.dim() != 2 or packed_out.shape[1] != odim or packed_out.shape[0] < rows):
+                            raise ValueError("packed_out must be a contiguous float32 [>= %d, %d] tensor on %s" % (rows, odim, dev))
+                        out["after_packed"] = packed_out[:rows]
+                    else:
+                        out["after_packed"] = torch.empty((rows, odim), dtype=torch.float32, device=dev)
+                    dio.after_packed = out["after_packed"].data_ptr()
+                if dio.after is None and dio.after_packed is None:
+                    raise ValueError("'after' or 'after_packed' must be requested")
                 _lib.check(L.fs2_decode(h, st, C.byref(dio)), h)
                 out["olens"], out["status"] = olens_dev, status
                 if d_int is not None:
@@ -564,7 +574,7 @@ class FeedForwardTransformer(nn.Module):
         self._learn_ratio(il, r["olens"], alpha)
         return r["after"][0]
 
-    def inference_batch(self, xs, ilens, d_override=None, packed=False, sync=True, capacity=None, alpha=1.0):
+    def inference_batch(self, xs, ilens, d_override=None, packed=False, sync=True, capacity=None, alpha=1.0, packed_out=None):
         """Batched free-running synthesis (not in the reference, which only has single-utterance
         ``inference``): per-utterance semantics; returns (mels [B, Lmax, odim], olens [B] on the host), or with
         ``packed=True`` (valid frames back to back [sum(olens), odim], olens): the form the multi-GPU gather ships.
@@ -576,7 +586,8 @@ class FeedForwardTransformer(nn.Module):
         (mels [B, Lcap, odim] zero-padded - or, with ``packed=True``, [rows_cap, odim] whose first sum(olens) rows are the
         valid frames - , olens as a DEVICE int64 tensor) and carries ``status`` / ``ok()`` / ``check()`` for THIS call.
         If a capacity did not suffice the mels of that call are NaN-filled on the device (never silently wrong);
-        ``ok()`` is then False: repeat the batch with ``sync=True`` (which learns the exact sizes).  Any number of
+        ``ok()`` is then False: repeat the batch with ``sync=True`` (which learns the exact sizes).  ``packed_out``: a
+        caller-owned [>= row capacity, odim] buffer that receives the pack in place (the multi-GPU send buffer).  Any number of
         asynchronous calls may be in flight; ``async_ok()`` waits for all of them and tells whether every one since the last
         ``async_ok()`` was valid.  The first call of a model is always synchronous.  ``alpha``: duration scale."""
         il = torch.as_tensor(ilens).detach().to("cpu", torch.int64).reshape(-1)
@@ -587,8 +598,9 @@ class FeedForwardTransformer(nn.Module):
         if not sync and (self._frames_per_token is not None or capacity is not None):
             self._harvest_async(block=False)
             total, Lcap = capacity if capacity is not None else self.predict_capacity(il, alpha)
-            key = "after_packed" if packed else "after"
-            r = self._run(xs, il, is_inference=True, compat=False, want=("after", key), d_override=d_override, capacity=(total, Lcap), alpha=alpha)
+            key = "after_packed" if packed else "after"         # (packed: the padded mels are neither built nor written)
+            r = self._run(xs, il, is_inference=True, compat=False, want=(key,), d_override=d_override, capacity=(total, Lcap), alpha=alpha,
+                          packed_out=packed_out if packed else None)
             if torch.cuda.is_current_stream_capturing():     # graph capture: no host-side bookkeeping inside the graph
                 return AsyncMels(r[key], r["olens"], r["status"], None)
             return AsyncMels(r[key], r["olens"], r["status"], self._record_async(il, r, xs.device, alpha))

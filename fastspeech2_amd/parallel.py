@@ -176,7 +176,30 @@ def row_capacity(n_utt, total_frames):
     return int(_lib.lib().fs2_row_capacity(C.byref(_lib.Batch(max(int(n_utt), 1), 1, None, 0, 0)), int(total_frames)))
 
 
-def gather_shards(packed_cap, olens_dev, parts, Lout, cap=None, group=None):
+_TABLE_CACHE = {}
+
+
+def _scatter_table(parts, bmax, total, dev):
+    """Host-known scatter table of :func:`gather_shards`: slot (r, j) -> global utterance index, holes -> a dummy slot
+    ``total``; on the device, int64 [world * bmax].  Built in pinned memory and copied without blocking the host (a pageable
+    copy would wait for the stream, i.e. for the forward just enqueued); the last table is cached (a server re-uses bucketed
+    batch shapes, the benchmark repeats one batch)."""
+    key = (tuple(tuple(p) for p in parts), bmax, str(dev))
+    hit = _TABLE_CACHE.get("last")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    gi = torch.full((len(parts), bmax), total, dtype=torch.int64)
+    for r, p in enumerate(parts):
+        if p:
+            gi[r, : len(p)] = torch.as_tensor(p, dtype=torch.int64)
+    gi = gi.reshape(-1)
+    if dev.type == "cuda":
+        gi = gi.pin_memory().to(dev, non_blocking=True)
+    _TABLE_CACHE["last"] = (key, gi)
+    return gi
+
+
+def gather_shards(packed_cap, olens_dev, parts, Lout, cap=None, group=None, send_buf=None):
     """The ONE collective of the sharded path, sync-free (for ``inference_batch(sync=False, packed=True)``): nothing is read
     back to the host.
 
@@ -188,6 +211,8 @@ def gather_shards(packed_cap, olens_dev, parts, Lout, cap=None, group=None):
     (RCCL over xGMI) moves everything; the global indices are already known to every rank.  Offsets are computed on the
     device, one unpack kernel scatters the received rows into the ordered, zero-padded result.  ``Lout`` = padded length of
     the result (>= the longest utterance of any rank, e.g. the agreed per-utterance capacity).
+    ``send_buf``: the [cap + meta_rows(bmax, odim), odim] buffer whose leading rows ARE ``packed_cap`` (the model wrote its pack
+    straight into it: no staging copy); otherwise one is allocated and the pack copied in.
     Returns (mels [total, Lout, odim] in global utterance order, olens [total] int64 on the device)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -202,8 +227,11 @@ def gather_shards(packed_cap, olens_dev, parts, Lout, cap=None, group=None):
     if olens_dev.numel() != b:
         raise ValueError("rank %d holds %d utterances but passed %d frame counts" % (rank, b, olens_dev.numel()))
     mrows = meta_rows(bmax, odim)
-    send = packed_cap.new_zeros(cap + mrows, odim)
-    send[:rows].copy_(packed_cap)
+    if send_buf is not None and send_buf.shape[0] == cap + mrows and send_buf.data_ptr() == packed_cap.data_ptr():
+        send = send_buf                                      # rows beyond the valid frames are never read (lengths are clamped)
+    else:
+        send = packed_cap.new_zeros(cap + mrows, odim)
+        send[:rows].copy_(packed_cap)
     if b:
         send[cap:].view(-1).view(torch.int64)[:b].copy_(olens_dev)
     recv = packed_cap.new_empty(world * (cap + mrows), odim)
@@ -213,12 +241,7 @@ def gather_shards(packed_cap, olens_dev, parts, Lout, cap=None, group=None):
     starts = torch.cumsum(ol, 1) - ol + base
     # a rank whose capacities overflowed ships a NaN-filled pack with its true frame counts: never index past its region
     ol = torch.minimum(ol, (base + cap - starts).clamp(min=0))
-    # host-known scatter table: slot (r, j) -> global utterance index, holes -> a dummy slot `total`
-    gi = torch.full((world, bmax), total, dtype=torch.int64)
-    for r, p in enumerate(parts):
-        if p:
-            gi[r, : len(p)] = torch.as_tensor(p, dtype=torch.int64)
-    gi = gi.to(dev).reshape(-1)
+    gi = _scatter_table(parts, bmax, total, dev)
     starts_g = torch.zeros(total + 1, dtype=torch.int32, device=dev).scatter_(0, gi, starts.reshape(-1).to(torch.int32))[:total]
     lens_g = torch.zeros(total + 1, dtype=torch.int32, device=dev).scatter_(0, gi, ol.reshape(-1).to(torch.int32))[:total]
     if packed_cap.is_cuda:
@@ -251,10 +274,15 @@ class ShardedSynthesizer:
     * ``ShardedSynthesizer(run_local)`` with a callable ``run_local(xs_shard, ilens_shard) -> (mels, olens)``: generic form
       (host-driven gather of ragged padded batches, :func:`gather_mels`)."""
 
-    def __init__(self, model_or_fn, group=None):
+    def __init__(self, model_or_fn, group=None, overlap=False):
+        """``overlap=True`` (throughput mode): the collective and the unpack of a sync-free call run on a side stream, so the
+        all-gather of batch i over xGMI overlaps the forward of batch i+1; the returned tensors then belong to that stream:
+        call ``wait()`` (or synchronize the device) before touching them on the current stream."""
         self.model = model_or_fn if hasattr(model_or_fn, "inference_batch") else None
         self.run_local = None if self.model is not None else model_or_fn
         self.group = group
+        self.overlap = bool(overlap)
+        self._comm = None
         self._ratio = None          # (mean, max) frames per phoneme agreed between the ranks
         self._last = None
 
@@ -318,7 +346,13 @@ class ShardedSynthesizer:
             mel, ol = gather_packed(packed, olens, mine, xs.shape[0], self.group)
             return mel, ol.to(xs.device)
         total, Lcap = self.capacities(il, parts)
+        cap = max(row_capacity(len(p), total) for p in parts)
+        send_buf = None
         if len(mine):
+            if coll and xs.is_cuda:      # the model writes its pack straight into the send buffer of the all-gather
+                bmax = max(max(len(p) for p in parts), 1)
+                send_buf = torch.empty(cap + meta_rows(bmax, model.odim), model.odim, dtype=torch.float32, device=xs.device)
+                kw_loc = dict(kw_loc, packed_out=send_buf)
             res = model.inference_batch(xs_loc, il_loc, packed=True, sync=False, capacity=(total, Lcap), **kw_loc)
             packed, olens_dev = res
             self._last = res
@@ -328,8 +362,22 @@ class ShardedSynthesizer:
         if not coll:
             # same data path without the collective: offsets on the device, one unpack kernel
             return _unpack_local(packed, olens_dev, Lcap), olens_dev
-        cap = max(row_capacity(len(p), total) for p in parts)
-        return gather_shards(packed, olens_dev, parts, Lcap, cap=cap, group=self.group)
+        if self.overlap and packed.is_cuda:
+            cur = torch.cuda.current_stream(xs.device)
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=xs.device)
+            self._comm.wait_stream(cur)                       # the pack of this batch is complete
+            with torch.cuda.stream(self._comm):
+                out = gather_shards(packed, olens_dev, parts, Lcap, cap=cap, group=self.group, send_buf=send_buf)
+            packed.record_stream(self._comm)                  # allocated on the compute stream, read by the side stream
+            olens_dev.record_stream(self._comm)
+            return out
+        return gather_shards(packed, olens_dev, parts, Lcap, cap=cap, group=self.group, send_buf=send_buf)
+
+    def wait(self):
+        """Make the current stream wait for the gathers issued in overlap mode (no host synchronisation)."""
+        if self._comm is not None:
+            torch.cuda.current_stream(self._dev).wait_stream(self._comm)
 
     def ok(self):
         """True if the capacities of the last sync-free call sufficed on EVERY rank (waits for the GPU; collective)."""

@@ -119,7 +119,8 @@ typedef struct fs2_decode_io {
     const float *ps;          /* device [B, ps_stride] pitches to quantise,  or NULL: predict    */
     int32_t es_stride, ps_stride;
     float *before;            /* device [B, Lmax, odim] mel before Postnet (pads = 0 unless compat) */
-    float *after;             /* device [B, Lmax, odim] mel after Postnet                         */
+    float *after;             /* device [B, Lmax, odim] mel after Postnet (may be NULL when after_packed
+                                 is given: the sharded path ships only the packed form)             */
     float *e_out, *p_out;     /* device [B, Lmax] predictor outputs (or NULL)                     */
     int32_t *qe, *qp;         /* device [B, Lmax] bucket indices actually embedded (or NULL)      */
     int32_t *lr_index;        /* device [B, Lmax] phoneme index of every frame, -1 at pads (or NULL) */

@@ -495,6 +495,13 @@ def test_sharded_synthesizer_over_nccl_world_size_1(env):
             L = ref.shape[1]
             assert torch.equal(o1.cpu(), ol) and torch.equal(o2.cpu(), ol)
             assert torch.equal(m1[:, :L], ref) and torch.equal(m2[:, :L], ref) and float(m2[:, L:].abs().sum()) == 0.0
+            over = ShardedSynthesizer(model, overlap=True)         # throughput mode: gather + unpack on a side stream
+            over._ratio = synth._ratio
+            outs = [over(xs, il, d_override=ds) for _ in range(3)] # three batches in flight, none waited for
+            over.wait()
+            assert over.ok()
+            for m, o in outs:
+                assert torch.equal(o.cpu(), ol) and torch.equal(m[:, :L], ref)
             synth._ratio = (0.05, 0.05)                            # absurd capacities -> overflow must be visible, not silent
             m3, _ = synth(xs, il, d_override=ds)
             assert not synth.ok()

@@ -7,7 +7,9 @@ HBM traffic = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes): on gfx950 FETCH_SIZE ta
 coalesced reads at 64 B (MI355X_MICROARCH.md, HBM/rocprofv3 section); WRITE_SIZE is used as is."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+workload = os.environ.get("FS2_PROF_WORKLOAD", "c3")
+precision = os.environ.get("FS2_PROF_PRECISION", "bf16x3")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
@@ -42,10 +44,10 @@ dom = max(agg.items(), key=lambda kv: sum(kv[1].get("dur_us", [0])))
 (kern, grid), v = dom
 fetch = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
 write = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
-info = {"_comment": "HBM-side traffic of the dominant kernel per launch: rocprofv3 PMC passes (tools/profile_round.sh) of `python bench.py --steps 4 --warmup 2 "
-                    "--no-cpu-baseline` (c3, bf16x3) on MI355X; FETCH_SIZE and WRITE_SIZE from separate --pmc runs, averaged over all launches of the kernel/grid; "
+info = {"_comment": "HBM-side traffic of the dominant kernel per launch: rocprofv3 PMC passes (tools/profile_round.sh) of `python bench.py --workload %s --precision %s "
+                    "--steps 4 --warmup 2 --no-cpu-baseline` on MI355X;" % (workload, precision) + " FETCH_SIZE and WRITE_SIZE from separate --pmc runs, averaged over all launches of the kernel/grid; "
                     "traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md). Raw table: profiles/%s_pmc_summary.csv" % tag,
-        "workload": "c3", "precision": "bf16x3", "kernel": kern, "grid_size": grid, "launches_averaged": len(v["FETCH_SIZE"]),
+        "workload": workload, "precision": precision, "kernel": kern, "grid_size": grid, "launches_averaged": len(v["FETCH_SIZE"]),
         "fetch_size_kb_raw": round(fetch, 1), "write_size_kb": round(write, 1), "traffic_bytes": int((2 * fetch + write) * 1024),
         "avg_duration_us_pmc_run": round(sum(v["dur_us"]) / len(v["dur_us"]), 1)}
 if len(sys.argv) > 2:
