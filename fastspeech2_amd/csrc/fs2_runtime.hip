@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/fs2.h"
@@ -931,6 +932,13 @@ template <typename T>
 int unpack(fs2_handle* h, hipStream_t s, const T* src, int W, const int* start, const int* limit, int B, int Lout, T* dst, T fill) {
     const int64_t total = (int64_t)B * Lout * W;
     if (total == 0) return FS2_OK;
+    if constexpr (std::is_same<T, float>::value) {
+        if (W % 4 == 0 && fill == 0.f && (reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) % 16 == 0) {
+            hipLaunchKernelGGL(unpack_rows4, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, src, W / 4, start, limit, B, Lout, dst);
+            HIP_TRY(h, hipGetLastError());
+            return FS2_OK;
+        }
+    }
     hipLaunchKernelGGL(unpack_rows<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, W, start, limit, B, Lout, dst, fill);
     HIP_TRY(h, hipGetLastError());
     return FS2_OK;
@@ -1438,7 +1446,10 @@ int fs2_op_unpack_rows(void* stream, const float* src, int32_t W, int32_t B, con
     for (int i = 0; i < B; ++i) { host[i] = starts[i]; host[B + i] = lens[i]; }
     OP_TRY(hipMemcpyAsync(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, s));
     const int64_t total = (int64_t)B * Lout * W;
-    hipLaunchKernelGGL(unpack_rows<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, W, dev, dev + B, B, Lout, dst, 0.f);
+    if (W % 4 == 0 && (reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) % 16 == 0)
+        hipLaunchKernelGGL(unpack_rows4, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, src, W / 4, dev, dev + B, B, Lout, dst);
+    else
+        hipLaunchKernelGGL(unpack_rows<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, W, dev, dev + B, B, Lout, dst, 0.f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "unpack_rows: %s", hipGetErrorString(e));
     return FS2_OK;
@@ -1449,7 +1460,10 @@ int fs2_op_unpack_rows_dev(void* stream, const float* src, int32_t W, int32_t B,
     if (!src || !dst || !starts_dev || !lens_dev || B <= 0 || W <= 0 || Lout <= 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_unpack_rows_dev: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = (int64_t)B * Lout * W;
-    hipLaunchKernelGGL(unpack_rows<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, W, starts_dev, lens_dev, B, Lout, dst, 0.f);
+    if (W % 4 == 0 && (reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) % 16 == 0)
+        hipLaunchKernelGGL(unpack_rows4, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, src, W / 4, starts_dev, lens_dev, B, Lout, dst);
+    else
+        hipLaunchKernelGGL(unpack_rows<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, W, starts_dev, lens_dev, B, Lout, dst, 0.f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, FS2_ERR_HIP, "unpack_rows: %s", hipGetErrorString(e));
     return FS2_OK;
