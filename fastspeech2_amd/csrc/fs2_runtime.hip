@@ -242,6 +242,15 @@ hipError_t launch_row8_t(hipStream_t s, const GemmArgs& a) {
 }
 
 template <int NSPLIT, int NB>
+hipError_t launch_row8c_t(hipStream_t s, const GemmArgs& a) {
+    static LdsAttr attr;
+    constexpr size_t lds = row8c_lds_bytes<NB>();
+    allow_lds(reinterpret_cast<const void*>(&gemm_row8c_bf16<NSPLIT, NB>), lds, attr);
+    hipLaunchKernelGGL((gemm_row8c_bf16<NSPLIT, NB>), dim3((a.R + 127) / 128), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int NSPLIT, int NB>
 hipError_t launch_qkv8_t(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
     constexpr size_t lds = row8_lds_bytes<NB>();
@@ -260,7 +269,10 @@ bool use_qkv8(const GemmArgs& a) {
 // Row-complete LN-fused kernel (gemm_row8_bf16) for k = 1 GEMMs that end in a row epilogue: one workgroup per CU, so it
 // needs about a CU's worth of 128-row tiles to pay (FS2_ROW8=0|1 forces the choice).
 bool use_row8(const GemmArgs& a) {
-    if (a.ktaps != 1 || a.dot_w || a.qk_hi || (a.N != 256 && a.N != 384) || !(a.ln_g || a.pe)) return false;
+    if (a.qk_hi || (a.N != 256 && a.N != 384)) return false;
+    if (a.ktaps > 1) {      // conv form (gemm_row8c_bf16): LayerNorm-terminated convolutions, optionally with the scalar head; no PE
+        if (!a.ln_g || a.pe || a.f16_terms) return false;
+    } else if (a.dot_w || !(a.ln_g || a.pe)) return false;
     if (opts().row8 >= 0) return opts().row8 != 0;
     return ((a.regime_rows ? a.regime_rows : a.R) + 127) / 128 >= 128;
 }
@@ -315,7 +327,7 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         if (!a.Xp && !a.xp_scratch) return fail(h, FS2_ERR_STATE, "%s: no activation planes and no scratch to build them", name);
         if (a.ldy % 4 != 0 || (a.resid && a.ldr % 4 != 0)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: bf16 path needs row strides that are multiples of 4", name);
         const bool row8 = use_row8(a);
-        const bool y_needed = (need_rows && !row8) || (!a.Yp && !a.qk_hi);
+        const bool y_needed = (need_rows && !row8) || (!a.Yp && !a.qk_hi && !(row8 && a.dot_w));      // (row-complete + scalar head: nothing but dot_out leaves)
         if (!t.Y && y_needed) { t.Y = a.scratch; t.ldy = a.N; }
         if (!t.Y && y_needed) return fail(h, FS2_ERR_ARG, "%s: no output or scratch buffer", name);
         if (t.qk_hi && (a.ktaps != 1 || a.att_D % kB16BN != 0 || a.N != 3 * a.att_D)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: fused QKV split needs D %% 128 == 0", name);
@@ -360,6 +372,9 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
             } else if (use_qkv8(t)) {
                 if (a.att_D == 384) e = (precision == FS2_PREC_BF16X3) ? launch_qkv8_t<3, 3>(s, t) : launch_qkv8_t<1, 3>(s, t);
                 else e = (precision == FS2_PREC_BF16X3) ? launch_qkv8_t<3, 2>(s, t) : launch_qkv8_t<1, 2>(s, t);
+            } else if (row8 && a.ktaps > 1) {
+                if (a.N == 384) e = (precision == FS2_PREC_BF16X3) ? launch_row8c_t<3, 3>(s, t) : launch_row8c_t<1, 3>(s, t);
+                else e = (precision == FS2_PREC_BF16X3) ? launch_row8c_t<3, 2>(s, t) : launch_row8c_t<1, 2>(s, t);
             } else if (row8) {
                 if (a.N == 384) e = (precision == FS2_PREC_BF16X3) ? launch_row8_t<3, 3>(s, t) : launch_row8_t<1, 3>(s, t);
                 else e = (precision == FS2_PREC_BF16X3) ? launch_row8_t<3, 2>(s, t) : launch_row8_t<1, 2>(s, t);
@@ -656,7 +671,8 @@ int run_predictor(fs2_handle* h, hipStream_t s, const char* tag, const Predictor
     for (size_t l = 0; l < p.conv.size(); ++l) {
         const bool last = (l + 1 == p.conv.size());
         float* out = bufs[l & 1];
-        GemmArgs a = gemm_args(p.conv[l], in, ld, R, row_pos, last ? nullptr : out, p.conv[l].N);
+        // bf16 modes: the next layer consumes the planes; the fp32 copy is written only where a kernel pair needs it as scratch
+        GemmArgs a = gemm_args(p.conv[l], in, ld, R, row_pos, (last || (xps && prec != FS2_PREC_FP32)) ? nullptr : out, p.conv[l].N);
         a.Rp = Rp;
         a.relu_pre = 1; a.ln_g = p.lng[l]; a.ln_b = p.lnb[l]; a.ln_eps = 1e-12f;
         if (last) { a.dot_w = p.lin_w; a.dot_b = p.lin_b; a.dot_out = out_rows; }

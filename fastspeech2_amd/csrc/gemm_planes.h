@@ -482,6 +482,242 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// gemm_row8c_bf16: the row-complete structure for a k-tap convolution (N = 128 NB outputs per row) with ReLU -> LayerNorm ->
+// activation (and the predictors' scalar head Linear(N, 1)) in the epilogue: the pitch / energy predictor layers at frame level
+// (conv k = 3, 256 -> 256, reference variance_predictor.py:46-51).  They used to run as 128 x 128 conv tiles that wrote the pre-LN
+// tensor, followed by an HBM-bound row pass (ln_rows): four 20-us passes plus four 30-MB scratch round trips per step at c3.
+//   * 8 waves as 4(M) x 2(N), wave tile 32 rows x 64 NB columns, as gemm_row8_bf16; one workgroup per CU.
+//   * A: one tile of 128 + halo rows per 32-channel chunk, shared by the taps (single buffer, refilled behind a barrier at the
+//     end of a chunk, exactly as in gemm_pl_bf16's conv form); B: one 128 NB x 128 B tile per (chunk, tap), double-buffered.
+template <int NB> constexpr size_t row8c_lds_bytes() { return (size_t)(128 + kMaxHalo) * 128 + 2 * (size_t)(128 * NB) * 128; }
+
+template <int NSPLIT, int NB>
+__global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
+    constexpr int MT = 2, NT = 4 * NB, BM = 128, BN = 128 * NB;
+    constexpr int AROWS = BM + kMaxHalo;
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    char* As = smem_c;
+    char* Bs0 = smem_c + AROWS * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM;
+    if (a.Rp != nullptr && m0 >= ((*a.Rp + 127) & ~127)) return;      // device-driven layout: tile beyond the rows in use
+    const int ktaps = a.ktaps, P = (ktaps - 1) >> 1;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int lp = rperm(lr);
+    const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
+    const __bf16* Xp = reinterpret_cast<const __bf16*>(a.Xp);
+    const int nchunks = a.Cpad / 32;
+    const int niter = nchunks * ktaps;
+    const int jrow = lane >> 3, jslot = lane & 7;
+    // A: instruction q = w, w + 8, w + 16 fills tile rows 8q + jrow (q & 1 == w & 1, so the swizzle term is a per-lane constant)
+    const int a_instr = (BM + 2 * P + 7) >> 3;
+    const int sA = jslot ^ (jrow >> 1) ^ ((wave & 1) << 2);
+    const int arow0 = m0 - P + wave * 8 + jrow;
+    const __bf16* a_src0 = Xp + (ptrdiff_t)arow0 * nchunks * 64 + sA * 8;
+    const size_t a_qstride = (size_t)64 * nchunks * 64;
+    auto dma_A = [&](int ch) {
+        char* dst = As + wave * 1024;
+        const __bf16* src = a_src0 + (size_t)ch * 64;
+        int row = arow0;
+        for (int q = wave; q < a_instr; q += 8) {
+            const bool ok = row >= 0 && row < a.R;
+            const void* sp = ok ? static_cast<const void*>(src) : static_cast<const void*>(g_zero16);
+            __builtin_amdgcn_global_load_lds(sp, (lds_void_t*)dst, 16, 0, 0);
+            dst += 8192; src += a_qstride; row += 64;
+        }
+    };
+    // B: as gemm_row8_bf16 (weight row 64u + 4 rperm_inv(jB) + (w >> 1) -> LDS rows 16 ((w >> 1) + 4u) + jB), image step it = chunk * ktaps + tap
+    const int jB = (wave & 1) * 8 + jrow;
+    const int sB = jslot ^ ((jB >> 1) & 7);
+    const __bf16* b_src0 = Wb + ((size_t)(4 * rperm_inv(jB) + (wave >> 1)) * niter) * 64 + sB * 8;
+    const size_t b_ustride = (size_t)64 * niter * 64;
+    auto dma_B = [&](int it, int buf) {
+        char* bs = Bs0 + buf * (BN * 128) + wave * 1024;
+        const __bf16* bsrc = b_src0 + (size_t)it * 64;
+#pragma unroll
+        for (int u = 0; u < 2 * NB; ++u)
+            __builtin_amdgcn_global_load_lds(bsrc + u * b_ustride, (lds_void_t*)(bs + u * 8192), 16, 0, 0);
+    };
+
+    dma_A(0);
+    dma_B(0, 0);
+    const int col0 = wn * (64 * NB) + 4 * lr;
+    int rowi[MT][4];
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowi[mt][r] = m0 + wm * 32 + mt * 16 + rperm(lg * 4 + r);
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + col0 + 64 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4 v = bv;
+                if (a.resid && rowi[mt][r] < a.R) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)rowi[mt][r] * a.ldr + col0 + 64 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mt][4 * g + j][r] = v[j];
+            }
+    }
+    int it = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        for (int tap = 0; tap < ktaps; ++tap, ++it) {
+            dma_barrier();                       // DMA of step `it` landed; every wave is done with step it - 1
+            if (it + 1 < niter) dma_B(it + 1, (it + 1) & 1);
+            const char* Bs = Bs0 + (it & 1) * (BN * 128);
+            bf16x8_t ah[MT], al[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = wm * 32 + mt * 16 + lp + tap;
+                ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
+                if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
+            }
+            if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int n2 = 0; n2 < NT; n2 += 2) {
+                bf16x8_t bh[2], bl[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int n = wn * (64 * NB) + (n2 + u) * 16 + lp;
+                    bh[u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
+                    if (NSPLIT == 3) bl[u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
+                }
+                if (NSPLIT == 3) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[u], acc[mt][n2 + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[u], acc[mt][n2 + u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[u], acc[mt][n2 + u], 0, 0, 0);
+            }
+            if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
+            if (tap == ktaps - 1 && chunk + 1 < nchunks) {
+                __syncthreads();                 // every wave has read its last fragments of this chunk's A tile
+                dma_A(chunk + 1);
+            }
+        }
+    }
+
+    // ---- epilogue: rows stay in registers (as gemm_row8_bf16) + the scalar head
+    const int* __restrict__ rpos = a.row_pos;
+    float* __restrict__ Y = a.Y;
+    void* __restrict__ Yp = a.Yp;
+    const bool relu_first = a.relu_pre != 0;
+    int pos[MT][4];
+    float rsum[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pos[mt][r] = rowi[mt][r] < a.R ? (rpos ? rpos[rowi[mt][r]] : 0) : -1;
+            float s = 0.f;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                if (relu_first) acc[mt][n][r] = fmaxf(acc[mt][n][r], 0.f);
+                s += acc[mt][n][r];
+            }
+            rsum[mt][r] = wave16_sum(s);
+        }
+    float* red = reinterpret_cast<float*>(smem_c);      // [3 passes][8 waves][32 rows]
+    float mean[MT][4], rstd[MT][4];
+    __syncthreads();                                    // operand buffers are dead
+    if (a.ln_g) {
+        if (lr == 0)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * 32 + mt * 16 + lg * 4 + r] = rsum[mt][r];
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mean[mt][r] = (rsum[mt][r] + red[(wave ^ 1) * 32 + mt * 16 + lg * 4 + r]) / (float)a.N;
+                float q = 0.f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) { const float d = acc[mt][n][r] - mean[mt][r]; q += d * d; }
+                rsum[mt][r] = wave16_sum(q);
+            }
+        if (lr == 0)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[256 + wave * 32 + mt * 16 + lg * 4 + r] = rsum[mt][r];
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                rstd[mt][r] = 1.f / sqrtf((rsum[mt][r] + red[256 + (wave ^ 1) * 32 + mt * 16 + lg * 4 + r]) / (float)a.N + a.ln_eps);
+    }
+    float dsum[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dsum[mt][r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        const int col = col0 + 64 * g;
+        f32x4 gam = f32x4{1.f, 1.f, 1.f, 1.f}, bet = f32x4{0.f, 0.f, 0.f, 0.f}, dw = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.ln_g) { gam = *reinterpret_cast<const f32x4*>(a.ln_g + col); bet = *reinterpret_cast<const f32x4*>(a.ln_b + col); }
+        if (a.dot_w) dw = *reinterpret_cast<const f32x4*>(a.dot_w + col);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rowi[mt][r];
+                if (row >= a.R) continue;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (pos[mt][r] >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = acc[mt][4 * g + j][r];
+                        if (a.ln_g) t = (t - mean[mt][r]) * rstd[mt][r] * gam[j] + bet[j];
+                        t = apply_act(t, a.act_post);
+                        v[j] = t;
+                        dsum[mt][r] += t * dw[j];
+                    }
+                }
+                if (Y) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
+                if (Yp) store_planes4(Yp, row, a.yp_chunks, col, v, a.yp_f16 != 0);
+            }
+    }
+    if (a.dot_w) {      // scalar head: dot_out[row] = v . dot_w + dot_b, summed over the 16 lanes of a row group and the two N-waves
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dsum[mt][r] = wave16_sum(dsum[mt][r]);
+        if (lr == 0)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[512 + wave * 32 + mt * 16 + lg * 4 + r] = dsum[mt][r];
+        __syncthreads();
+        if (wn == 0 && lr == 0) {
+            const float db = a.dot_b ? a.dot_b[0] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rowi[mt][r];
+                    if (row < a.R) a.dot_out[row] = pos[mt][r] >= 0 ? dsum[mt][r] + red[512 + (wave ^ 1) * 32 + mt * 16 + lg * 4 + r] + db : 0.f;
+                }
+        }
+    }
+}
+
 // gemm_qkv8_bf16: the fused QKV projection on the row8 structure (8 waves, 128 rows x 128 NB columns per pass, one workgroup per
 // CU).  N = 3 D with D = 128 NB: the workgroup makes three passes over its 128 rows - Q, K, V - re-streaming the A tile from L2;
 // per MFMA it issues 1/2.25 of the LDS-DMA instructions and meets 1/3 of the barriers of the 64 x 128 tiles of gemm_pl_bf16, whose

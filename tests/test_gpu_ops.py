@@ -39,6 +39,7 @@ CASES = [
     (100, 384, 80, 1, True, False, False, None, 0, False, "feat_out 384->80"),
     (70, 256, 384, 1, True, False, False, 1e-5, 1, False, "decoder input layer Linear+LN+ReLU"),
     (64, 256, 1024, 1, True, False, False, None, 1, False, "linear FFN (k=1) + relu, exact tile rows"),
+    (290, 256, 384, 5, True, True, False, 1e-5, 1, False, "conv k5 + residual + LN + relu, N=384 (row-complete conv form)"),
 ]
 
 
@@ -108,14 +109,15 @@ def test_conv_gemm_planes_kernel_tile_heights(case, precision, bm, fs2_option):
     test_conv_gemm(case, precision)
 
 
-ROW8_CASES = [c for c in CASES if c[3] == 1 and c[7] is not None and c[2] in (256, 384)]
+ROW8_CASES = [c for c in CASES if c[7] is not None and c[2] in (256, 384)]      # k = 1 (gemm_row8_bf16) and conv form (gemm_row8c_bf16, incl. the scalar head)
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("case", ROW8_CASES, ids=[c[-1] for c in ROW8_CASES])
 def test_conv_gemm_row_complete_ln_fused_kernel(case, precision, fs2_option):
-    """gemm_row8_bf16 (128 rows x all N columns per workgroup, LayerNorm in the epilogue) is chosen by size in the
-    model path; force it here on the small op cases (several row tiles, ragged last tile, gap rows)."""
+    """gemm_row8_bf16 / gemm_row8c_bf16 (128 rows x all N columns per workgroup, ReLU / LayerNorm / activation / scalar head in the
+    epilogue; k = 1 and k-tap conv form) are chosen by size in the model path; force them here on the small op cases (several row
+    tiles, ragged last tile, gap rows)."""
     fs2_option("FS2_ROW8", 1)
     test_conv_gemm(case, precision)
 
