@@ -30,7 +30,7 @@ __global__ void build_row_meta(const int* start, const int* len, int B, int rpad
 // utterances before b (row offset of utterance b in the packed output); 8 = kGap, 32 = kAttAlign, 64 = kAttBQ.
 __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B, int compat, int masked, int row_cap, int work_cap,
                                                          int lmax_cap, int pe_rows, int* start, int* len, int* klen, int* vlen,
-                                                         int* rank_tmp, int* woff_tmp, int* pcum, int2* work, int* dims) {
+                                                         int* rank_tmp, int* woff_tmp, int* pcum, int2* work, int* dims, int* status = nullptr) {
     // The serial parts (row prefix with alignment, longest-first dealing to eight queues) run on one thread: their operands are staged
     // in LDS first -- from global memory every iteration was a dependent round trip (46 us per call at B = 64, 1 % of a c3 step).
     constexpr int kStage = 4096;                      // utterances staged in LDS (beyond: the same code on the global arrays)
@@ -94,6 +94,9 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
         if (mx > pe_rows) ovf |= 4;
         if (s_min <= 0) ovf |= 8;
         dims[0] = row; dims[1] = ovf ? 0 : depth * 8; dims[2] = ovf; dims[3] = mx; dims[4] = frames; dims[5] = 0; dims[6] = 0; dims[7] = 0;
+        if (status) {     // the caller's copy of the same eight words
+            status[0] = row; status[1] = ovf ? 0 : depth * 8; status[2] = ovf; status[3] = mx; status[4] = frames; status[5] = 0; status[6] = 0; status[7] = 0;
+        }
     }
     __syncthreads();
     if (dims[2] != 0) {           // a capacity is too small: leave an empty layout (all rows are gap rows, no work) so that
@@ -156,7 +159,7 @@ __global__ void duration_kernel(const float* d_log, int64_t n, int64_t* d) {
 // Duration post-op (reference duration_predictor.py:77-84): packed per-row log-durations ->
 // padded [B,Tmax] outputs; d = clamp(round_half_even(exp(y) - 1), 0), pads -> 0.
 __global__ void dur_finalize(const float* dlog_rows, const int* start, const int* vlen, int B, int Tmax,
-                             float* d_log, int64_t* d_int) {
+                             float* d_log, int64_t* d_int, int64_t* d_int2 = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * Tmax) return;
     const int b = i / Tmax, t = i - b * Tmax;
@@ -168,6 +171,7 @@ __global__ void dur_finalize(const float* dlog_rows, const int* start, const int
     }
     if (d_log) d_log[i] = y;
     if (d_int) d_int[i] = d;
+    if (d_int2) d_int2[i] = d;      // the caller's copy (saves a device-to-device memcpy launch)
 }
 
 // Per-utterance inclusive prefix sum of the durations actually used (reference length_regulator.py:60,
@@ -331,23 +335,27 @@ __global__ void unpack_rows(const T* src, int W, const int* start, const int* li
 }
 
 // the same for float rows with W % 4 == 0 (the mel outputs: W = 80): 16-byte accesses, one (row, 4 channels) piece per thread
-__global__ void unpack_rows4(const float* src, int W4, const int* start, const int* limit, int B, int Lout, float* dst) {
+// ovf (device-driven layout): the overflow flags of the call; when set the outputs of the call do not exist -> NaN instead of zeros
+__global__ void unpack_rows4(const float* src, int W4, const int* start, const int* limit, int B, int Lout, float* dst, const int* ovf = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * Lout * W4) return;
     const int w = (int)(i % W4);
     const int64_t bj = i / W4;
     const int j = (int)(bj % Lout), b = (int)(bj / Lout);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < limit[b]) v = reinterpret_cast<const float4*>(src)[(size_t)(start[b] + j) * W4 + w];
+    if (ovf && *ovf != 0) { const float q = __builtin_nanf(""); v = make_float4(q, q, q, q); }
+    else if (j < limit[b]) v = reinterpret_cast<const float4*>(src)[(size_t)(start[b] + j) * W4 + w];
     reinterpret_cast<float4*>(dst)[i] = v;
 }
 
 // gapped packed rows -> dense packed rows (valid frames only, utterances back to back): dst row cum[b] + j
+// (ovf as in unpack_rows4; dst then holds R rows: the row capacity)
 __global__ void pack_rows(const float* src, int W, const int* row_pos, const int* row_seq, const int* vlen, const int* cum, int R,
-                          float* dst) {
+                          float* dst, const int* ovf = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int w4 = W / 4;
     if (i >= (int64_t)R * w4) return;
+    if (ovf && *ovf != 0) { const float q = __builtin_nanf(""); reinterpret_cast<float4*>(dst)[i] = make_float4(q, q, q, q); return; }
     const int row = (int)(i / w4), c = (int)(i - (int64_t)row * w4) * 4;
     const int b = row_seq[row];
     if (b < 0) return;

@@ -580,7 +580,7 @@ int upload_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, D
 
 // device-driven variant: the layout arrays are produced by frame_layout_dev from the device frame counts
 int device_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, DevLayout& D, const int* olens32, int compat, int masked,
-                  int lmax_cap, int pe_rows) {
+                  int lmax_cap, int pe_rows, int* status) {
     D.start = dev; D.len = dev + L.B; D.klen = dev + 2 * L.B; D.vlen = dev + 3 * L.B;
     int* rank_tmp = dev + 4 * L.B;
     int* woff_tmp = dev + 5 * L.B;
@@ -592,7 +592,7 @@ int device_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, D
     rest = reinterpret_cast<int*>(align_up(reinterpret_cast<size_t>(rest), 16));
     D.row_pos = rest; D.row_seq = rest + L.Rpad;
     hipLaunchKernelGGL(frame_layout_dev, dim3(1), dim3(1024), 0, s, olens32, L.B, compat, masked, L.R, L.nwork(), lmax_cap, pe_rows,
-                       D.start, D.len, D.klen, D.vlen, rank_tmp, woff_tmp, D.pcum, D.work, D.dims);
+                       D.start, D.len, D.klen, D.vlen, rank_tmp, woff_tmp, D.pcum, D.work, D.dims, status);
     hipLaunchKernelGGL(build_row_meta, dim3((L.Rpad + 255) / 256), dim3(256), 0, s, D.start, D.len, L.B, L.Rpad, D.row_pos, D.row_seq);
     HIP_TRY(h, hipGetLastError());
     return FS2_OK;
@@ -945,12 +945,15 @@ void frame_layout(const fs2_batch& b, const int64_t* olens, int masked, HostLayo
 }
 
 template <typename T>
-int unpack(fs2_handle* h, hipStream_t s, const T* src, int W, const int* start, const int* limit, int B, int Lout, T* dst, T fill) {
+int unpack(fs2_handle* h, hipStream_t s, const T* src, int W, const int* start, const int* limit, int B, int Lout, T* dst, T fill,
+           const int* ovf = nullptr, bool* ovf_handled = nullptr) {
     const int64_t total = (int64_t)B * Lout * W;
+    if (ovf_handled) *ovf_handled = false;
     if (total == 0) return FS2_OK;
     if constexpr (std::is_same<T, float>::value) {
         if (W % 4 == 0 && fill == 0.f && (reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) % 16 == 0) {
-            hipLaunchKernelGGL(unpack_rows4, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, src, W / 4, start, limit, B, Lout, dst);
+            hipLaunchKernelGGL(unpack_rows4, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, src, W / 4, start, limit, B, Lout, dst, ovf);
+            if (ovf_handled) *ovf_handled = true;
             HIP_TRY(h, hipGetLastError());
             return FS2_OK;
         }
@@ -1125,9 +1128,8 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
     {
         Scope sc(h, s, "dur.post", 0, 0);
         const int n = b.B * b.Tmax;
-        hipLaunchKernelGGL(dur_finalize, dim3((n + 255) / 256), dim3(256), 0, s, dlog_rows, dl.start, dl.vlen, b.B, b.Tmax, io->d_log, dint);
+        hipLaunchKernelGGL(dur_finalize, dim3((n + 255) / 256), dim3(256), 0, s, dlog_rows, dl.start, dl.vlen, b.B, b.Tmax, io->d_log, dint, io->d_int);
         HIP_TRY(h, hipGetLastError());
-        if (io->d_int) HIP_TRY(h, hipMemcpyAsync(io->d_int, dint, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(dur_scan, dim3(b.B), dim3(256), 0, s, io->ds ? io->ds : dint, b.Tmax, dl.vlen, cum, io->olens, o32,
                            io->duration_alpha > 0.f ? io->duration_alpha : 1.f);
         HIP_TRY(h, hipGetLastError());
@@ -1207,8 +1209,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     h->kp = f.kp; h->kp_cap = f.kp_cap;
     DevLayout dl;
     if (devlay) {
-        if ((rc = device_layout(h, s, L, f.meta, dl, h->o32, b.compat_padded, io->masked, io->Lmax, h->dec.pe_rows))) return rc;
-        HIP_TRY(h, hipMemcpyAsync(io->status, dl.dims, 8 * sizeof(int), hipMemcpyDeviceToDevice, s));
+        if ((rc = device_layout(h, s, L, f.meta, dl, h->o32, b.compat_padded, io->masked, io->Lmax, h->dec.pe_rows, io->status))) return rc;
     } else if ((rc = upload_layout(h, s, L, f.meta, dl))) return rc;
     const int R = L.R;
     // Kernel variants with different summation orders (LayerNorm fused into the row-complete GEMM or not) are chosen from a row
@@ -1293,8 +1294,12 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         Scope sc(h, s, "unpack", 0, 4.0 * R * c.odim * 4);
         const int* lim_len = dl.len;    // every stored row (pads carry real values in compat mode)
         const int* lim_msk = (b.compat_padded && !io->masked) ? dl.len : dl.vlen;
-        if (io->after && (rc = unpack<float>(h, s, mel_after, c.odim, dl.start, lim_len, b.B, io->Lmax, io->after, 0.f))) return rc;
-        if (io->before && (rc = unpack<float>(h, s, f.before, c.odim, dl.start, lim_len, b.B, io->Lmax, io->before, 0.f))) return rc;
+        // device-driven layout: the kernels that write the mel outputs look at the overflow flags themselves and write NaN when a
+        // capacity was too small (nobody can mistake the outputs of such a call for silence); poison_on_overflow covers the rest
+        const int* ovf = devlay ? dl.dims + 2 : nullptr;
+        bool after_done = false, before_done = false, packed_done = false;
+        if (io->after && (rc = unpack<float>(h, s, mel_after, c.odim, dl.start, lim_len, b.B, io->Lmax, io->after, 0.f, ovf, &after_done))) return rc;
+        if (io->before && (rc = unpack<float>(h, s, f.before, c.odim, dl.start, lim_len, b.B, io->Lmax, io->before, 0.f, ovf, &before_done))) return rc;
         if (io->e_out && (rc = unpack<float>(h, s, f.e_rows, 1, dl.start, lim_msk, b.B, io->Lmax, io->e_out, 0.f))) return rc;
         if (io->p_out && (rc = unpack<float>(h, s, f.p_rows, 1, dl.start, lim_msk, b.B, io->Lmax, io->p_out, 0.f))) return rc;
         if (io->qe && (rc = unpack<int>(h, s, f.qe, 1, dl.start, lim_len, b.B, io->Lmax, io->qe, -1))) return rc;
@@ -1315,15 +1320,16 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
                 dcum = up;
             }
             const int64_t n = (int64_t)R * (c.odim / 4);
-            hipLaunchKernelGGL(pack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mel_after, c.odim, dl.row_pos, dl.row_seq, dl.vlen, dcum, R, io->after_packed);
+            hipLaunchKernelGGL(pack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mel_after, c.odim, dl.row_pos, dl.row_seq, dl.vlen, dcum, R, io->after_packed,
+                               (devlay && R == io->row_capacity) ? ovf : (const int*)nullptr);
             HIP_TRY(h, hipGetLastError());
+            packed_done = devlay && R == io->row_capacity;
         }
-        if (devlay) {
-            // a capacity was too small: the mels of this call do not exist.  NaN-fill them so that a caller who forgets to look at
-            // `status` cannot mistake the (empty-layout) zeros or uninitialised rows for silence
-            hipLaunchKernelGGL(poison_on_overflow, dim3(256), dim3(256), 0, s, dl.dims, io->after, io->after ? (int64_t)b.B * io->Lmax * c.odim : (int64_t)0,
-                               io->after_packed, io->after_packed ? io->row_capacity * c.odim : (int64_t)0, io->before,
-                               io->before ? (int64_t)b.B * io->Lmax * c.odim : (int64_t)0);
+        const bool need_poison = devlay && ((io->after && !after_done) || (io->before && !before_done) || (io->after_packed && !packed_done));
+        if (need_poison) {
+            hipLaunchKernelGGL(poison_on_overflow, dim3(256), dim3(256), 0, s, dl.dims, io->after, (io->after && !after_done) ? (int64_t)b.B * io->Lmax * c.odim : (int64_t)0,
+                               io->after_packed, (io->after_packed && !packed_done) ? io->row_capacity * c.odim : (int64_t)0, io->before,
+                               (io->before && !before_done) ? (int64_t)b.B * io->Lmax * c.odim : (int64_t)0);
             HIP_TRY(h, hipGetLastError());
         }
     }
