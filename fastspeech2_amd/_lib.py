@@ -31,7 +31,8 @@ class Config(C.Structure):
         "idim", "odim", "adim", "aheads", "elayers", "eunits", "ddim", "dlayers", "dunits", "ffn_kernel",
         "dur_layers", "dur_chans", "dur_kernel", "var_layers", "var_chans", "var_kernel", "n_bins",
         "postnet_layers", "postnet_chans", "postnet_filts", "use_batch_norm", "use_scaled_pos_enc",
-        "reduction_factor", "device", "decoder_input_layer")]
+        "reduction_factor", "device", "decoder_input_layer", "enc_normalize_before", "dec_normalize_before", "enc_concat_after",
+        "dec_concat_after")]
 
 
 class TensorDesc(C.Structure):

@@ -44,6 +44,7 @@ struct GemmArgs {
     const float* pe; int pe_ld; const float* pe_alpha; float x_scale;  // v = v*x_scale + alpha*pe[pos] if pe
     const float* dot_w; const float* dot_b; float* dot_out;            // dot_out[row] = v . dot_w + dot_b
     float* Y; int ldy;                     // output [R, ldy] or nullptr
+    const float* Ysrc; int ldsrc;          // ln_rows only: read the rows from here instead of Y (out-of-place LayerNorm)
     const void* Wb;                        // split-bf16 weight image (gemm_bf16.h) or nullptr
     // fused QKV epilogue (bf16 attention operands, attn_bf16.h): when qk_hi != nullptr the tile is not written to Y
     // but split into bf16 hi/lo planes: columns [0,2D) -> qk_hi/lo [Rvt][2D] (Q scaled by q_scale), [2D,3D) -> V^T [D][Rvt]

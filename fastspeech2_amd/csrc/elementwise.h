@@ -394,8 +394,9 @@ __global__ __launch_bounds__(256) void transpose_rows(const float* src, int64_t 
 // ---- weight repacking (run once per load_state_dict) ----
 // conv / linear weight [N][C][k] -> [Npad][k][Cpad], zero padded, optionally scaled per output channel by
 // gamma / sqrt(var + eps) (eval-mode BatchNorm folded into the Postnet convs, reference modules.py:285-348).
+// ldw: elements between consecutive output rows of the source (0: C; larger for a column slice of a wider Linear weight, k = 1).
 __global__ void repack_weight(const float* w, int N, int C, int k, int Npad, int Cpad, const float* bn_g,
-                              const float* bn_v, float bn_eps, float* out) {
+                              const float* bn_v, float bn_eps, float* out, int ldw = 0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)Npad * k * Cpad;
     if (i >= total) return;
@@ -404,7 +405,7 @@ __global__ void repack_weight(const float* w, int N, int C, int k, int Npad, int
     const int n = (int)(i / ((int64_t)Cpad * k));
     float v = 0.f;
     if (n < N && c < C) {
-        v = w[((size_t)n * C + c) * k + tap];
+        v = w[((size_t)n * (ldw ? ldw : C) + c) * k + tap];
         if (bn_g) v *= bn_g[n] / sqrtf(bn_v[n] + bn_eps);
     }
     out[i] = v;

@@ -39,6 +39,7 @@ struct Gemm {          // one repacked Linear / Conv1d
 };
 struct Layer {
     Gemm qkv, out, w1, w2;
+    Gemm cat_x, cat_a;       // concat_after: concat_linear [D, 2D] split into its x half (carries the bias) and its attention half
     float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
 };
 struct Predictor {
@@ -50,6 +51,8 @@ struct Stack {
     std::vector<Layer> layers;
     float* pe = nullptr; int pe_rows = 0;
     float* alpha = nullptr;
+    bool pre_ln = false, concat = false;            // encoder.py:53-71: normalize_before / concat_after
+    float *after_g = nullptr, *after_b = nullptr;   // after_norm (applied only when pre_ln, encoder.py:201-202)
 };
 
 // Split-K serves small batches (regime_rows <= kSplitRegime: beyond, the grids fill the chip anyway).  Its scratch holds up to 4 slabs of
@@ -603,10 +606,14 @@ int device_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, D
 // In the bf16 modes the attention context and the FFN hidden layer exist ONLY as planes, in the ctx / hid storage.
 struct StackBufs { float *x0, *x1, *qkv, *ctx, *hid; __bf16 *qkh, *qkl, *vth, *vtl; void *x0p, *x1p, *xps; };
 
+int run_stack_general(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, int D, int heads, int R, const HostLayout& L, const DevLayout& dl,
+                      int mask_q, const StackBufs& b, int prec, bool x0p_ready, int regime_rows);
+
 // x0 holds the input; returns the buffer holding the output (x0 again).
 int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, int D, int heads, int R,
               const HostLayout& L, const DevLayout& dl, int mask_q, const StackBufs& b, int prec, bool x0p_ready = false, bool allow_splitk = false,
               int regime_rows = 0, int ffn_terms = 0) {
+    if (st.pre_ln || st.concat) return run_stack_general(h, s, tag, st, D, heads, R, L, dl, mask_q, b, prec, x0p_ready, regime_rows);
     char nm[96];
     double att_flops = 0;
     for (size_t i = 0; i < L.klen.size(); ++i) att_flops += 4.0 * D * (double)L.klen[i] * std::min(L.len[i], mask_q ? L.klen[i] : L.len[i]);
@@ -657,6 +664,110 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         a.resid = b.x1; a.ldr = D; a.ln_g = ly.ln2g; a.ln_b = ly.ln2b; a.ln_eps = 1e-5f;
         if (pl) { a.Xp = hidp; a.Yp = b.x0p; a.yp_chunks = D / 32; }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
+    }
+    return FS2_OK;
+}
+
+// standalone LayerNorm over rows (out of place): src [R, ld] -> Y [R, N] fp32 and / or planes
+int launch_ln(fs2_handle* h, hipStream_t s, const char* name, const float* src, int ld, int R, int N, const int* row_pos, const float* g,
+              const float* bta, float eps, float* Y, void* Yp) {
+    GemmArgs a;
+    memset(&a, 0, sizeof a);
+    a.N = N; a.R = R; a.row_pos = row_pos; a.Y = Y; a.ldy = N; a.Ysrc = src; a.ldsrc = ld; a.ln_g = g; a.ln_b = bta; a.ln_eps = eps;
+    a.x_scale = 1.f; a.ksplit = 1; a.Yp = Yp; a.yp_chunks = round_up(N, 32) / 32;
+    if (N > 1024 || N % 4) return fail(h, FS2_ERR_UNSUPPORTED, "%s: LayerNorm width %d", name, N);
+    Scope sc(h, s, name, 0.0, 8.0 * R * N);
+    hipLaunchKernelGGL(ln_rows, dim3((R + 3) / 4), dim3(256), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, FS2_ERR_HIP, "%s launch: %s", name, hipGetErrorString(e));
+    return FS2_OK;
+}
+
+// FFT-block stack for the non-default block variants (reference core/encoder.py:53-71,201-202): normalize_before (LayerNorm in front of
+// the sub-layers, after_norm at the end) and / or concat_after (x + concat_linear(cat(x, self_attn(x)))).  Same kernels as run_stack,
+// without the LayerNorm fusion where the norm no longer follows a GEMM; cat(x, a) . Wc^T is computed as x . Wc[:, :D]^T + a . Wc[:, D:]^T
+// (two GEMMs chained through the residual input).  Scratch: xn1 -> hid / xps, attention output -> qkv / qkh, xn2 -> qkv / xps.
+int run_stack_general(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, int D, int heads, int R, const HostLayout& L, const DevLayout& dl,
+                      int mask_q, const StackBufs& b, int prec, bool x0p_ready, int regime_rows) {
+    char nm[96];
+    double att_flops = 0;
+    for (size_t i = 0; i < L.klen.size(); ++i) att_flops += 4.0 * D * (double)L.klen[i] * std::min(L.len[i], mask_q ? L.klen[i] : L.len[i]);
+    const bool pl = prec != FS2_PREC_FP32;
+    const bool pre = st.pre_ln, cat = st.concat;
+    void* ctxp = pl ? (void*)b.ctx : nullptr;
+    void* hidp = pl ? (void*)b.hid : nullptr;
+    int rc;
+    if (pl && !pre && !x0p_ready) {
+        const int64_t n = (int64_t)R * (D / 4);
+        hipLaunchKernelGGL(to_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, b.x0, D, D, R, D / 32, b.x0p, 0);
+    }
+    for (size_t li = 0; li < st.layers.size(); ++li) {
+        const Layer& ly = st.layers[li];
+        const float* qin = b.x0; const void* qinp = pl ? b.x0p : nullptr;
+        if (pre) {
+            snprintf(nm, sizeof nm, "%s.ln1", tag);
+            if ((rc = launch_ln(h, s, nm, b.x0, D, R, D, dl.row_pos, ly.ln1g, ly.ln1b, 1e-5f, pl ? nullptr : b.hid, pl ? b.xps : nullptr))) return rc;
+            qin = b.hid; qinp = pl ? b.xps : nullptr;
+        }
+        snprintf(nm, sizeof nm, "%s.qkv", tag);
+        GemmArgs a = gemm_args(ly.qkv, qin, D, R, dl.row_pos, b.qkv, 3 * D);
+        a.Rp = dl.dims; a.regime_rows = regime_rows; a.Xp = qinp;
+        const bool fused_split = pl && D % kB16BN == 0;
+        if (fused_split) {
+            a.Y = nullptr; a.qk_hi = b.qkh; a.qk_lo = b.qkl; a.vt_hi = b.vth; a.vt_lo = b.vtl; a.att_D = D; a.Rvt = L.Rpad;
+            a.q_scale = 1.4426950408889634f / sqrtf((float)(D / heads));
+        }
+        if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
+        snprintf(nm, sizeof nm, "%s.attn", tag);
+        if (!pl) rc = launch_attention(h, s, nm, b.qkv, b.ctx, D, heads, dl, L.nwork(), mask_q, att_flops);
+        else rc = launch_attention_b16(h, s, nm, fused_split ? nullptr : b.qkv, nullptr, D, heads, R, L.Rpad, dl, L.nwork(), mask_q, att_flops, prec, b.qkh, b.qkl, b.vth, b.vtl, ctxp);
+        if (rc) return rc;
+        if (cat) {
+            // a = linear_out(context) (no residual), then x1 = x0 + xq . Wc_x^T + bc, then x1 += a . Wc_a^T (+ LayerNorm when post-LN)
+            float* att = b.qkv; void* attp = pl ? (void*)b.qkh : nullptr;       // both free once the attention kernel has run
+            snprintf(nm, sizeof nm, "%s.out", tag);
+            a = gemm_args(ly.out, b.ctx, D, R, dl.row_pos, pl ? nullptr : att, D);
+            a.Rp = dl.dims; a.regime_rows = regime_rows;
+            if (pl) { a.Xp = ctxp; a.Yp = attp; a.yp_chunks = D / 32; }
+            if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
+            snprintf(nm, sizeof nm, "%s.cat_x", tag);
+            a = gemm_args(ly.cat_x, qin, D, R, dl.row_pos, b.x1, D);
+            a.Rp = dl.dims; a.regime_rows = regime_rows; a.Xp = qinp; a.resid = b.x0; a.ldr = D;
+            if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
+            snprintf(nm, sizeof nm, "%s.cat_a", tag);
+            a = gemm_args(ly.cat_a, att, D, R, dl.row_pos, b.x1, D);
+            a.Rp = dl.dims; a.regime_rows = regime_rows; a.Xp = attp; a.resid = b.x1; a.ldr = D;      // in place: every element is read, then written, by one lane
+            if (!pre) { a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f; if (pl) { a.Yp = b.x1p; a.yp_chunks = D / 32; } }
+            if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
+        } else {
+            snprintf(nm, sizeof nm, "%s.out", tag);
+            a = gemm_args(ly.out, b.ctx, D, R, dl.row_pos, b.x1, D);
+            a.Rp = dl.dims; a.regime_rows = regime_rows; a.resid = b.x0; a.ldr = D;
+            if (pl) a.Xp = ctxp;
+            if (!pre) { a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f; if (pl) { a.Yp = b.x1p; a.yp_chunks = D / 32; } }
+            if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
+        }
+        const float* fin = b.x1; const void* finp = pl ? b.x1p : nullptr;
+        if (pre) {
+            snprintf(nm, sizeof nm, "%s.ln2", tag);
+            if ((rc = launch_ln(h, s, nm, b.x1, D, R, D, dl.row_pos, ly.ln2g, ly.ln2b, 1e-5f, pl ? nullptr : b.qkv, pl ? b.xps : nullptr))) return rc;
+            fin = b.qkv; finp = pl ? b.xps : nullptr;
+        }
+        snprintf(nm, sizeof nm, "%s.ffn1", tag);
+        a = gemm_args(ly.w1, fin, D, R, dl.row_pos, pl ? nullptr : b.hid, ly.w1.N);
+        a.Rp = dl.dims; a.regime_rows = regime_rows; a.act_post = 1; a.Xp = finp;
+        if (pl) { a.Yp = hidp; a.yp_chunks = round_up(ly.w1.N, 32) / 32; }
+        if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
+        snprintf(nm, sizeof nm, "%s.ffn2", tag);
+        a = gemm_args(ly.w2, b.hid, ly.w1.N, R, dl.row_pos, b.x0, D);
+        a.Rp = dl.dims; a.regime_rows = regime_rows; a.resid = b.x1; a.ldr = D;
+        if (pl) a.Xp = hidp;
+        if (!pre) { a.ln_g = ly.ln2g; a.ln_b = ly.ln2b; a.ln_eps = 1e-5f; if (pl) { a.Yp = b.x0p; a.yp_chunks = D / 32; } }
+        if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
+    }
+    if (pre) {      // Encoder.forward: xs = after_norm(xs); downstream consumers read x0 (fp32) and, in the bf16 modes, its planes
+        snprintf(nm, sizeof nm, "%s.after_norm", tag);
+        if ((rc = launch_ln(h, s, nm, b.x0, D, R, D, dl.row_pos, st.after_g, st.after_b, 1e-5f, b.x0, pl ? b.x0p : nullptr))) return rc;
     }
     return FS2_OK;
 }
@@ -721,8 +832,9 @@ struct Loader {
         return p;
     }
     // parts: weights stacked along N (q|k|v); each [n_i, C, k] (k omitted for Linear)
+    // col_off / src_cols: take columns [col_off, col_off + C) of a Linear weight stored [Neach, src_cols] (concat_linear halves)
     Gemm gemm(std::vector<std::string> wnames, std::vector<std::string> bnames, int Neach, int C, int k, bool linear,
-              const std::string& bn_prefix = "", bool f16_image = false) {
+              const std::string& bn_prefix = "", bool f16_image = false, int col_off = 0, int src_cols = 0) {
         Gemm g;
         const int parts = (int)wnames.size();
         g.N = Neach * parts; g.C = C; g.ktaps = k; g.Cpad = round_up(C, kBK);
@@ -754,19 +866,20 @@ struct Loader {
             hipMemsetAsync(pf, 0, wb_elems * 2, s);
         }
         for (int p = 0; p < parts; ++p) {
-            const fs2_tensor_desc* d = linear ? get(wnames[p], {Neach, C}) : get(wnames[p], {Neach, C, k});
+            const fs2_tensor_desc* d = src_cols ? get(wnames[p], {Neach, src_cols}) : (linear ? get(wnames[p], {Neach, C}) : get(wnames[p], {Neach, C, k}));
             if (!d) return g;
+            const float* wsrc = (const float*)d->data + col_off;
             {
                 const int64_t tb = (int64_t)Neach * k * nchunks * 32;
-                hipLaunchKernelGGL(repack_weight_bf16, dim3((unsigned)((tb + 255) / 256)), dim3(256), 0, s, (const float*)d->data, Neach, C, k,
-                                   Neach, nchunks, bg, bv, 1e-5f, reinterpret_cast<__bf16*>(g.wb) + (size_t)p * Neach * k * nchunks * 64, 0);
+                hipLaunchKernelGGL(repack_weight_bf16, dim3((unsigned)((tb + 255) / 256)), dim3(256), 0, s, wsrc, Neach, C, k,
+                                   Neach, nchunks, bg, bv, 1e-5f, reinterpret_cast<__bf16*>(g.wb) + (size_t)p * Neach * k * nchunks * 64, 0, src_cols);
                 if (g.wf)
-                    hipLaunchKernelGGL(repack_weight_bf16, dim3((unsigned)((tb + 255) / 256)), dim3(256), 0, s, (const float*)d->data, Neach, C, k,
-                                       Neach, nchunks, bg, bv, 1e-5f, reinterpret_cast<__bf16*>(g.wf) + (size_t)p * Neach * k * nchunks * 64, 1);
+                    hipLaunchKernelGGL(repack_weight_bf16, dim3((unsigned)((tb + 255) / 256)), dim3(256), 0, s, wsrc, Neach, C, k,
+                                       Neach, nchunks, bg, bv, 1e-5f, reinterpret_cast<__bf16*>(g.wf) + (size_t)p * Neach * k * nchunks * 64, 1, src_cols);
             }
             const int64_t total = (int64_t)Neach * k * g.Cpad;
-            hipLaunchKernelGGL(repack_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)d->data, Neach, C, k,
-                               Neach, g.Cpad, bg, bv, 1e-5f, g.w + (size_t)p * Neach * k * g.Cpad);
+            hipLaunchKernelGGL(repack_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wsrc, Neach, C, k,
+                               Neach, g.Cpad, bg, bv, 1e-5f, g.w + (size_t)p * Neach * k * g.Cpad, src_cols);
         }
         if (!bnames.empty()) {
             g.bias = dalloc(g.N);
@@ -786,8 +899,10 @@ struct Loader {
 };
 
 void load_stack(Loader& L, Stack& st, const std::string& pre, int nlayers, int D, int units, int k, const std::string& pe_pre,
-                bool scaled) {
+                bool scaled, bool pre_ln, bool concat) {
     st.layers.resize(nlayers);
+    st.pre_ln = pre_ln; st.concat = concat;
+    if (pre_ln) { st.after_g = L.copy(pre + ".after_norm.weight", {D}); st.after_b = L.copy(pre + ".after_norm.bias", {D}); }
     for (int i = 0; i < nlayers; ++i) {
         const std::string p = pre + ".encoders_." + std::to_string(i);
         Layer& ly = st.layers[i];
@@ -799,6 +914,10 @@ void load_stack(Loader& L, Stack& st, const std::string& pre, int nlayers, int D
         {
             const bool lin2 = L.m.count(p + ".feed_forward.w_2.weight") && L.m[p + ".feed_forward.w_2.weight"]->ndim == 2;
             ly.w2 = L.gemm({p + ".feed_forward.w_2.weight"}, {p + ".feed_forward.w_2.bias"}, D, units, 1, lin2);
+        }
+        if (concat) {
+            ly.cat_x = L.gemm({p + ".concat_linear.weight"}, {p + ".concat_linear.bias"}, D, D, 1, true, "", false, /*col_off=*/0, /*src_cols=*/2 * D);
+            ly.cat_a = L.gemm({p + ".concat_linear.weight"}, {}, D, D, 1, true, "", false, /*col_off=*/D, /*src_cols=*/2 * D);
         }
         ly.ln1g = L.copy(p + ".norm1.weight", {D}); ly.ln1b = L.copy(p + ".norm1.bias", {D});
         ly.ln2g = L.copy(p + ".norm2.weight", {D}); ly.ln2b = L.copy(p + ".norm2.bias", {D});
@@ -1014,9 +1133,10 @@ int fs2_load_weights(fs2_handle* h, const fs2_tensor_desc* t, int32_t n, void* s
     for (int i = 0; i < n; ++i) if (t[i].name) L.m[t[i].name] = &t[i];
 
     h->enc_embed = L.copy("encoder.embed.0.weight", {c.idim, c.adim});
-    load_stack(L, h->enc, "encoder", c.elayers, c.adim, c.eunits, c.ffn_kernel, "encoder.embed.1", c.use_scaled_pos_enc);
+    load_stack(L, h->enc, "encoder", c.elayers, c.adim, c.eunits, c.ffn_kernel, "encoder.embed.1", c.use_scaled_pos_enc,
+               c.enc_normalize_before != 0, c.enc_concat_after != 0);
     load_stack(L, h->dec, "decoder", c.dlayers, c.ddim, c.dunits, c.ffn_kernel, c.decoder_input_layer ? "decoder.embed.4" : "decoder.embed.0",
-               c.use_scaled_pos_enc);
+               c.use_scaled_pos_enc, c.dec_normalize_before != 0, c.dec_concat_after != 0);
     load_predictor(L, h->dur, "duration_predictor", c.dur_layers, c.adim, c.dur_chans, c.dur_kernel);
     load_predictor(L, h->energy, "energy_predictor.predictor", c.var_layers, c.adim, c.var_chans, c.var_kernel);
     load_predictor(L, h->pitch, "pitch_predictor.predictor", c.var_layers, c.adim, c.var_chans, c.var_kernel);

@@ -119,9 +119,11 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
     if (row >= a.R) return;
     const int pos = a.row_pos ? a.row_pos[row] : 0;
     float* y = a.Y + (size_t)row * a.ldy;
+    const float* ysrc = a.Ysrc ? a.Ysrc + (size_t)row * a.ldsrc : y;      // out-of-place form (pre-LN blocks keep the un-normalised stream)
     const int pc = a.Yp ? a.yp_chunks * 32 : 0;      // channels of the output planes (>= N, zero padded)
     if (pos < 0) {
-        for (int c = lane * 4; c < a.N; c += 256) *reinterpret_cast<float4*>(y + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.Y)
+            for (int c = lane * 4; c < a.N; c += 256) *reinterpret_cast<float4*>(y + c) = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int c = lane * 4; c < pc; c += 256) store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{0.f, 0.f, 0.f, 0.f}, a.yp_f16 != 0);
         if (a.dot_w && lane == 0) a.dot_out[row] = 0.f;
         return;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = lane * 4 + j * 256;
-        v[j] = (c < a.N) ? *reinterpret_cast<const float4*>(y + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[j] = (c < a.N) ? *reinterpret_cast<const float4*>(ysrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < a.N)
             for (int z = 1; z < a.ksplit; ++z) {      // split-K partials of the GEMM, added in a fixed order
                 const float4 q = *reinterpret_cast<const float4*>(a.kpart + (size_t)(z - 1) * a.kpart_stride + (size_t)row * a.ldy + c);
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
                 const float4 w = *reinterpret_cast<const float4*>(a.dot_w + c);
                 d += (t.x * w.x + t.y * w.y) + (t.z * w.z + t.w * w.w);
             }
-            *reinterpret_cast<float4*>(y + c) = t;
+            if (a.Y) *reinterpret_cast<float4*>(y + c) = t;
             if (a.Yp) store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{t.x, t.y, t.z, t.w}, a.yp_f16 != 0);
         } else if (c < pc) {
             store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{0.f, 0.f, 0.f, 0.f}, a.yp_f16 != 0);
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
 // weights [N][C][k] fp32 -> split bf16 LDS image [Npad][nchunks][k][hi 32 | lo 32]; optional BatchNorm fold.
 // f16 != 0: the same image in _Float16 (fp16 hi + fp16 lo), the operand of the two- / one-term FFN arithmetic.
 __global__ void repack_weight_bf16(const float* w, int N, int C, int k, int Npad, int nchunks, const float* bn_g,
-                                   const float* bn_v, float bn_eps, __bf16* out, int f16 = 0) {
+                                   const float* bn_v, float bn_eps, __bf16* out, int f16 = 0, int ldw = 0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)Npad * k * nchunks * 32;
     if (i >= total) return;
@@ -213,7 +215,7 @@ __global__ void repack_weight_bf16(const float* w, int N, int C, int k, int Npad
     const int c = chunk * 32 + kperm(kk);
     float v = 0.f;
     if (n < N && c < C) {
-        v = w[((size_t)n * C + c) * k + tap];
+        v = w[((size_t)n * (ldw ? ldw : C) + c) * k + tap];
         if (bn_g) v *= bn_g[n] / sqrtf(bn_v[n] + bn_eps);
     }
     const size_t base = (((size_t)n * nchunks + chunk) * k + tap) * 64;     // k-step order: it = chunk * k + tap

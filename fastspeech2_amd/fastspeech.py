@@ -233,8 +233,6 @@ class FeedForwardTransformer(nn.Module):
         self.use_scaled_pos_enc = bool(m.use_scaled_pos_enc)
         self.use_masking = bool(m.use_masking)
         self.use_weighted_masking = bool(m.use_weighted_masking)
-        if m.encoder_normalize_before or m.decoder_normalize_before or m.encoder_concat_after or m.decoder_concat_after:
-            raise NotImplementedError("only post-LN FFT blocks without concat_after (the reference default) are implemented")
         if m.positionwise_layer_type not in ("conv1d", "linear"):
             raise NotImplementedError("Support only linear or conv1d.")
         if m.reduction_factor != 1:
@@ -248,7 +246,9 @@ class FeedForwardTransformer(nn.Module):
             dur_kernel=m.duration_predictor_kernel_size, var_layers=2, var_chans=256, var_kernel=3, n_bins=256,
             postnet_layers=m.postnet_layers, postnet_chans=m.postnet_chans, postnet_filts=m.postnet_filts,
             use_batch_norm=int(bool(m.use_batch_norm)), use_scaled_pos_enc=int(self.use_scaled_pos_enc),
-            reduction_factor=m.reduction_factor, decoder_input_layer=0 if _script_twin else 1)
+            reduction_factor=m.reduction_factor, decoder_input_layer=0 if _script_twin else 1,
+            enc_normalize_before=int(bool(m.encoder_normalize_before)), dec_normalize_before=int(bool(m.decoder_normalize_before)),
+            enc_concat_after=int(bool(m.encoder_concat_after)), dec_concat_after=int(bool(m.decoder_concat_after)))
 
         enc_embed = nn.Sequential(nn.Embedding(idim, m.adim, padding_idx=0), _PositionalTable(m.adim, self.use_scaled_pos_enc))
         self.encoder = _FFTStack(enc_embed, m.adim, m.eunits, m.elayers, kernel, conv)
@@ -335,9 +335,7 @@ class FeedForwardTransformer(nn.Module):
         self.decoder.embed[-1].ensure(max(need_frames, 1))
         if self._handle is None or self._handle_device != device:
             self._drop_handle()
-            cfg = _lib.Config(**{k: v for k, v in self._cfg.items() if k != 'decoder_input_layer'},
-                              device=device.index if device.index is not None else torch.cuda.current_device(),
-                              decoder_input_layer=self._cfg['decoder_input_layer'])
+            cfg = _lib.Config(**self._cfg, device=device.index if device.index is not None else torch.cuda.current_device())
             h = C.c_void_p()
             with torch.cuda.device(device):      # (the library also restores the caller's current device itself)
                 _lib.check(L.fs2_create(C.byref(cfg), C.byref(h)))

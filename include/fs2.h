@@ -69,6 +69,9 @@ typedef struct fs2_config {
     int32_t decoder_input_layer;        /* 1: Linear -> LN -> ReLU -> +pe (fastspeech.py:120-135, encoder.py:118-125);
                                            0: +pe only (the TorchScript twin, utils/fastspeech2_script.py:112-127;
                                            needs ddim == adim)                                */
+    /* FFT-block variants (reference core/encoder.py:53-71,201-202; hp.model.{encoder,decoder}_{normalize_before,concat_after}) */
+    int32_t enc_normalize_before, dec_normalize_before;   /* LayerNorm in front of the sub-layers + after_norm at the end */
+    int32_t enc_concat_after, dec_concat_after;           /* x + concat_linear(cat(x, self_attn(x))) instead of x + self_attn(x) */
 } fs2_config;
 
 /* One reference-layout tensor (state_dict entry), fp32, resident on the device. */

@@ -33,6 +33,8 @@ def config_from_hp(hp, idim, odim, script_twin=False):
         postnet_layers=m.postnet_layers, use_batch_norm=bool(m.use_batch_norm),
         use_scaled_pos_enc=bool(m.use_scaled_pos_enc), reduction_factor=m.reduction_factor,
         dur_layers=m.duration_predictor_layers, var_layers=2,
+        enc_pre_ln=bool(m.encoder_normalize_before), dec_pre_ln=bool(m.decoder_normalize_before),
+        enc_concat=bool(m.encoder_concat_after), dec_concat=bool(m.decoder_concat_after),
     )
 
 
@@ -90,15 +92,30 @@ def _ffn(sd, p, x, cfg):
     return F.conv1d(h, w2, b2).transpose(1, 2)
 
 
-def _fft_stack(sd, prefix, x, mask, nlayers, heads, cfg):
-    """post-LN FFT blocks, reference core/encoder.py:46-71 (normalize_before=False)."""
+def _fft_stack(sd, prefix, x, mask, nlayers, heads, cfg, pre_ln=False, concat=False):
+    """FFT blocks, reference core/encoder.py:46-71 (default: post-LN, no concat_after) and the stack's after_norm (:201-202)."""
+    D = x.shape[-1]
+    ln = lambda t, name: F.layer_norm(t, (D,), sd[name + ".weight"], sd[name + ".bias"], 1e-5)
     for i in range(nlayers):
         p = "%s.encoders_.%d" % (prefix, i)
-        D = x.shape[-1]
-        x = F.layer_norm(x + _mha(sd, p + ".self_attn", x, mask, heads), (D,),
-                         sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5)
-        x = F.layer_norm(x + _ffn(sd, p + ".feed_forward", x, cfg), (D,),
-                         sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+        residual = x
+        if pre_ln:
+            x = ln(x, p + ".norm1")
+        att = _mha(sd, p + ".self_attn", x, mask, heads)
+        if concat:
+            x = residual + F.linear(torch.cat((x, att), dim=-1), sd[p + ".concat_linear.weight"], sd[p + ".concat_linear.bias"])
+        else:
+            x = residual + att
+        if not pre_ln:
+            x = ln(x, p + ".norm1")
+        residual = x
+        if pre_ln:
+            x = ln(x, p + ".norm2")
+        x = residual + _ffn(sd, p + ".feed_forward", x, cfg)
+        if not pre_ln:
+            x = ln(x, p + ".norm2")
+    if pre_ln:
+        x = ln(x, prefix + ".after_norm")
     return x
 
 
@@ -186,7 +203,7 @@ def padded_forward(sd, cfg, xs, ilens, olens=None, ds=None, es=None, ps=None, is
     x_mask = valid.unsqueeze(-2) & valid.unsqueeze(-1)
     h = F.embedding(xs, sd["encoder.embed.0.weight"])
     h = _add_pos(sd, "encoder.embed.1", h, cfg)
-    hs = _fft_stack(sd, "encoder", h, x_mask, cfg["elayers"], heads, cfg)
+    hs = _fft_stack(sd, "encoder", h, x_mask, cfg["elayers"], heads, cfg, cfg.get("enc_pre_ln", False), cfg.get("enc_concat", False))
     out = {"encoder_out": hs}
     d_pad = ~valid
     dlog = _predictor(sd, "duration_predictor", hs, cfg["dur_layers"])
@@ -224,7 +241,7 @@ def padded_forward(sd, cfg, xs, ilens, olens=None, ds=None, es=None, ps=None, is
         z = _add_pos(sd, "decoder.embed.4", torch.relu(z), cfg)
     else:   # utils/fastspeech2_script.py:112-127: input_layer=None -> embed = Sequential(pos_enc)
         z = _add_pos(sd, "decoder.embed.0", hs_f, cfg)
-    z = _fft_stack(sd, "decoder", z, h_mask, cfg["dlayers"], heads, cfg)
+    z = _fft_stack(sd, "decoder", z, h_mask, cfg["dlayers"], heads, cfg, cfg.get("dec_pre_ln", False), cfg.get("dec_concat", False))
     out["decoder_out"] = z
     before = F.linear(z, sd["feat_out.weight"], sd["feat_out.bias"]).view(B, -1, cfg["odim"])
     if cfg["postnet_layers"] > 0:

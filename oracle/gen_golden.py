@@ -210,10 +210,65 @@ def main():
         print("  %-32s %7.1f KB" % (f, os.path.getsize(os.path.join(out_dir, f)) / 1024))
 
 
+BLOCK_VARIANTS = {
+    "pre_ln": dict(encoder_normalize_before=True, decoder_normalize_before=True),
+    "concat_after": dict(encoder_concat_after=True, decoder_concat_after=True),
+    "pre_ln_concat": dict(encoder_normalize_before=True, decoder_normalize_before=True, encoder_concat_after=True, decoder_concat_after=True),
+    "enc_pre_ln_dec_concat": dict(encoder_normalize_before=True, decoder_concat_after=True),
+}
+
+
+def block_variants():
+    """G7: the non-default FFT-block variants of the reference (core/encoder.py:53-71,201-202: normalize_before, concat_after), real
+    reference run on a small teacher-forced batch per variant; also checks the oracle against each."""
+    from fastspeech2_amd.synthetic import portable_state_dict
+    from oracle import fs2_oracle as O
+    hp, idim, Ref = import_reference()
+    odim = hp.audio.num_mels
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    b = small_batch(17, [19, 9], 7)
+    arrays = dict(xs=b["xs"].numpy(), ilens=b["ilens"].numpy(), olens=b["olens"].numpy(), ds=b["ds"].numpy(), es=b["es"].numpy(), ps=b["ps"].numpy(),
+                  names=np.array(sorted(BLOCK_VARIANTS)))
+    worst = 0.0
+    for name in sorted(BLOCK_VARIANTS):
+        for k, v in BLOCK_VARIANTS[name].items():
+            setattr(hp.model, k, v)
+        torch.manual_seed(0)
+        ref = Ref(idim, odim, hp).eval()
+        sd = portable_state_dict(ref.state_dict(), seed=21)
+        ref.load_state_dict(sd)
+        cfg = O.config_from_hp(hp, idim, odim)
+        with torch.no_grad():
+            outs = []
+            for i in range(2):          # one utterance at a time: per-utterance semantics (what the HIP path computes by default)
+                T, L = int(b["ilens"][i]), int(b["olens"][i])
+                r = ref._forward(b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], b["olens"][i:i + 1], b["ds"][i:i + 1, :T].clone(),
+                                 b["es"][i:i + 1, :L], b["ps"][i:i + 1, :L], is_inference=False)
+                outs.append(r)
+                arrays["%s_after_%d" % (name, i)] = r[1][0].numpy()
+                arrays["%s_before_%d" % (name, i)] = r[0][0].numpy()
+                arrays["%s_d_outs_%d" % (name, i)] = r[2][0].numpy()
+        o = O.per_utterance_forward(sd, cfg, b["xs"], b["ilens"], b["ds"], b["es"], b["ps"])
+        for i in range(2):
+            L = int(b["olens"][i])
+            d = float((o["after"][i, :L] - outs[i][1][0]).abs().max())
+            worst = max(worst, d)
+            print("G7 %-22s utterance %d (L=%d): oracle vs reference mel max-abs %.3e" % (name, i, L, d))
+        for k in BLOCK_VARIANTS[name]:
+            setattr(hp.model, k, False)
+    np.savez_compressed(os.path.join(out_dir, "g7_block_variants_b2.npz"), **arrays)
+    assert worst < 2e-5, "oracle restatement of the block variants drifted from the reference"
+    print("G7 written; worst %.3e" % worst)
+
+
 def math_log(v):
     import math
     return math.log(v)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g7":
+        block_variants()          # only the block-variant fixture (leaves G1-G6 untouched)
+    else:
+        main()
+        block_variants()

@@ -99,10 +99,13 @@ def test_cpu_inputs_raise_not_fallback():
 def test_unsupported_configs_raise():
     from fastspeech2_amd import FeedForwardTransformer
     _, hp = _model()
-    hp.model.encoder_normalize_before = True
+    hp.model.reduction_factor = 2
     with pytest.raises(NotImplementedError):
         FeedForwardTransformer(68, 80, hp)
-    hp.model.encoder_normalize_before = False
+    hp.model.reduction_factor = 1
+    hp.model.encoder_normalize_before = True          # pre-LN / concat_after blocks are implemented (fixture G7)
+    hp.model.decoder_concat_after = True
+    assert FeedForwardTransformer(68, 80, hp)._cfg["enc_normalize_before"] == 1
     hp.model.positionwise_layer_type = "conv2d"
     with pytest.raises(NotImplementedError):
         FeedForwardTransformer(68, 80, hp)

@@ -654,6 +654,35 @@ def test_config_variants_vs_oracle(name, precision):
         assert _maxabs(mel, oi["after"][0]) <= MEL_TOL
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("name", ["pre_ln", "concat_after", "pre_ln_concat", "enc_pre_ln_dec_concat"])
+def test_g7_block_variants_on_device(name, precision, golden_dir):
+    """The non-default FFT-block variants of the reference (hp.model.{encoder,decoder}_{normalize_before,concat_after},
+    core/encoder.py:53-71,201-202) on the HIP path against the REAL reference's outputs (fixture G7), both parity modes; plus a
+    free-running single-utterance call against the oracle."""
+    from tests.test_oracle_golden import variant_setup
+    from oracle import fs2_oracle as O
+    g = np.load(golden_dir + "/g7_block_variants_b2.npz")
+    hp, model, sd, cfg = variant_setup(name)
+    model.load_state_dict(sd)
+    model = model.to("cuda:0")
+    model.precision = precision
+    with torch.no_grad():
+        before, after, d_outs, _, _ = model._forward(_t(g["xs"]), _t(g["ilens"]), _t(g["olens"]), _t(g["ds"]), _t(g["es"]), _t(g["ps"]))
+        x = _t(g["xs"])[0, : int(g["ilens"][0])]
+        mel = model.inference(x)
+    worst = 0.0
+    for i in range(2):
+        L, T = int(g["olens"][i]), int(g["ilens"][i])
+        worst = max(worst, _maxabs(after[i, :L], g["%s_after_%d" % (name, i)]), _maxabs(before[i, :L], g["%s_before_%d" % (name, i)]),
+                    _maxabs(d_outs[i, :T], g["%s_d_outs_%d" % (name, i)]))
+    print("G7 %s [%s] max-abs vs the reference %.2e" % (name, precision, worst))
+    assert worst <= MEL_TOL
+    oi = O.padded_forward(sd, cfg, torch.from_numpy(g["xs"][:1, : int(g["ilens"][0])]), torch.from_numpy(g["ilens"][:1]), is_inference=True)
+    if precision == "fp32":
+        assert mel.shape == tuple(oi["after"][0].shape) and _maxabs(mel, oi["after"][0]) <= MEL_TOL
+
+
 def test_packed_output_and_unpack_kernel(env):
     """`after_packed` (valid frames back to back, what the multi-GPU all-gather ships) and its inverse
     fs2_op_unpack_rows reproduce the padded output bit-for-bit."""
