@@ -361,6 +361,32 @@ def test_hip_graph_replay_of_the_forward(env):
         model.precision = "fp32"
 
 
+def test_graph_refuses_to_run_after_a_weight_reload_and_async_ring_wraps(env):
+    """(1) A captured graph holds pointers into the library's weight copies: after the weights were re-uploaded `run` must raise instead
+    of replaying onto released memory.  (2) More asynchronous calls in flight than pinned slots (16): the ring waits for and folds the
+    oldest; every result stays valid and bit-identical."""
+    model, sd, cfg, O = env
+    from fastspeech2_amd import _lib
+    from fastspeech2_amd.synthetic import make_batch
+    b = make_batch("c3", B=3)
+    xs, il, ds = b["xs"].cuda(), b["ilens"], b["ds"].cuda()
+    with torch.no_grad():
+        run = model.capture_graph(xs, il, d_override=ds)
+        mel, _, status = run(xs)
+        assert int(status.cpu()[2]) == 0
+        model.load_state_dict(sd)                       # same values, new upload: device copies are re-allocated
+        model.inference_batch(xs, il, d_override=ds)    # (triggers the upload)
+        with pytest.raises(RuntimeError, match="capture"):
+            run(xs)
+        ref, ol = model.inference_batch(xs, il, d_override=ds)
+        outs = [model.inference_batch(xs, il, d_override=ds, sync=False) for _ in range(40)]
+        assert model.async_ok()
+        for o in outs[::7] + outs[-1:]:
+            assert o.ok() and torch.equal(o[0][:, : ref.shape[1]], ref) and torch.equal(o[1].cpu(), ol)
+    with pytest.raises(_lib.Fs2Error):
+        _lib.set_option("FS2_NO_SUCH_SWITCH", 1)
+
+
 def test_reference_smoke_shape(env):
     """Counterpart of the reference's only test (tests/test_fastspeech2.py:7-20): B=2, T=L=100, all ones,
     through forward(); here in eval mode, asserting what the reference merely runs."""
