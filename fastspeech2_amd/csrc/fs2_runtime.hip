@@ -22,6 +22,7 @@
 #include "elementwise.h"
 #include "gemm_bf16.h"
 #include "gemm_planes.h"
+#include "gemm_mx.h"
 #include "gemm_f32.h"
 
 using namespace fs2;
@@ -34,6 +35,8 @@ struct Gemm {          // one repacked Linear / Conv1d
     float* w = nullptr;      // [Npad][ktaps][Cpad]
     void* wb = nullptr;      // split-bf16 image [Npad][ktaps][Cpad/32][hi 32 | lo 32]
     void* wf = nullptr;      // the same image in fp16 (FFN w_1 only): operand of the two- / one-term arithmetic modes
+    void* w8 = nullptr;      // fp8 correction image of the "mx" mode (gemm_mx.h; 9-tap FFN w_1 only) ...
+    int kw = 0;              // ... and the exponent of its static scale: |w| 2^kw <= 448
     float* bias = nullptr;   // [N] or null
     int N = 0, C = 0, Cpad = 0, ktaps = 1;
 };
@@ -41,6 +44,8 @@ struct Layer {
     Gemm qkv, out, w1, w2;
     Gemm cat_x, cat_a;       // concat_after: concat_linear [D, 2D] split into its x half (carries the bias) and its attention half
     float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+    int ka = 0;              // "mx" mode: exponent of the static scale of the FFN input (the LN1 output): |x| 2^ka <= 448 from the bound
+                             // |LN(x)_c| <= sqrt(D) |gamma_c| + |beta_c|
 };
 struct Predictor {
     std::vector<Gemm> conv;
@@ -85,8 +90,28 @@ Options& opts() {
 }
 
 // Mixed modes: everything as bf16x3 except the FFN convolution w_1, which runs on fp16 operands with 2 or 1 MFMA per fragment pair.
-inline int base_precision(int p) { return (p == FS2_PREC_MIX_F16X2 || p == FS2_PREC_MIX_F16X1) ? FS2_PREC_BF16X3 : p; }
-inline int ffn_f16_terms(int p) { return p == FS2_PREC_MIX_F16X2 ? 2 : (p == FS2_PREC_MIX_F16X1 ? 1 : 0); }
+inline int base_precision(int p) { return (p == FS2_PREC_MIX_F16X2 || p == FS2_PREC_MIX_F16X1 || p == FS2_PREC_MIX_MX) ? FS2_PREC_BF16X3 : p; }
+constexpr int kFfnMx = 9;      // value of "ffn_terms" that selects the fp16 + block-scaled-fp8 arithmetic (gemm_mx.h)
+inline int ffn_f16_terms(int p) { return p == FS2_PREC_MIX_F16X2 ? 2 : (p == FS2_PREC_MIX_F16X1 ? 1 : (p == FS2_PREC_MIX_MX ? kFfnMx : 0)); }
+inline int scale_byte4(int e) { const int b = std::min(std::max(e, 1), 254); return b * 0x01010101; }
+
+// max |x| of a device array (weight-load time only: one small launch + a blocking 4-byte read-back)
+__global__ void absmax_kernel(const float* x, int64_t n, unsigned* out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+float device_absmax(hipStream_t s, const float* x, int64_t n, unsigned* scratch) {
+    hipMemsetAsync(scratch, 0, 4, s);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0, s, x, n, scratch);
+    unsigned bits = 0;
+    hipMemcpyAsync(&bits, scratch, 4, hipMemcpyDeviceToHost, s);
+    hipStreamSynchronize(s);
+    float f; memcpy(&f, &bits, 4);
+    return f;
+}
+inline int fp8_scale_exponent(float bound) { return bound > 0.f ? (int)std::floor(std::log2(448.0 / (double)bound)) : 0; }
 
 // Every entry point that takes a handle runs on the handle's device and leaves the caller's current device as it found it.
 struct DeviceGuard {
@@ -297,6 +322,24 @@ hipError_t launch_pl(hipStream_t s, const GemmArgs& a) {
     return bm == 128 ? launch_pl_t<NSPLIT, 128, false>(s, a) : launch_pl_t<NSPLIT, 64, false>(s, a);
 }
 
+// fp16 + block-scaled-fp8 form of the 9-tap conv (gemm_mx.h)
+template <int BM>
+hipError_t launch_mx_t(hipStream_t s, const GemmArgs& a) {
+    static LdsAttr attr;
+    constexpr size_t lds = pl_lds_bytes<BM, false>();
+    allow_lds(reinterpret_cast<const void*>(&gemm_mx_conv9<BM>), lds, attr);
+    dim3 grid((a.N + kB16BN - 1) / kB16BN, (a.R + BM - 1) / BM, 1);
+    hipLaunchKernelGGL((gemm_mx_conv9<BM>), grid, dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_mx(hipStream_t s, const GemmArgs& a) {
+    // 128-row tiles at most: the 256-row instantiation needs > 512 VGPRs (measured: 758 spilled, 7x slower)
+    const int force = opts().bm > 0 ? opts().bm : 0;
+    const long nN = (a.N + kB16BN - 1) / kB16BN;
+    const int bm = force ? (force >= 128 ? 128 : 64) : (nN * ((a.R + 127) / 128) >= 400 ? 128 : 64);
+    return bm == 128 ? launch_mx_t<128>(s, a) : launch_mx_t<64>(s, a);
+}
+
 // fp16-operand form of the conv kernel (FFN w_1 in the mixed modes): NSPLIT MFMAs per fragment pair
 template <int NSPLIT>
 hipError_t launch_pl_f16(hipStream_t s, const GemmArgs& a) {
@@ -341,7 +384,7 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         t.ksplit = 1;
         size_t y_slab = 0;       // 1: Y lives in the first slab of kpart (no fp32 output buffer of the caller's)
         const long rr = a.regime_rows ? a.regime_rows : a.R;
-        if (!row8 && !a.qk_hi && a.kpart && !opts().nosplitk && a.N <= 1024 && rr <= kSplitRegime && a.R <= kSplitRows) {
+        if (!row8 && !a.qk_hi && !a.mx && a.kpart && !opts().nosplitk && a.N <= 1024 && rr <= kSplitRegime && a.R <= kSplitRows) {
             const int nchunks = a.Cpad / 32;
             const long wgs = (long)((a.N + kB16BN - 1) / kB16BN) * ((rr + 63) / 64);
             const bool own_y = t.Y != nullptr;
@@ -359,18 +402,22 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
             t.kpart = a.kpart + y_slab * (size_t)a.R * a.N;
             t.kpart_stride = (size_t)a.R * t.ldy;
         }
-        if (a.f16_terms && (a.ktaps == 1 || need_rows || a.qk_hi)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: the fp16 arithmetic exists for plain convolutions only", name);
+        if ((a.f16_terms || a.mx) && (a.ktaps == 1 || need_rows || a.qk_hi)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: the fp16 arithmetic exists for plain convolutions only", name);
+        if (a.mx && (a.ktaps != kMxTaps || !a.W8 || a.N % 128 != 0)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: the mx arithmetic needs a 9-tap convolution with N %% 128 == 0 and its fp8 image", name);
+
         if (!a.Xp) {
             char nm[112];
             snprintf(nm, sizeof nm, "%s.planes", name);
             Scope sc(h, s, nm, 0.0, 8.0 * a.R * a.Cpad);
             const int64_t n = (int64_t)a.R * (a.Cpad / 4);
-            hipLaunchKernelGGL(to_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.X, a.ldx, a.C, a.R, a.Cpad / 32, a.xp_scratch, a.f16_terms ? 1 : 0);
+            hipLaunchKernelGGL(to_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.X, a.ldx, a.C, a.R, a.Cpad / 32, a.xp_scratch, a.mx ? 2 : (a.f16_terms ? 1 : 0), a.yp_scale);
             t.Xp = a.xp_scratch;
         }
         {
             Scope sc(h, s, name, flops, bytes);
-            if (a.f16_terms) {
+            if (a.mx) {
+                e = launch_mx(s, t);
+            } else if (a.f16_terms) {
                 e = a.f16_terms == 3 ? launch_pl_f16<3>(s, t) : (a.f16_terms == 2 ? launch_pl_f16<2>(s, t) : launch_pl_f16<1>(s, t));
             } else if (use_qkv8(t)) {
                 if (a.att_D == 384) e = (precision == FS2_PREC_BF16X3) ? launch_qkv8_t<3, 3>(s, t) : launch_qkv8_t<1, 3>(s, t);
@@ -648,8 +695,9 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         a = gemm_args(ly.out, b.ctx, D, R, dl.row_pos, b.x1, D);
         a.Rp = dl.dims; a.regime_rows = regime_rows;
         a.resid = b.x0; a.ldr = D; a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
-        const int f16t = (pl && ffn_terms && ly.w1.ktaps > 1 && ly.w1.wf) ? ffn_terms : 0;      // this layer's FFN conv on fp16 operands?
-        if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; a.yp_f16 = f16t ? 1 : 0; }       // x1p feeds only that conv
+        const bool mxl = pl && ffn_terms == kFfnMx && ly.w1.w8 && ly.w1.wf;                      // this layer's FFN conv in the mx arithmetic?
+        const int f16t = (pl && ffn_terms && ffn_terms != kFfnMx && ly.w1.ktaps > 1 && ly.w1.wf) ? ffn_terms : 0;      // ... or on fp16 operands?
+        if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; a.yp_f16 = mxl ? 2 : (f16t ? 1 : 0); a.yp_scale = mxl ? exp2f((float)ly.ka) : 1.f; }       // x1p feeds only that conv
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.ffn1", tag);
         a = gemm_args(ly.w1, b.x1, D, R, dl.row_pos, pl ? nullptr : b.hid, ly.w1.N);
@@ -657,6 +705,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         a.act_post = 1;
         if (pl) { a.Xp = b.x1p; a.Yp = hidp; a.yp_chunks = round_up(ly.w1.N, 32) / 32; }
         if (f16t) { a.f16_terms = f16t; a.Wb = ly.w1.wf; }
+        if (mxl) { a.mx = 1; a.Wb = ly.w1.wf; a.W8 = ly.w1.w8; a.mx_scale = scale_byte4(127 - ly.ka - 11); a.mx_scale_b = scale_byte4(127 - ly.w1.kw); }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.ffn2_ln", tag);
         a = gemm_args(ly.w2, b.hid, ly.w1.N, R, dl.row_pos, b.x0, D);
@@ -806,6 +855,8 @@ struct Loader {
     fs2_handle* h; hipStream_t s;
     std::map<std::string, const fs2_tensor_desc*> m;
     int rc = FS2_OK;
+    unsigned* absmax_scratch = nullptr;
+    ~Loader() { if (absmax_scratch) hipFree(absmax_scratch); }
     const fs2_tensor_desc* get(const std::string& name, std::initializer_list<int64_t> shape) {
         auto it = m.find(name);
         if (it == m.end()) { if (!rc) rc = fail(h, FS2_ERR_WEIGHT, "missing tensor %s", name.c_str()); return nullptr; }
@@ -857,6 +908,19 @@ struct Loader {
             h->allocs.push_back(pb);
             g.wb = pb;
             hipMemsetAsync(pb, 0, wb_elems * 2, s);
+        }
+        if (f16_image && k == kMxTaps && parts == 1 && !linear && g.N % 128 == 0) {      // "mx" mode: fp8 correction image (gemm_mx.h)
+            const fs2_tensor_desc* d = get(wnames[0], {Neach, C, k});
+            if (!d) return g;
+            if (!absmax_scratch && hipMalloc((void**)&absmax_scratch, 16) != hipSuccess) { if (!rc) rc = fail(h, FS2_ERR_HIP, "hipMalloc failed"); return g; }
+            g.kw = fp8_scale_exponent(device_absmax(s, (const float*)d->data, (int64_t)Neach * C * k, absmax_scratch));
+            const size_t bytes = mx_w8_bytes(Npad, nchunks);
+            void* p8 = nullptr;
+            if (hipMalloc(&p8, bytes) != hipSuccess) { if (!rc) rc = fail(h, FS2_ERR_HIP, "hipMalloc of fp8 weights failed"); return g; }
+            h->allocs.push_back(p8);
+            g.w8 = p8;
+            hipLaunchKernelGGL(repack_weight_mx8, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, s, (const float*)d->data, g.N, C, Npad, nchunks, g.kw,
+                               reinterpret_cast<unsigned char*>(p8));
         }
         if (f16_image) {
             void* pf = nullptr;
@@ -920,6 +984,10 @@ void load_stack(Loader& L, Stack& st, const std::string& pre, int nlayers, int D
             ly.cat_a = L.gemm({p + ".concat_linear.weight"}, {}, D, D, 1, true, "", false, /*col_off=*/D, /*src_cols=*/2 * D);
         }
         ly.ln1g = L.copy(p + ".norm1.weight", {D}); ly.ln1b = L.copy(p + ".norm1.bias", {D});
+        if (ly.w1.w8 && ly.ln1g && ly.ln1b && L.absmax_scratch) {      // a-priori bound of the LayerNorm output that feeds the FFN conv
+            const float gm = device_absmax(L.s, ly.ln1g, D, L.absmax_scratch), bm = device_absmax(L.s, ly.ln1b, D, L.absmax_scratch);
+            ly.ka = fp8_scale_exponent(std::sqrt((float)D) * gm + bm);
+        }
         ly.ln2g = L.copy(p + ".norm2.weight", {D}); ly.ln2b = L.copy(p + ".norm2.bias", {D});
     }
     auto it = L.m.find(pe_pre + ".pe");
@@ -954,7 +1022,7 @@ int check_batch(fs2_handle* h, const fs2_batch& b) {
     if (b.B <= 0 || b.Tmax <= 0 || !b.ilens) return fail(h, FS2_ERR_ARG, "batch: B=%d Tmax=%d ilens=%p", b.B, b.Tmax, (const void*)b.ilens);
     for (int i = 0; i < b.B; ++i)
         if (b.ilens[i] <= 0 || b.ilens[i] > b.Tmax) return fail(h, FS2_ERR_ARG, "ilens[%d]=%lld outside [1,%d]", i, (long long)b.ilens[i], b.Tmax);
-    if (b.precision < FS2_PREC_FP32 || b.precision > FS2_PREC_MIX_F16X1) return fail(h, FS2_ERR_ARG, "unknown precision mode %d", b.precision);
+    if (b.precision < FS2_PREC_FP32 || b.precision > FS2_PREC_MIX_MX) return fail(h, FS2_ERR_ARG, "unknown precision mode %d", b.precision);
     return FS2_OK;
 }
 
@@ -1475,8 +1543,9 @@ struct DevTmp {
 
 int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
     if (!o || !o->x || !o->w || o->R <= 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_conv_gemm: bad arguments");
-    if (o->precision < FS2_PREC_FP32 || o->precision > FS2_PREC_MIX_F16X1) return fail(nullptr, FS2_ERR_ARG, "unknown precision %d", o->precision);
-    const int f16t = ffn_f16_terms(o->precision);      // mixed modes: THIS operator on fp16 operands with 2 / 1 MFMAs per fragment pair
+    if (o->precision < FS2_PREC_FP32 || o->precision > FS2_PREC_MIX_MX) return fail(nullptr, FS2_ERR_ARG, "unknown precision %d", o->precision);
+    const bool mx = o->precision == FS2_PREC_MIX_MX;   // THIS operator in the fp16 + block-scaled-fp8 arithmetic (9-tap convolutions)
+    const int f16t = mx ? 1 : ffn_f16_terms(o->precision);      // mixed modes: THIS operator on fp16 operands with 2 / 1 MFMAs per fragment pair
     hipStream_t s = (hipStream_t)stream;
     Gemm g; g.N = o->N; g.C = o->C; g.ktaps = o->ktaps; g.Cpad = round_up(o->C, kBK);
     const int Npad = round_up(o->N, 128);
@@ -1513,7 +1582,19 @@ int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
     a.resid = o->resid; a.ldr = o->N; a.relu_pre = o->relu_pre; a.ln_g = o->ln_gamma; a.ln_b = o->ln_beta; a.ln_eps = o->ln_eps;
     a.act_post = o->act_post; a.dot_w = o->dot_w; a.dot_b = o->dot_b; a.dot_out = o->dot_out;
     a.xp_scratch = xps;
-    a.f16_terms = f16t;
+    a.f16_terms = mx ? 0 : f16t;
+    if (mx) {
+        if (o->ktaps != kMxTaps || Npad != o->N) return fail(nullptr, FS2_ERR_UNSUPPORTED, "the mx arithmetic needs a 9-tap convolution with N %% 128 == 0");
+        unsigned* scr = nullptr;
+        OP_TRY(tmp.alloc((void**)&scr, 16));
+        const int ka = fp8_scale_exponent(device_absmax(s, o->x, (int64_t)o->R * o->C, scr));
+        const int kw = fp8_scale_exponent(device_absmax(s, o->w, (int64_t)o->N * o->C * o->ktaps, scr));
+        void* w8 = nullptr;
+        const size_t bytes = mx_w8_bytes(Npad, nchunks);
+        OP_TRY(tmp.alloc(&w8, bytes));
+        hipLaunchKernelGGL(repack_weight_mx8, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, s, o->w, o->N, o->C, Npad, nchunks, kw, reinterpret_cast<unsigned char*>(w8));
+        a.mx = 1; a.W8 = w8; a.yp_scale = exp2f((float)ka); a.mx_scale = scale_byte4(127 - ka - 11); a.mx_scale_b = scale_byte4(127 - kw);
+    }
     return launch_gemm(nullptr, s, "op.conv_gemm", a, base_precision(o->precision));      // (tmp drains the stream and frees)
 }
 

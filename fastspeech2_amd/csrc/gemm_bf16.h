@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
     if (pos < 0) {
         if (a.Y)
             for (int c = lane * 4; c < a.N; c += 256) *reinterpret_cast<float4*>(y + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c = lane * 4; c < pc; c += 256) store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{0.f, 0.f, 0.f, 0.f}, a.yp_f16 != 0);
+        for (int c = lane * 4; c < pc; c += 256) store_planes4m(a.Yp, row, a.yp_chunks, c, f32x4{0.f, 0.f, 0.f, 0.f}, a.yp_f16, a.yp_scale);
         if (a.dot_w && lane == 0) a.dot_out[row] = 0.f;
         return;
     }
@@ -190,9 +190,9 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
                 d += (t.x * w.x + t.y * w.y) + (t.z * w.z + t.w * w.w);
             }
             if (a.Y) *reinterpret_cast<float4*>(y + c) = t;
-            if (a.Yp) store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{t.x, t.y, t.z, t.w}, a.yp_f16 != 0);
+            if (a.Yp) store_planes4m(a.Yp, row, a.yp_chunks, c, f32x4{t.x, t.y, t.z, t.w}, a.yp_f16, a.yp_scale);
         } else if (c < pc) {
-            store_planes4(a.Yp, row, a.yp_chunks, c, f32x4{0.f, 0.f, 0.f, 0.f}, a.yp_f16 != 0);
+            store_planes4m(a.Yp, row, a.yp_chunks, c, f32x4{0.f, 0.f, 0.f, 0.f}, a.yp_f16, a.yp_scale);
         }
     }
     if (a.dot_w) {

@@ -31,14 +31,14 @@ constexpr size_t pl_lds_bytes() {
 template <int BM, bool K1> constexpr int pl_occ() { return pl_lds_bytes<BM, K1>() > 53 * 1024 ? 2 : 3; }
 
 // fp32 [R, ldx] -> planes (for activations whose producer is not plane-aware); channels >= C are zero
-__global__ void to_planes(const float* __restrict__ X, int ldx, int C, int R, int nchunks, void* __restrict__ Xp, int f16 = 0) {
+__global__ void to_planes(const float* __restrict__ X, int ldx, int C, int R, int nchunks, void* __restrict__ Xp, int f16 = 0, float scale = 1.f) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int per_row = nchunks * 8;
     if (i >= (int64_t)R * per_row) return;
     const int row = (int)(i / per_row), c = (int)(i - (int64_t)row * per_row) * 4;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < C) v = *reinterpret_cast<const f32x4*>(X + (size_t)row * ldx + c);
-    store_planes4(Xp, row, nchunks, c, v, f16 != 0);
+    store_planes4m(Xp, row, nchunks, c, v, f16, scale);
 }
 
 // Elementwise epilogue on 4-channel pieces (bias and residual are already in the accumulators): ReLU, activation,
@@ -72,7 +72,7 @@ __device__ __forceinline__ void pl_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][
                 v[j] = (valid[r] && colok) ? t : 0.f;
             }
             if (Y && inb[r] && colok) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
-            if (pcol && inb[r]) store_planes4(Yp, row, a.yp_chunks, col, v, a.yp_f16 != 0);
+            if (pcol && inb[r]) store_planes4m(Yp, row, a.yp_chunks, col, v, a.yp_f16, a.yp_scale);
         }
     }
 }
@@ -289,6 +289,55 @@ namespace fs2 {
 //   * B rows are DMA'd permuted as in gemm_pl_bf16: n-tile nt of lane lr is channel 64 NB wn + 64 (nt >> 2) + 4 lr + (nt & 3).
 //   * LayerNorm statistics: two passes (mean, then centred sum of squares) over the 64 NB values a wave holds per row
 //     (16-lane reduction), completed across the two N-waves through 2 KB of LDS.
+// The MFMAs of one k-step of the 8-wave row-complete kernels (wave tile MT x NT 16x16 tiles; A fragments already in registers).
+// B fragments are read one pair of n-tiles AHEAD of the MFMAs that use them (register double buffer, order pinned with
+// sched_group_barrier): 3 LDS waits per k-step instead of 17.  Measured at c3: no change (dec.qkv 0.105 -> 0.102 ms, ffn2+LN
+// 0.095 -> 0.095, out+LN 0.072 -> 0.069): with two waves per SIMD the LDS stalls were already hidden.  Ablations of
+// gemm_row8_bf16 at c3 (232 workgroups in lockstep, N = 384): without any MFMA the kernel takes the same time; a k-step costs
+// 1.3-1.6 us = the round trip of the ONE 64-KB stage that 160 KB of LDS lets a workgroup keep in flight (48 KB of it the
+// weight slice every CU fetches from L2 at the same moment); the bias/residual/LayerNorm/store phase moves 137 MB in ~25 us.
+template <int NSPLIT, int MT, int NT>
+__device__ __forceinline__ void row8_mfma_step(const char* Bs, int nrow, int lg, const bf16x8_t (&ah)[MT], const bf16x8_t (&al)[MT], f32x4 (&acc)[MT][NT]) {
+    constexpr int kReads = NSPLIT == 3 ? 4 : 2, kMfma = 2 * MT * NSPLIT;
+    bf16x8_t bh[2][2], bl[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        bh[0][u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(nrow + u * 16, lg));
+        if (NSPLIT == 3) bl[0][u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(nrow + u * 16, 4 + lg));
+    }
+    // hipcc's scheduler otherwise sinks every read to just before its first use, whatever the source order: pin the order
+    // [first B reads] ([next B reads] [this group's MFMAs])*   (the A reads sit in the caller, before s_setprio)
+    __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+#pragma unroll
+    for (int n2 = 0; n2 < NT; n2 += 2) {
+        const int cb = (n2 >> 1) & 1, nb = cb ^ 1;
+        if (n2 + 2 < NT) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = nrow + (n2 + 2 + u) * 16;
+                bh[nb][u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
+                if (NSPLIT == 3) bl[nb][u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, kMfma, 0);
+        if (NSPLIT == 3) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[cb][u], acc[mt][n2 + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[cb][u], acc[mt][n2 + u], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[cb][u], acc[mt][n2 + u], 0, 0, 0);
+    }
+}
+
 template <int NB> constexpr size_t row8_lds_bytes() { return 2 * (size_t)(128 + 128 * NB) * 128; }
 
 template <int NSPLIT, int NB>
@@ -372,30 +421,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
             if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
         }
         if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int n2 = 0; n2 < NT; n2 += 2) {
-            bf16x8_t bh[2], bl[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int n = wn * (64 * NB) + (n2 + u) * 16 + lp;
-                bh[u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
-                if (NSPLIT == 3) bl[u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
-            }
-            if (NSPLIT == 3) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[u], acc[mt][n2 + u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[u], acc[mt][n2 + u], 0, 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[u], acc[mt][n2 + u], 0, 0, 0);
-        }
+        row8_mfma_step<NSPLIT, MT, NT>(Bs, wn * (64 * NB) + lp, lg, ah, al, acc);
         if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
     }
 
@@ -477,7 +503,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
                     }
                 }
                 if (Y) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
-                if (Yp) store_planes4(Yp, row, a.yp_chunks, col, v, a.yp_f16 != 0);
+                if (Yp) store_planes4m(Yp, row, a.yp_chunks, col, v, a.yp_f16, a.yp_scale);
             }
     }
 }
@@ -578,30 +604,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
                 if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
             }
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int n2 = 0; n2 < NT; n2 += 2) {
-                bf16x8_t bh[2], bl[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int n = wn * (64 * NB) + (n2 + u) * 16 + lp;
-                    bh[u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
-                    if (NSPLIT == 3) bl[u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
-                }
-                if (NSPLIT == 3) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[u], acc[mt][n2 + u], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[u], acc[mt][n2 + u], 0, 0, 0);
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[u], acc[mt][n2 + u], 0, 0, 0);
-            }
+            row8_mfma_step<NSPLIT, MT, NT>(Bs, wn * (64 * NB) + lp, lg, ah, al, acc);
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
             if (tap == ktaps - 1 && chunk + 1 < nchunks) {
                 __syncthreads();                 // every wave has read its last fragments of this chunk's A tile
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
                     }
                 }
                 if (Y) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
-                if (Yp) store_planes4(Yp, row, a.yp_chunks, col, v, a.yp_f16 != 0);
+                if (Yp) store_planes4m(Yp, row, a.yp_chunks, col, v, a.yp_f16, a.yp_scale);
             }
     }
     if (a.dot_w) {      // scalar head: dot_out[row] = v . dot_w + dot_b, summed over the 16 lanes of a row group and the two N-waves
@@ -810,30 +813,7 @@ __global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
                 if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
             }
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int n2 = 0; n2 < NT; n2 += 2) {
-                bf16x8_t bh[2], bl[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int n = wn * (64 * NB) + (n2 + u) * 16 + lp;
-                    bh[u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
-                    if (NSPLIT == 3) bl[u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
-                }
-                if (NSPLIT == 3) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[u], acc[mt][n2 + u], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[u], acc[mt][n2 + u], 0, 0, 0);
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt][n2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[u], acc[mt][n2 + u], 0, 0, 0);
-            }
+            row8_mfma_step<NSPLIT, MT, NT>(Bs, wn * (64 * NB) + lp, lg, ah, al, acc);
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
         }
 

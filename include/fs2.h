@@ -48,6 +48,9 @@ extern "C" {
  * fragment pair), or both operands rounded once (1 MFMA).  Measured error / speed: BASELINE.md section 4. */
 #define FS2_PREC_MIX_F16X2 3
 #define FS2_PREC_MIX_F16X1 4
+/* as FS2_PREC_BF16X3, except that the 9-tap FFN convolution computes a.w = ah.wh (fp16 MFMA) + ra.wh + ah.rw (block-scaled
+ * fp8 MFMA, v_mfma_scale_f32_16x16x128_f8f6f4): ~2.2 MFMA-equivalents per product at split-bf16-class accuracy */
+#define FS2_PREC_MIX_MX 5
 
 typedef struct fs2_handle fs2_handle;
 

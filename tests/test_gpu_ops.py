@@ -150,6 +150,28 @@ def test_conv_gemm_fp16_two_and_one_term(case, precision, bm, fs2_option):
     assert torch.isfinite(yo).all() and err < F16_TOL[precision]
 
 
+@pytest.mark.parametrize("bm", ["64", "128", "256"])
+@pytest.mark.parametrize("shape", [(300, 384, 1024), (517, 256, 1024), (90, 384, 128)])
+def test_conv_gemm_mx_fp16_plus_block_scaled_fp8(shape, bm, fs2_option):
+    """gemm_mx_conv9: a.w = ah.wh (fp16 MFMA) + ra.wh + ah.rw (v_mfma_scale_f32_16x16x128_f8f6f4 on fp8 operands with static scales):
+    the 9-tap FFN convolution at ~2.2 MFMA-equivalents per product.  Accuracy class of split-bf16 (tolerance: 5 x measured)."""
+    fs2_option("FS2_BM", bm)
+    from tests import ops_binding as ops
+    from tests.conftest import record_measurement
+    R, C, N = shape
+    rs = np.random.RandomState(R + C + N)
+    dev = _dev()
+    x = _rand(rs, R, C) * torch.from_numpy(rs.uniform(0.2, 2.0, size=(1, C)).astype(np.float32))      # per-channel gains, LayerNorm-like
+    w = _rand(rs, N, C, 9, scale=1.0 / np.sqrt(C * 9))
+    bias = _rand(rs, N, scale=0.5)
+    y = torch.relu(_ref_conv(x.double(), w.double(), bias.double())).float()
+    yo, _ = ops.conv_gemm(x.to(dev), w.to(dev), bias.to(dev), None, False, None, 1e-5, 1, None, None, precision="mix_mx")
+    err = float((yo.cpu() - y).abs().max())
+    print("mix_mx R=%d C=%d N=%d BM=%s max-abs %.2e" % (R, C, N, bm, err))
+    record_measurement("gemm_mix_mx", err)
+    assert torch.isfinite(yo).all() and err < 2.5e-4
+
+
 def test_conv_gemm_transpose_detecting():
     """A = identity-like with an ASYMMETRIC weight: catches a swapped C/D row<->col mapping."""
     from tests import ops_binding as ops

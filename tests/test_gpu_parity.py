@@ -118,7 +118,7 @@ def test_c2_batch_vs_oracle(env, precision):
         model.precision = "fp32"
 
 
-@pytest.mark.parametrize("precision", ["mix_f16x2", "mix_f16x1"])
+@pytest.mark.parametrize("precision", ["mix_f16x2", "mix_f16x1", "mix_mx"])
 def test_c2_mixed_modes_vs_oracle(env, precision):
     """The mixed arithmetic modes (bf16x3 everywhere except the FFN convolution w_1, which runs on fp16 operands with 2 / 1 MFMAs
     per fragment pair): c2 against the oracle within the 1e-3 mel tolerance; integer decisions still exact.  Measured errors
@@ -139,7 +139,7 @@ def test_c2_mixed_modes_vs_oracle(env, precision):
         d = max(_maxabs(r["before"], o["before"]), _maxabs(r["after"], o["after"]))
         print("c2 [%s] mel max-abs vs oracle %.2e" % (precision, d))
         record_measurement("c2_mel_maxabs_" + precision, d)
-        assert d <= MEL_TOL
+        assert d <= (2.5e-4 if precision == "mix_mx" else MEL_TOL)      # mix_mx is a parity-grade mode (split-bf16 class)
     finally:
         model.precision = "fp32"
 
