@@ -109,6 +109,18 @@ __device__ __forceinline__ void vt_tile_store(const GemmArgs& a, const float* ti
 
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // LDS-DMA source for out-of-range pieces (a masked lane would leave stale LDS bytes)
 
+// Per-lane optional loads without a branch: a lane that must not load reads the zero vector instead (address select).  hipcc
+// compiles `if (ok) v += *p` inside an unrolled tile prologue into a branch with its own s_waitcnt vmcnt(0) per load: the 24-32
+// residual loads of a tile became as many serialized memory round trips (~11 us per LayerNorm-fused GEMM launch at c3).
+__device__ __forceinline__ f32x4 load4_or_zero(const float* p, bool ok) {
+    const float* q = ok ? p : g_zero16;
+    return *reinterpret_cast<const f32x4*>(q);
+}
+__device__ __forceinline__ int loadi_or_zero(const int* p, bool ok) {
+    const int* q = ok ? p : reinterpret_cast<const int*>(g_zero16);
+    return *q;
+}
+
 // Row epilogue as its own HBM-bound kernel (used after gemm_pl_bf16 when the op ends in a LayerNorm, a
 // positional-encoding add or the scalar head): in place on Y [R, N], one wavefront per row, N <= 1024.
 //   v = LN(y) (if ln_g) -> act_post -> v*x_scale + alpha*pe[pos] -> store; dot_out[row] = v . dot_w + dot_b

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_conv9(GemmArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * (BM / 2) + mt * 16 + rperm(lg * 4 + r);
                 f32x4 v = bv;
-                if (a.resid && row < a.R && col < a.N) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
+                v += load4_or_zero(a.resid + (size_t)row * a.ldr + col, a.resid != nullptr && row < a.R && col < a.N);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[mt][nt][r] = v[nt];
             }

@@ -17,6 +17,7 @@
 //     instead of 4-byte ones, without any shuffle.
 //   * A rows keep the conflict-free lane -> row permutation rperm (common.h).
 #pragma once
+#include <type_traits>
 #include "gemm_bf16.h"
 
 namespace fs2 {
@@ -58,7 +59,7 @@ __device__ __forceinline__ void pl_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][
         for (int r = 0; r < 4; ++r) {
             const int row = row_base + mt * 16 + rperm(lg * 4 + r);
             inb[r] = row < a.R;
-            valid[r] = inb[r] && (rpos == nullptr || rpos[row] >= 0);
+            valid[r] = inb[r] && loadi_or_zero(rpos + row, rpos != nullptr && inb[r]) >= 0;      // (branch-free: see load4_or_zero)
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * (BM / 2) + mt * 16 + rperm(lg * 4 + r);
                 f32x4 v = bv;
-                if (a.resid && ks == 0 && row < a.R && col < a.N) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)row * a.ldr + col);
+                v += load4_or_zero(a.resid + (size_t)row * a.ldr + col, a.resid != nullptr && ks == 0 && row < a.R && col < a.N);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[mt][nt][r] = v[nt];
             }
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     int it = c_begin * ktaps;
 #ifdef FS2_GEMM_TIMING
     long long tprev = __builtin_readcyclecounter();
+    const long long t_begin = tprev, r_begin = __builtin_amdgcn_s_memrealtime();      // shader cycles vs the constant 100-MHz counter
 #endif
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         for (int tap = 0; tap < ktaps; ++tap, ++it) {
@@ -223,6 +225,12 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
             }
         }
     }
+#ifdef FS2_GEMM_TIMING
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        g_gemm_phase[6] = __builtin_readcyclecounter() - t_begin;
+        g_gemm_phase[7] = __builtin_amdgcn_s_memrealtime() - r_begin;
+    }
+#endif
     if constexpr (K1 && BM <= 128) {
         if (a.qk_hi != nullptr && n0 < 2 * a.att_D) {
             // fused QKV epilogue, Q | K tiles: row-major split-bf16 operands straight from the registers (8 + 8 bytes per
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 f32x4 v = bv;
-                if (a.resid && rowi[mt][r] < a.R) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)rowi[mt][r] * a.ldr + col0 + 64 * g);
+                v += load4_or_zero(a.resid + (size_t)rowi[mt][r] * a.ldr + col0 + 64 * g, a.resid != nullptr && rowi[mt][r] < a.R);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[mt][4 * g + j][r] = v[j];
             }
@@ -436,7 +444,8 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            pos[mt][r] = rowi[mt][r] < a.R ? (rpos ? rpos[rowi[mt][r]] : 0) : -1;
+            const int pv = loadi_or_zero(rpos + rowi[mt][r], rpos != nullptr && rowi[mt][r] < a.R);
+            pos[mt][r] = rowi[mt][r] < a.R ? pv : -1;
             float s = 0.f;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -478,34 +487,40 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
                 rstd[mt][r] = 1.f / sqrtf((rsum[mt][r] + red[256 + (wave ^ 1) * 32 + mt * 16 + lg * 4 + r]) / (float)a.N + a.ln_eps);
     }
     const float alpha = (a.pe && a.pe_alpha) ? a.pe_alpha[0] : 1.f;
+    // the two forms (with / without the positional-encoding add) are separate straight-line bodies: no load sits behind a
+    // per-lane branch (see load4_or_zero), and the common form carries no positional-encoding loads at all
+    auto emit = [&](auto pe_tag) {
+        constexpr bool PE = decltype(pe_tag)::value;
 #pragma unroll
-    for (int g = 0; g < NB; ++g) {
-        const int col = col0 + 64 * g;
-        f32x4 gam = f32x4{1.f, 1.f, 1.f, 1.f}, bet = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.ln_g) { gam = *reinterpret_cast<const f32x4*>(a.ln_g + col); bet = *reinterpret_cast<const f32x4*>(a.ln_b + col); }
+        for (int g = 0; g < NB; ++g) {
+            const int col = col0 + 64 * g;
+            f32x4 gam = f32x4{1.f, 1.f, 1.f, 1.f}, bet = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.ln_g) { gam = *reinterpret_cast<const f32x4*>(a.ln_g + col); bet = *reinterpret_cast<const f32x4*>(a.ln_b + col); }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = rowi[mt][r];
-                if (row >= a.R) continue;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (pos[mt][r] >= 0) {
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rowi[mt][r];
+                    const bool live = pos[mt][r] >= 0;
                     f32x4 pe4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (a.pe) pe4 = *reinterpret_cast<const f32x4*>(a.pe + (size_t)pos[mt][r] * a.pe_ld + col);
+                    if (PE) pe4 = load4_or_zero(a.pe + (size_t)(live ? pos[mt][r] : 0) * a.pe_ld + col, live);
+                    f32x4 v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float t = acc[mt][4 * g + j][r];
                         if (a.ln_g) t = (t - mean[mt][r]) * rstd[mt][r] * gam[j] + bet[j];
                         t = apply_act(t, a.act_post);
-                        if (a.pe) t = t * a.x_scale + alpha * pe4[j];
-                        v[j] = t;
+                        if (PE) t = t * a.x_scale + alpha * pe4[j];
+                        v[j] = live ? t : 0.f;
+                    }
+                    if (row < a.R) {
+                        if (Y) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
+                        if (Yp) store_planes4m(Yp, row, a.yp_chunks, col, v, a.yp_f16, a.yp_scale);
                     }
                 }
-                if (Y) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
-                if (Yp) store_planes4m(Yp, row, a.yp_chunks, col, v, a.yp_f16, a.yp_scale);
-            }
-    }
+        }
+    };
+    if (a.pe) emit(std::true_type{}); else emit(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -585,7 +600,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 f32x4 v = bv;
-                if (a.resid && rowi[mt][r] < a.R) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)rowi[mt][r] * a.ldr + col0 + 64 * g);
+                v += load4_or_zero(a.resid + (size_t)rowi[mt][r] * a.ldr + col0 + 64 * g, a.resid != nullptr && rowi[mt][r] < a.R);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[mt][4 * g + j][r] = v[j];
             }
@@ -624,7 +639,8 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            pos[mt][r] = rowi[mt][r] < a.R ? (rpos ? rpos[rowi[mt][r]] : 0) : -1;
+            const int pv = loadi_or_zero(rpos + rowi[mt][r], rpos != nullptr && rowi[mt][r] < a.R);
+            pos[mt][r] = rowi[mt][r] < a.R ? pv : -1;
             float s = 0.f;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {

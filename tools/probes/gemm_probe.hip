@@ -1,12 +1,13 @@
 // Phase timing of gemm_pl_bf16<3, BM, K1> on synthetic operands (planes in, fp32 out): ticks (s_memtime) wave 0 of workgroup 0
 // spends per k-step in: barrier wait | DMA issue | fragment reads + MFMAs | chunk-end A refill (conv form), plus the kernel time.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DFS2_GEMM_TIMING -I fastspeech2_amd/csrc tools/probes/gemm_probe.hip -o tools/probes/gemm_probe.bin
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DFS2_GEMM_TIMING -I fastspeech2_amd/csrc -I tools/probes tools/probes/gemm_probe.hip -o tools/probes/gemm_probe.bin
 //   gemm_probe.bin R C N ktaps BM     (BM in 64,128,256; ktaps 1 -> k = 1 form)
+// Conv form: also runs gemm_plr_bf16 (weights straight to registers) on the same operands and compares the outputs bit for bit.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-#include "gemm_planes.h"
+#include "gemm_plr.h"
 using namespace fs2;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 template <int BM, bool K1>
@@ -16,15 +17,46 @@ int run(GemmArgs a, int steps) {
     dim3 grid((a.N + 127) / 128, (a.R + BM - 1) / BM);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
+#ifdef FS2_GEMM_TIMING
         long long zero[8] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_phase), zero, sizeof zero));
+#endif
         hipEventRecord(e0);
         hipLaunchKernelGGL((gemm_pl_bf16<3, BM, K1>), grid, dim3(256), lds, 0, a);
         hipEventRecord(e1); CK(hipDeviceSynchronize());
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        long long ph[8]; CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_gemm_phase), sizeof ph));
+        long long ph[8] = {0};
+#ifdef FS2_GEMM_TIMING
+        CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_gemm_phase), sizeof ph));
+#endif
         printf("BM=%d k=%d R=%d C=%d N=%d: %.1f us, %u workgroups x %d steps; per step: barrier %lld | dma issue %lld | reads+mfma %lld | A refill (per step) %lld ticks\n",
                BM, a.ktaps, a.R, a.C, a.N, ms * 1e3, grid.x * grid.y, steps, ph[0] / steps, ph[1] / steps, ph[2] / steps, ph[3] / steps);
+        if (ph[7]) printf("   k-loop of workgroup 0: %lld shader cycles in %.2f us (100-MHz counter) -> %.0f MHz effective clock\n", ph[6], ph[7] * 0.01, ph[6] / (ph[7] * 0.01));
     }
+    return 0;
+}
+template <int BM>
+int run_plr(GemmArgs a, size_t wbytes) {
+    constexpr size_t lds = plr_lds_bytes<BM>();
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_plr_bf16<3, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* wf; CK(hipMalloc(&wf, wbytes));
+    const int niter = a.Cpad / 32 * a.ktaps, Npad = (a.N + 127) / 128 * 128;
+    const long long nvec = (long long)Npad * niter * 8;
+    hipLaunchKernelGGL(frag_weight_image, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<const __bf16*>(a.Wb), Npad, niter, reinterpret_cast<uint4*>(wf));
+    float* y2; CK(hipMalloc(&y2, (size_t)a.R * a.N * 4));
+    GemmArgs b = a; b.W8 = wf; b.Y = y2;
+    dim3 grid((a.N + 127) / 128, (a.R + BM - 1) / BM);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((gemm_plr_bf16<3, BM>), grid, dim3(256), lds, 0, b);
+        hipEventRecord(e1); CK(hipDeviceSynchronize());
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("plr BM=%d: %.1f us\n", BM, ms * 1e3);
+    }
+    std::vector<float> h1((size_t)a.R * a.N), h2(h1.size());
+    CK(hipMemcpy(h1.data(), a.Y, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), y2, h2.size() * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0; for (size_t i = 0; i < h1.size(); ++i) bad += memcmp(&h1[i], &h2[i], 4) != 0;
+    printf("plr vs pl: %zu of %zu outputs differ\n", bad, h1.size());
     return 0;
 }
 int main(int argc, char** argv) {
@@ -43,6 +75,9 @@ int main(int argc, char** argv) {
     a.C = C; a.Cpad = nchunks * 32; a.ktaps = k; a.N = N; a.R = R; a.W = (const float*)wb; a.Wb = wb; a.Xp = xp; a.Y = y; a.ldy = N; a.x_scale = 1.f;
     const int steps = nchunks * k;
     if (k == 1) return BM == 128 ? run<128, true>(a, steps) : run<64, true>(a, steps);
-    if (BM == 256) return run<256, false>(a, steps);
-    return BM == 128 ? run<128, false>(a, steps) : run<64, false>(a, steps);
+    const size_t wbytes = w.size() * 2;
+    if (BM == 256) { if (run<256, false>(a, steps)) return 1; return run_plr<256>(a, wbytes); }
+    if (BM == 128) { if (run<128, false>(a, steps)) return 1; return run_plr<128>(a, wbytes); }
+    if (run<64, false>(a, steps)) return 1;
+    return run_plr<64>(a, wbytes);
 }
