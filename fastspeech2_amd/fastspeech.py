@@ -321,9 +321,23 @@ class FeedForwardTransformer(nn.Module):
 
     def _weights_fingerprint(self):
         """(storage, version) of every parameter / buffer.  Catches load_state_dict, .to(), optimizer steps and every in-place
-        op autograd sees; writes through ``.data`` bypass the version counter: call ``refresh_weights()`` after those."""
-        sd = self.state_dict(keep_vars=True)
-        return tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+        op autograd sees; writes through ``.data`` bypass the version counter: call ``refresh_weights()`` after those.
+        Runs on every call, so the tensor list is cached (walking ``state_dict()`` cost 0.25 ms of a 1.3-ms single-utterance
+        call); ``load_state_dict`` / ``_apply`` (``.to()``, ``.cuda()``, ``.float()``) and ``refresh_weights`` drop the cache.
+        Assigning a new ``nn.Parameter`` object to a submodule needs ``refresh_weights()``."""
+        refs = self.__dict__.get("_fp_refs")
+        if refs is None:
+            refs = list(self.state_dict(keep_vars=True).values())
+            self.__dict__["_fp_refs"] = refs
+        return tuple([(v.data_ptr(), v._version) for v in refs])
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__["_fp_refs"] = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__["_fp_refs"] = None
+        return super()._apply(fn, *args, **kwargs)
 
     def _ensure_ready(self, device, need_tok, need_frames=0):
         """Create the device handle and (re)upload weights whenever any parameter changed."""
@@ -361,6 +375,7 @@ class FeedForwardTransformer(nn.Module):
     def refresh_weights(self):
         """Force a re-upload of the parameters on the next call (normally automatic)."""
         self._fingerprint = None
+        self.__dict__["_fp_refs"] = None
 
     # ------------------------------------------------------------------ the path
     def _run(self, xs, ilens, olens=None, ds=None, es=None, ps=None, is_inference=False, compat=False,
