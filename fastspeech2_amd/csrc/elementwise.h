@@ -32,7 +32,9 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
                                                          int lmax_cap, int pe_rows, int* start, int* len, int* klen, int* vlen,
                                                          int* rank_tmp, int* woff_tmp, int* pcum, int2* work, int* dims, int* status = nullptr) {
     // The serial parts (row prefix with alignment, longest-first dealing to eight queues) run on one thread: their operands are staged
-    // in LDS first -- from global memory every iteration was a dependent round trip (46 us per call at B = 64, 1 % of a c3 step).
+    // in LDS first -- from global memory every iteration was a dependent round trip.  Round 2: 53 -> 28 us per call at B = 64 (one LDS
+    // atomic per wave instead of 1024 on one address; the dealing loop walks its operands front to back); what is left is seven
+    // barrier phases that each drain thread 0's global stores, and the launch.
     constexpr int kStage = 4096;                      // utterances staged in LDS (beyond: the same code on the global arrays)
     __shared__ int s_len[kStage], s_vlen[kStage], s_order[kStage];
     __shared__ int s_max, s_min;
@@ -42,8 +44,8 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
     __syncthreads();
     int mx = 0, mn = 0x7fffffff;
     for (int b = tid; b < B; b += 1024) { mx = max(mx, olens[b]); mn = min(mn, olens[b]); }
-    atomicMax(&s_max, mx);
-    atomicMin(&s_min, mn);
+    for (int o = 32; o > 0; o >>= 1) { mx = max(mx, __shfl_xor(mx, o)); mn = min(mn, __shfl_xor(mn, o)); }
+    if ((tid & 63) == 0) { atomicMax(&s_max, mx); atomicMin(&s_min, mn); }      // one LDS atomic per wave, not 1024 on one address
     __syncthreads();
     mx = s_max;
     for (int b = tid; b < B; b += 1024) {
@@ -68,6 +70,7 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
         if (staged) s_order[r] = b; else rank_tmp[r] = b;
     }
     __syncthreads();
+    __shared__ int s_row, s_frames;
     if (tid == 0) {
         int row = 8;      // kGap
         int frames = 0;
@@ -78,15 +81,30 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
             pcum[b] = frames;
             frames += staged ? s_vlen[b] : vlen[b];
         }
+        s_row = row; s_frames = frames;
+    }
+    __syncthreads();
+    // blocks of 64 queries per utterance IN DEALING ORDER, so that the serial loop below walks two arrays front to back instead of
+    // chasing s_order[r] -> s_len[b] through LDS (two dependent round trips per utterance on one thread)
+    if (staged)
+        for (int r = tid; r < B; r += 1024) s_vlen[r] = (s_len[s_order[r]] + 63) >> 6;
+    __syncthreads();
+    if (tid == 0) {
+        const int row = s_row, frames = s_frames;
+        // (qlen is only ever indexed by unrolled constants: registers)
         int qlen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int depth = 0;
         for (int r = 0; r < B; ++r) {
             const int b = staged ? s_order[r] : rank_tmp[r];
-            int j = 0;
-            for (int t = 1; t < 8; ++t) if (qlen[t] < qlen[j]) j = t;
-            woff_tmp[b] = qlen[j] * 8 + j;        // list position of the utterance's first block; the next ones follow 8 apart
-            qlen[j] += ((staged ? s_len[b] : len[b]) + 63) >> 6;
-            depth = max(depth, qlen[j]);
+            int j = 0, best = qlen[0];
+#pragma unroll
+            for (int t = 1; t < 8; ++t)
+                if (qlen[t] < best) { best = qlen[t]; j = t; }
+            woff_tmp[b] = best * 8 + j;           // list position of the utterance's first block; the next ones follow 8 apart
+            const int add = staged ? s_vlen[r] : ((len[b] + 63) >> 6);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) qlen[t] += (t == j) ? add : 0;
+            depth = max(depth, best + add);
         }
         int ovf = 0;
         if (row > row_cap || depth * 8 > work_cap) ovf |= 1;
