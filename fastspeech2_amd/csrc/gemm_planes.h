@@ -697,20 +697,20 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = rowi[mt][r];
-                if (row >= a.R) continue;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (pos[mt][r] >= 0) {
+                const bool live = pos[mt][r] >= 0;      // (selects, not branches: see gemm_row8_bf16)
+                f32x4 v;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float t = acc[mt][4 * g + j][r];
-                        if (a.ln_g) t = (t - mean[mt][r]) * rstd[mt][r] * gam[j] + bet[j];
-                        t = apply_act(t, a.act_post);
-                        v[j] = t;
-                        dsum[mt][r] += t * dw[j];
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    float t = acc[mt][4 * g + j][r];
+                    if (a.ln_g) t = (t - mean[mt][r]) * rstd[mt][r] * gam[j] + bet[j];
+                    t = apply_act(t, a.act_post);
+                    v[j] = live ? t : 0.f;
+                    dsum[mt][r] += live ? t * dw[j] : 0.f;
                 }
-                if (Y) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
-                if (Yp) store_planes4m(Yp, row, a.yp_chunks, col, v, a.yp_f16, a.yp_scale);
+                if (row < a.R) {
+                    if (Y) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
+                    if (Yp) store_planes4m(Yp, row, a.yp_chunks, col, v, a.yp_f16, a.yp_scale);
+                }
             }
     }
     if (a.dot_w) {      // scalar head: dot_out[row] = v . dot_w + dot_b, summed over the 16 lanes of a row group and the two N-waves
