@@ -27,7 +27,7 @@ __global__ void build_row_meta(const int* start, const int* len, int B, int rpad
 // kGap zero rows between utterances, attention work list = (utterance, 64-query block) items in eight interleaved per-XCD queues,
 // utterances dealt longest-key-range first to the shortest queue, padding entries (-1, 0).
 // One workgroup.  dims = {rows used, work list length, overflow flags, longest utterance, valid frames}; pcum[b] = valid frames of the
-// utterances before b (row offset of utterance b in the packed output); 8 = kGap, 32 = kAttAlign, 64 = kAttBQ.
+// utterances before b (row offset of utterance b in the packed output); 8 = kGap = kAttAlign, 64 = kAttBQ.
 __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B, int compat, int masked, int row_cap, int work_cap,
                                                          int lmax_cap, int pe_rows, int* start, int* len, int* klen, int* vlen,
                                                          int* rank_tmp, int* woff_tmp, int* pcum, int2* work, int* dims, int* status = nullptr) {
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
         int row = 8;      // kGap
         int frames = 0;
         for (int b = 0; b < B; ++b) {
-            row = (row + 31) & ~31;
+            row = (row + 7) & ~7;      // kAttAlign
             start[b] = row;
             row += (staged ? s_len[b] : len[b]) + 8;
             pcum[b] = frames;

@@ -585,7 +585,7 @@ void build_layout(HostLayout& L, int B, const std::vector<int>& len, const std::
     L.start.resize(B);
     int row = kGap;
     for (int b = 0; b < B; ++b) {
-        row = round_up(row, kAttAlign);     // 32-row aligned starts: 16-byte aligned V^T key tiles (attn_bf16.h)
+        row = round_up(row, kAttAlign);     // aligned starts: 16-byte aligned V^T key tiles (attn_bf16.h)
         L.start[b] = row;
         row += len[b] + kGap;
     }

@@ -199,7 +199,7 @@ def test_attention(D, heads, mask_q, precision):
     starts, row = [], 32
     for l in lens:
         starts.append(row)
-        row = (row + l + 8 + 31) // 32 * 32
+        row = (row + l + 8 + 7) // 8 * 8          # utterance starts are 8-row aligned (kAttAlign): 16-byte V^T loads
     qkv = _rand(rs, row, 3 * D, scale=2.0)
     ctx = ops.attention(qkv.to(dev), D, heads, starts, lens, klens, mask_q, precision=precision).cpu()
     dk = D // heads
