@@ -11,7 +11,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // (struct wrappers) larger than 64 bytes are not scalarised by hipcc and end up in scratch memory.
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kGap = 8;        // zero rows between packed sequences (>= largest conv halo, 4)
+constexpr int kGap = 8;        // upper bound of the zero rows between packed sequences (capacity formulas); a model uses
+constexpr int kMinGap = 4;     // max(kMinGap, its largest conv halo (k - 1) / 2): 4 for the default 9-tap FFN (fs2_handle::gap)
 constexpr int kMaxHalo = 16;   // LDS rows reserved for conv halos (ktaps <= 17)
 constexpr int kBK = 32;        // K-chunk (channels per LDS stage) of the fp32 GEMMs
 constexpr int kLd = kBK + 4;   // LDS row stride in floats (16-B aligned, breaks the 128-B bank period)

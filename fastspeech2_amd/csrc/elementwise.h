@@ -30,7 +30,7 @@ __global__ void build_row_meta(const int* start, const int* len, int B, int rpad
 // utterances before b (row offset of utterance b in the packed output); 8 = kGap = kAttAlign, 64 = kAttBQ.
 __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B, int compat, int masked, int row_cap, int work_cap,
                                                          int lmax_cap, int pe_rows, int* start, int* len, int* klen, int* vlen,
-                                                         int* rank_tmp, int* woff_tmp, int* pcum, int2* work, int* dims, int* status = nullptr) {
+                                                         int* rank_tmp, int* woff_tmp, int* pcum, int2* work, int* dims, int* status = nullptr, int gap = 8) {
     // The serial parts (row prefix with alignment, longest-first dealing to eight queues) run on one thread: their operands are staged
     // in LDS first -- from global memory every iteration was a dependent round trip.  Round 2: 53 -> 28 us per call at B = 64 (one LDS
     // atomic per wave instead of 1024 on one address; the dealing loop walks its operands front to back); what is left is seven
@@ -72,12 +72,12 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
     __syncthreads();
     __shared__ int s_row, s_frames;
     if (tid == 0) {
-        int row = 8;      // kGap
+        int row = gap;
         int frames = 0;
         for (int b = 0; b < B; ++b) {
             row = (row + 7) & ~7;      // kAttAlign
             start[b] = row;
-            row += (staged ? s_len[b] : len[b]) + 8;
+            row += (staged ? s_len[b] : len[b]) + gap;
             pcum[b] = frames;
             frames += staged ? s_vlen[b] : vlen[b];
         }

@@ -165,6 +165,7 @@ struct fs2_handle {
     long enc_ntok = 0;         // phonemes of the encoded batch (basis of the frame-level kernel-variant choice)
     float* kp = nullptr; size_t kp_cap = 0;   // split-K scratch of the call in progress (carved from its workspace)
     int cur_regime = 0;        // regime_rows of the call in progress (0: the launch's own row count)
+    int gap = kGap;            // zero rows between packed utterances: max(kMinGap, largest conv halo of this model)
     void* enc_ws = nullptr;
     std::vector<void*> graph_pinned;   // host staging owned by captured graphs (see upload_layout)
     // profiling
@@ -580,14 +581,14 @@ void build_work_list(const std::vector<int>& len, const std::vector<int>& klen, 
         for (size_t i = 0; i < q[j].size(); ++i) work[i * kXcds + j] = q[j][i];
 }
 
-void build_layout(HostLayout& L, int B, const std::vector<int>& len, const std::vector<int>& klen, const std::vector<int>& vlen) {
+void build_layout(HostLayout& L, int B, const std::vector<int>& len, const std::vector<int>& klen, const std::vector<int>& vlen, int gap) {
     L.B = B; L.len = len; L.klen = klen; L.vlen = vlen;
     L.start.resize(B);
-    int row = kGap;
+    int row = gap;
     for (int b = 0; b < B; ++b) {
         row = round_up(row, kAttAlign);     // aligned starts: 16-byte aligned V^T key tiles (attn_bf16.h)
         L.start[b] = row;
-        row += len[b] + kGap;
+        row += len[b] + gap;
     }
     L.R = row;
     L.Rpad = round_up(row, 128);
@@ -642,7 +643,7 @@ int device_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, D
     rest = reinterpret_cast<int*>(align_up(reinterpret_cast<size_t>(rest), 16));
     D.row_pos = rest; D.row_seq = rest + L.Rpad;
     hipLaunchKernelGGL(frame_layout_dev, dim3(1), dim3(1024), 0, s, olens32, L.B, compat, masked, L.R, L.nwork(), lmax_cap, pe_rows,
-                       D.start, D.len, D.klen, D.vlen, rank_tmp, woff_tmp, D.pcum, D.work, D.dims, status);
+                       D.start, D.len, D.klen, D.vlen, rank_tmp, woff_tmp, D.pcum, D.work, D.dims, status, h ? h->gap : kGap);
     hipLaunchKernelGGL(build_row_meta, dim3((L.Rpad + 255) / 256), dim3(256), 0, s, D.start, D.len, L.B, L.Rpad, D.row_pos, D.row_seq);
     HIP_TRY(h, hipGetLastError());
     return FS2_OK;
@@ -1026,13 +1027,13 @@ int check_batch(fs2_handle* h, const fs2_batch& b) {
     return FS2_OK;
 }
 
-void token_layout(const fs2_batch& b, HostLayout& L) {
+void token_layout(const fs2_batch& b, HostLayout& L, int gap) {
     std::vector<int> len(b.B), klen(b.B), vlen(b.B);
     for (int i = 0; i < b.B; ++i) {
         vlen[i] = klen[i] = (int)b.ilens[i];
         len[i] = b.compat_padded ? b.Tmax : (int)b.ilens[i];
     }
-    build_layout(L, b.B, len, klen, vlen);
+    build_layout(L, b.B, len, klen, vlen, gap);
 }
 
 struct TokenPlan {   // offsets inside the token workspace
@@ -1119,7 +1120,7 @@ size_t carve_frames(const fs2_config& c, const HostLayout& L, void* ws, size_t c
     return align_up(bp.off, 256);
 }
 
-void frame_layout(const fs2_batch& b, const int64_t* olens, int masked, HostLayout& L) {
+void frame_layout(const fs2_batch& b, const int64_t* olens, int masked, HostLayout& L, int gap) {
     std::vector<int> len(b.B), klen(b.B), vlen(b.B);
     int mx = 0;
     for (int i = 0; i < b.B; ++i) mx = std::max(mx, (int)olens[i]);
@@ -1128,7 +1129,7 @@ void frame_layout(const fs2_batch& b, const int64_t* olens, int masked, HostLayo
         len[i] = b.compat_padded ? mx : vlen[i];
         klen[i] = b.compat_padded ? (masked ? vlen[i] : mx) : vlen[i];
     }
-    build_layout(L, b.B, len, klen, vlen);
+    build_layout(L, b.B, len, klen, vlen, gap);
 }
 
 template <typename T>
@@ -1173,6 +1174,11 @@ int fs2_create(const fs2_config* cfg, fs2_handle** out) {
     }
     fs2_handle* h = new fs2_handle();
     h->cfg = *cfg;
+    {   // zero rows between packed utterances: the largest conv halo of this model (launch_gemm refuses kernels > kMaxHalo + 1 taps)
+        int p = std::max(std::max(cfg->ffn_kernel, cfg->dur_kernel), cfg->var_kernel);
+        if (cfg->postnet_layers > 0) p = std::max(p, cfg->postnet_filts);
+        h->gap = std::min(kGap, std::max(kMinGap, (p - 1) / 2));
+    }
     *out = h;
     return FS2_OK;
 }
@@ -1275,7 +1281,7 @@ int fs2_get_profile(fs2_handle* h, const char** names, float* ms, double* flops,
 size_t fs2_token_workspace_bytes(const fs2_handle* h, const fs2_batch* b) {
     if (!h || !b || b->B <= 0 || !b->ilens) return 0;
     HostLayout L;
-    token_layout(*b, L);
+    token_layout(*b, L, h->gap);
     return carve_tokens(h->cfg, *b, L, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
@@ -1293,7 +1299,7 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
     const fs2_batch& b = io->batch;
     const int prec = base_precision(b.precision), ffn_terms = ffn_f16_terms(b.precision);
     h->encoded = false;
-    token_layout(b, h->tok);
+    token_layout(b, h->tok, h->gap);
     const HostLayout& L = h->tok;
     if (L.len.size() && *std::max_element(L.len.begin(), L.len.end()) > h->enc.pe_rows)
         return fail(h, FS2_ERR_ARG, "sequence longer than the positional table (%d rows): extend `pe` and reload", h->enc.pe_rows);
@@ -1336,7 +1342,7 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
 size_t fs2_frame_workspace_bytes(const fs2_handle* h, const fs2_batch* b, const int64_t* olens) {
     if (!h || !b || !olens || b->B <= 0) return 0;
     HostLayout L;
-    frame_layout(*b, olens, 0, L);
+    frame_layout(*b, olens, 0, L, h->gap);
     return carve_frames(h->cfg, L, nullptr, 0, nullptr, nullptr);
 }
 
@@ -1390,7 +1396,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     const int prec = base_precision(b.precision), ffn_terms = ffn_f16_terms(b.precision);
     HostLayout L;
     if (devlay) capacity_layout(b, io->row_capacity, io->Lmax, L);
-    else frame_layout(b, io->olens, io->masked, L);
+    else frame_layout(b, io->olens, io->masked, L, h->gap);
     FrameBufs f; bool ok;
     carve_frames(c, L, io->workspace, io->workspace_bytes, &f, &ok);
     if (!ok) return fail(h, FS2_ERR_WORKSPACE, "fs2_decode: workspace too small");
