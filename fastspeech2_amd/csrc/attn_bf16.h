@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
     const int b = wk.x, h = blockIdx.y;
     const int s0 = a.start[b], len = a.len[b], klen = a.klen[b];
     const int q0 = wk.y * 64 + wave * 16;
+    const bool wave_live = __builtin_amdgcn_readfirstlane(q0) < len;      // wave-uniform: any of this wave's 16 queries inside the utterance
 
     // Q fragments (B operand of S^T): row q0 + lr, d = 32c + 8g .. +7
     bf16x8_t qh[NC], ql[NC];
@@ -209,6 +210,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
         __syncthreads();          // (A) K(kt) visible; every wave is done with P.V(kt-1), so the V^T buffer is free
         FS2_T(0)
         FS2_LOAD_V(key0)          // in flight during Q.K^T and the softmax
+        bf16x8_t ph, pl;
+        if (wave_live) {          // (a wave whose 16 queries all lie beyond the utterance only helps with the staging)
         f32x4 st[2];
         st[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         st[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -292,12 +295,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
             m_run = m_new;
         }
         l_run += psum;
-        bf16x8_t ph, pl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const __bf16 hb = (__bf16)p[j];
             ph[j] = hb;
             pl[j] = (__bf16)(p[j] - (float)hb);
+        }
         }
         FS2_T(2)
         FS2_STORE_V()
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
         FS2_T(3)
         if (kt + 1 < ntiles) FS2_LOAD_K(key0 + 32)     // in flight during P.V
         constexpr int PG = (DK > 128) ? 2 : 4;     // n-tiles in flight: independent accumulators between dependent MFMAs
+        if (wave_live)
 #pragma unroll
         for (int n4 = 0; n4 < NT; n4 += PG) {
             bf16x8_t vh[PG], vl[PG];
