@@ -165,6 +165,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
     const __bf16* vh_base = a.vt_hi + (size_t)h * DK * a.Rvt;
     const __bf16* vl_base = a.vt_lo + (size_t)h * DK * a.Rvt;
 
+    // Keys beyond klen (last tile of an utterance): their scores are overwritten with -inf whatever K holds, but P = 0 times a
+    // non-finite V would still poison P.V, and the rows behind the last utterance are not this call's data: K rows are clamped
+    // to the last key; 8-key V^T vectors that start beyond klen are not read at all, and in vectors that straddle klen the keys
+    // beyond it are zeroed in registers (they end inside the gap rows / the 8 rows every layout appends after its last utterance,
+    // so the read itself stays inside the buffers).
     // Staging: NLD 16-byte loads per thread per operand tile, all issued back-to-back (no branches), held in the
     // same registers for K and V^T in turn.  K(t+1) is fetched while P.V(t) runs, V^T(t) while Q.K^T(t) + softmax run.
     constexpr int NLD = DK / 32;     // 32 * 2*KSL / 256 == DK * 8 / 256
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
     _Pragma("unroll") for (int u = 0; u < NLD; ++u) {                                                       \
         const int idx = tid + u * 256;                                                                      \
         const int key = idx / (2 * KSL), s = idx - key * (2 * KSL);                                         \
-        const __bf16* src = ((s >= KSL) ? kl_base - KSL * 8 : kh_base) + (size_t)(s0 + (key0_) + key) * a.ldqk + s * 8; \
+        const __bf16* src = ((s >= KSL) ? kl_base - KSL * 8 : kh_base) + (size_t)(s0 + min((key0_) + key, klen - 1)) * a.ldqk + s * 8; \
         stg[u] = *reinterpret_cast<const u32x4*>(src);                                                      \
     }
 #define FS2_STORE_K()                                                                                       \
@@ -189,7 +194,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
         const int idx = tid + u * 256;                                                                      \
         const int n = idx >> 3, s = idx & 7;                                                                \
         const __bf16* src = ((s & 4) ? vl_base : vh_base) + (size_t)n * a.Rvt + s0 + (key0_) + (s & 3) * 8; \
-        stg[u] = *reinterpret_cast<const u32x4*>(src);                                                      \
+        const int nv = klen - ((key0_) + (s & 3) * 8);      /* keys of this 8-key vector that exist */          \
+        const void* sp = (nv > 0) ? static_cast<const void*>(src) : static_cast<const void*>(g_zero16);     \
+        stg[u] = *reinterpret_cast<const u32x4*>(sp);                                                       \
+        if (nv < 8) {               /* last tile only: zero the keys beyond klen whatever the memory holds */ \
+            _Pragma("unroll") for (int w = 0; w < 4; ++w)                                                   \
+                stg[u][w] &= (nv > 2 * w + 1) ? 0xffffffffu : ((nv > 2 * w) ? 0x0000ffffu : 0u);            \
+        }                                                                                                   \
     }
 #define FS2_STORE_V()                                                                                       \
     _Pragma("unroll") for (int u = 0; u < NLD; ++u) {                                                       \

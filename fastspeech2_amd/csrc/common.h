@@ -12,6 +12,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kGap = 8;        // upper bound of the zero rows between packed sequences (capacity formulas); a model uses
+constexpr int kTailRows = 8;   // zero rows every layout appends behind its last utterance
 constexpr int kMinGap = 4;     // max(kMinGap, its largest conv halo (k - 1) / 2): 4 for the default 9-tap FFN (fs2_handle::gap)
 constexpr int kMaxHalo = 16;   // LDS rows reserved for conv halos (ktaps <= 17)
 constexpr int kBK = 32;        // K-chunk (channels per LDS stage) of the fp32 GEMMs

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
             pcum[b] = frames;
             frames += staged ? s_vlen[b] : vlen[b];
         }
-        s_row = row; s_frames = frames;
+        s_row = row + 8; s_frames = frames;      // + kTailRows, as build_layout on the host
     }
     __syncthreads();
     // blocks of 64 queries per utterance IN DEALING ORDER, so that the serial loop below walks two arrays front to back instead of

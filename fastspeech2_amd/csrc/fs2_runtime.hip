@@ -590,6 +590,7 @@ void build_layout(HostLayout& L, int B, const std::vector<int>& len, const std::
         L.start[b] = row;
         row += len[b] + gap;
     }
+    row += kTailRows;        // zero rows behind the last utterance (attn_bf16.h: V^T vectors that straddle the last key)
     L.R = row;
     L.Rpad = round_up(row, 128);
     build_work_list(len, klen, L.work);
@@ -1631,7 +1632,7 @@ int fs2_op_attention(void* stream, const float* qkv, float* ctx, int32_t D, int3
     if (precision == FS2_PREC_FP32) {
         rc = launch_attention(nullptr, s, "op.attention", qkv, ctx, D, heads, dl, (int)work.size(), mask_q, 0.0);
     } else {
-        const int Rvt = round_up(R, 128);
+        const int Rvt = round_up(R + kTailRows, 128);      // (8-key V^T vectors that straddle the last key stay inside the planes)
         __bf16* planes = nullptr;
         OP_TRY(tmp.alloc((void**)&planes, (size_t)Rvt * D * 6 * sizeof(__bf16)));
         __bf16 *qkh = planes, *qkl = planes + (size_t)Rvt * 2 * D, *vth = qkl + (size_t)Rvt * 2 * D, *vtl = vth + (size_t)Rvt * D;

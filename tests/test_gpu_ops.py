@@ -200,14 +200,21 @@ def test_attention(D, heads, mask_q, precision):
     for l in lens:
         starts.append(row)
         row = (row + l + 8 + 7) // 8 * 8          # utterance starts are 8-row aligned (kAttAlign): 16-byte V^T loads
-    qkv = _rand(rs, row, 3 * D, scale=2.0)
+    qkv = _rand(rs, row + 64, 3 * D, scale=2.0)
+    # Keys beyond klen must not matter WHATEVER their rows hold: every K / V row that is not a live key (masked pad keys, the gap
+    # rows, the rows behind the last utterance) is NaN.  0 * NaN would poison P.V if the kernel let a dead key through.
+    live = torch.zeros(qkv.shape[0], dtype=torch.bool)
+    for s, kl in zip(starts, klens):
+        live[s:s + kl] = True
+    qkv[~live, D:] = float("nan")
     ctx = ops.attention(qkv.to(dev), D, heads, starts, lens, klens, mask_q, precision=precision).cpu()
+    assert torch.isfinite(ctx[live]).all(), "a dead key reached the output"
     dk = D // heads
     worst = 0.0
     for s, l, kl in zip(starts, lens, klens):
-        q, k, v = (qkv[s:s + l, i * D:(i + 1) * D].view(l, heads, dk).transpose(0, 1) for i in range(3))
+        q = qkv[s:s + l, :D].view(l, heads, dk).transpose(0, 1)
+        k, v = (qkv[s:s + kl, i * D:(i + 1) * D].view(kl, heads, dk).transpose(0, 1) for i in (1, 2))
         sc = q @ k.transpose(1, 2) / np.sqrt(dk)
-        sc[:, :, kl:] = float("-inf")
         a = torch.softmax(sc, dim=-1)
         o = (a @ v).transpose(0, 1).reshape(l, D)
         if mask_q:
