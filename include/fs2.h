@@ -202,7 +202,8 @@ typedef struct fs2_op_gemm_args {
 int fs2_op_conv_gemm(void *stream, const fs2_op_gemm_args *a);
 
 /* scaled-dot-product self-attention over packed sequences: qkv [R, 3*D] (q | k | v, head-major inside
- * each), ctx [R, D].  seq_start/len/klen: HOST [B].  Query rows >= klen produce zeros when mask_q.
+ * each), ctx [R, D].  seq_start/len/klen: HOST [B]; in the bf16 modes seq_start must be a multiple of 8.  Keys >= klen
+ * never reach the output whatever their rows hold (NaN included).  Query rows >= klen produce zeros when mask_q.
  * (reference core/attention.py:47-70) */
 int fs2_op_attention(void *stream, const float *qkv, float *ctx, int32_t D, int32_t heads, int32_t B,
                      const int32_t *seq_start, const int32_t *seq_len, const int32_t *seq_klen,
