@@ -127,6 +127,18 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
     }
 }
 
+// reduction_factor r > 1: the Postnet's row layout = the decoder's with every row expanded to r rows
+__global__ void scale_layout(const int* start, const int* len, const int* vlen, const int* dims, int B, int r, int* start2, int* len2,
+                             int* vlen2, int* dims2) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) { start2[b] = start[b] * r; len2[b] = len[b] * r; vlen2[b] = vlen[b] * r; }
+    if (b == 0 && dims != nullptr) {
+        dims2[0] = dims[0] * r;      // rows in use
+#pragma unroll
+        for (int i = 1; i < 8; ++i) dims2[i] = dims[i];
+    }
+}
+
 // h[row] = E[xs[b, t]] * xscale + alpha * pe[t]      (reference encoder.py:196, embedding.py:77-80,105-120)
 __global__ __launch_bounds__(256) void embed_pe(const int64_t* xs, int Tmax, const float* E, int idim, int D,
                                                 const float* pe, const float* alpha_p, float xscale,

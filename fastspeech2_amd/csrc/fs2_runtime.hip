@@ -1085,6 +1085,8 @@ size_t carve_tokens(const fs2_config& c, const fs2_batch& b, const HostLayout& L
 struct FrameBufs {
     int* meta; float* hfr; float *t0, *t1, *e_rows, *p_rows; StackBufs sb; float *before, *after; int *qe, *qp, *lri;
     float* kp; size_t kp_cap;
+    // reduction_factor r > 1: the Postnet runs on r rows per decoder row (its own row metadata and ping-pong buffers)
+    int* meta2 = nullptr; float *pa2 = nullptr, *pb2 = nullptr, *xps2 = nullptr;
 };
 
 size_t carve_frames(const fs2_config& c, const HostLayout& L, void* ws, size_t cap, FrameBufs* fb, bool* ok) {
@@ -1109,8 +1111,15 @@ size_t carve_frames(const fs2_config& c, const HostLayout& L, void* ws, size_t c
     f.sb.x0p = bp.take<float>(R * (size_t)round_up(std::max(c.ddim, c.postnet_chans), 32));
     f.sb.x1p = bp.take<float>(R * (size_t)round_up(std::max(std::max(c.adim, c.ddim), c.postnet_chans), 32));    // also holds the length-regulator output's planes
     f.sb.xps = bp.take<float>(R * (size_t)round_up(std::max(std::max(c.adim, c.ddim), std::max(std::max(c.var_chans, c.postnet_chans), c.odim)), 32));
-    f.before = bp.take<float>(R * c.odim);
-    f.after = bp.take<float>(R * c.odim);
+    const size_t rf = (size_t)std::max(c.reduction_factor, 1);
+    f.before = bp.take<float>(R * rf * c.odim);
+    f.after = bp.take<float>(R * rf * c.odim);
+    if (rf > 1) {
+        f.meta2 = bp.take<int>(4 * (size_t)L.B + 2 * R * rf + 64);
+        f.pa2 = bp.take<float>(R * rf * c.postnet_chans);
+        f.pb2 = bp.take<float>(R * rf * c.postnet_chans);
+        f.xps2 = bp.take<float>(R * rf * (size_t)round_up(std::max(c.postnet_chans, c.odim), 32));
+    }
     f.qe = bp.take<int>(R);
     f.qp = bp.take<int>(R);
     f.lri = bp.take<int>(R);
@@ -1160,7 +1169,7 @@ extern "C" {
 int fs2_create(const fs2_config* cfg, fs2_handle** out) {
     if (!cfg || !out) return fail(nullptr, FS2_ERR_ARG, "fs2_create: null argument");
     *out = nullptr;
-    if (cfg->reduction_factor != 1) return fail(nullptr, FS2_ERR_UNSUPPORTED, "reduction_factor %d (only 1 is implemented)", cfg->reduction_factor);
+    if (cfg->reduction_factor < 1 || cfg->reduction_factor > 8) return fail(nullptr, FS2_ERR_UNSUPPORTED, "reduction_factor %d outside [1, 8]", cfg->reduction_factor);
     if (cfg->adim % cfg->aheads || cfg->ddim % cfg->aheads) return fail(nullptr, FS2_ERR_ARG, "adim/ddim not divisible by aheads");
     if (!cfg->decoder_input_layer && cfg->ddim != cfg->adim) return fail(nullptr, FS2_ERR_ARG, "decoder_input_layer = 0 needs ddim == adim");
     if (cfg->n_bins != cfg->adim) return fail(nullptr, FS2_ERR_ARG, "n_bins (%d) must equal adim (%d): the reference feeds one_hot(256) into Linear(adim, adim)", cfg->n_bins, cfg->adim);
@@ -1233,7 +1242,7 @@ int fs2_load_weights(fs2_handle* h, const fs2_tensor_desc* t, int32_t n, void* s
         h->dec_in_lng = L.copy("decoder.embed.1.weight", {c.ddim});
         h->dec_in_lnb = L.copy("decoder.embed.1.bias", {c.ddim});
     }
-    h->feat = L.gemm({"feat_out.weight"}, {"feat_out.bias"}, c.odim, c.ddim, 1, true);
+    h->feat = L.gemm({"feat_out.weight"}, {"feat_out.bias"}, c.odim * std::max(c.reduction_factor, 1), c.ddim, 1, true);
     h->post.clear();
     for (int l = 0; l < c.postnet_layers; ++l) {
         const std::string p = "postnet.postnet." + std::to_string(l);
@@ -1453,10 +1462,28 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     }
     const int mask_q = (b.compat_padded && io->masked) ? 1 : 0;
     if ((rc = run_stack(h, s, "dec", h->dec, c.ddim, c.aheads, R, L, dl, mask_q, f.sb, prec, /*x0p_ready=*/dec_pl, /*allow_splitk=*/false, regime_rows, ffn_terms))) return rc;
+    // reduction_factor r (reference fastspeech.py:153,228-230): feat_out emits r mel frames per decoder frame; its [R, odim r] output
+    // IS the [R r, odim] row image the Postnet runs on (decoder row i -> rows i r .. i r + r - 1, gap rows stay zero rows), so only the
+    // row metadata is rebuilt at the finer rate.  r = 1 uses the decoder's own metadata and buffers.
+    const int rf = std::max(c.reduction_factor, 1);
+    const int R2 = R * rf;
+    DevLayout dl2 = dl;
+    if (rf > 1) {
+        if (io->after_packed) return fail(h, FS2_ERR_UNSUPPORTED, "after_packed with reduction_factor > 1");
+        int* m = f.meta2;
+        dl2.start = m; dl2.len = m + b.B; dl2.vlen = m + 2 * b.B; dl2.klen = dl2.len;
+        int* rest = reinterpret_cast<int*>(align_up(reinterpret_cast<size_t>(m + 3 * b.B), 16));
+        dl2.dims = dl.dims ? rest : nullptr; rest += 16;
+        const int Rpad2 = L.Rpad * rf;
+        dl2.row_pos = rest; dl2.row_seq = rest + Rpad2;
+        hipLaunchKernelGGL(scale_layout, dim3((b.B + 255) / 256), dim3(256), 0, s, dl.start, dl.len, dl.vlen, dl.dims, b.B, rf, dl2.start, dl2.len, dl2.vlen, dl2.dims);
+        hipLaunchKernelGGL(build_row_meta, dim3((Rpad2 + 255) / 256), dim3(256), 0, s, dl2.start, dl2.len, b.B, Rpad2, dl2.row_pos, dl2.row_seq);
+        HIP_TRY(h, hipGetLastError());
+    }
     // planes hand-off through the tail: decoder -> feat_out (fp32 mel + planes of it) -> Postnet convs ping-pong x0p / x1p
-    const bool post_pl = dec_pl && c.postnet_layers > 1;
+    const bool post_pl = dec_pl && c.postnet_layers > 1 && rf == 1;     // (r > 1: feat_out's planes would be in the decoder-row layout)
     {
-        GemmArgs a = gemm_args(h->feat, f.sb.x0, c.ddim, R, dl.row_pos, f.before, c.odim);
+        GemmArgs a = gemm_args(h->feat, f.sb.x0, c.ddim, R, dl.row_pos, f.before, c.odim * rf);
         a.Rp = dl.dims;
         if (dec_pl) a.Xp = f.sb.x0p;
         if (post_pl) { a.Yp = f.sb.xps; a.yp_chunks = round_up(c.odim, 32) / 32; }
@@ -1464,20 +1491,20 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     }
     const float* mel_after = f.before;
     if (c.postnet_layers > 0) {
-        float* pa = f.sb.hid;
-        float* pb = f.sb.hid + (size_t)L.Rpad * c.postnet_chans;
+        float* pa = rf > 1 ? f.pa2 : f.sb.hid;
+        float* pb = rf > 1 ? f.pb2 : f.sb.hid + (size_t)L.Rpad * c.postnet_chans;
         const float* in = f.before; int ld = c.odim;
         for (int l = 0; l < c.postnet_layers; ++l) {
             const bool last = (l == c.postnet_layers - 1);
             float* out = last ? f.after : ((l & 1) ? pb : pa);
-            GemmArgs a = gemm_args(h->post[l], in, ld, R, dl.row_pos, out, h->post[l].N);
-            a.Rp = dl.dims;
+            GemmArgs a = gemm_args(h->post[l], in, ld, R2, dl2.row_pos, out, h->post[l].N);
+            a.Rp = dl2.dims;
             if (!last) a.act_post = 2; else { a.resid = f.before; a.ldr = c.odim; }
             if (post_pl) {
                 a.Xp = (l == 0) ? f.sb.xps : ((l & 1) ? f.sb.x0p : f.sb.x1p);
                 if (!last) { a.Y = nullptr; a.Yp = (l & 1) ? f.sb.x1p : f.sb.x0p; a.yp_chunks = round_up(h->post[l].N, 32) / 32; }
             } else {
-                a.xp_scratch = f.sb.xps;
+                a.xp_scratch = rf > 1 ? f.xps2 : f.sb.xps;
             }
             char nm[32]; snprintf(nm, sizeof nm, "postnet.%d", l);
             if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
@@ -1493,8 +1520,9 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         // capacity was too small (nobody can mistake the outputs of such a call for silence); poison_on_overflow covers the rest
         const int* ovf = devlay ? dl.dims + 2 : nullptr;
         bool after_done = false, before_done = false, packed_done = false;
-        if (io->after && (rc = unpack<float>(h, s, mel_after, c.odim, dl.start, lim_len, b.B, io->Lmax, io->after, 0.f, ovf, &after_done))) return rc;
-        if (io->before && (rc = unpack<float>(h, s, f.before, c.odim, dl.start, lim_len, b.B, io->Lmax, io->before, 0.f, ovf, &before_done))) return rc;
+        // (mel outputs hold Lmax * reduction_factor frames per utterance)
+        if (io->after && (rc = unpack<float>(h, s, mel_after, c.odim, dl2.start, dl2.len, b.B, io->Lmax * rf, io->after, 0.f, ovf, &after_done))) return rc;
+        if (io->before && (rc = unpack<float>(h, s, f.before, c.odim, dl2.start, dl2.len, b.B, io->Lmax * rf, io->before, 0.f, ovf, &before_done))) return rc;
         if (io->e_out && (rc = unpack<float>(h, s, f.e_rows, 1, dl.start, lim_msk, b.B, io->Lmax, io->e_out, 0.f))) return rc;
         if (io->p_out && (rc = unpack<float>(h, s, f.p_rows, 1, dl.start, lim_msk, b.B, io->Lmax, io->p_out, 0.f))) return rc;
         if (io->qe && (rc = unpack<int>(h, s, f.qe, 1, dl.start, lim_len, b.B, io->Lmax, io->qe, -1))) return rc;
@@ -1522,9 +1550,9 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         }
         const bool need_poison = devlay && ((io->after && !after_done) || (io->before && !before_done) || (io->after_packed && !packed_done));
         if (need_poison) {
-            hipLaunchKernelGGL(poison_on_overflow, dim3(256), dim3(256), 0, s, dl.dims, io->after, (io->after && !after_done) ? (int64_t)b.B * io->Lmax * c.odim : (int64_t)0,
+            hipLaunchKernelGGL(poison_on_overflow, dim3(256), dim3(256), 0, s, dl.dims, io->after, (io->after && !after_done) ? (int64_t)b.B * io->Lmax * rf * c.odim : (int64_t)0,
                                io->after_packed, (io->after_packed && !packed_done) ? io->row_capacity * c.odim : (int64_t)0, io->before,
-                               (io->before && !before_done) ? (int64_t)b.B * io->Lmax * c.odim : (int64_t)0);
+                               (io->before && !before_done) ? (int64_t)b.B * io->Lmax * rf * c.odim : (int64_t)0);
             HIP_TRY(h, hipGetLastError());
         }
     }

@@ -235,8 +235,9 @@ class FeedForwardTransformer(nn.Module):
         self.use_weighted_masking = bool(m.use_weighted_masking)
         if m.positionwise_layer_type not in ("conv1d", "linear"):
             raise NotImplementedError("Support only linear or conv1d.")
-        if m.reduction_factor != 1:
-            raise NotImplementedError("reduction_factor != 1")
+        if not 1 <= int(m.reduction_factor) <= 8:
+            raise NotImplementedError("reduction_factor outside [1, 8]")
+        self.reduction_factor = int(m.reduction_factor)      # feat_out emits r mel frames per decoder frame (reference fastspeech.py:153,228-230)
         conv = m.positionwise_layer_type == "conv1d"
         kernel = m.positionwise_conv_kernel_size if conv else 1
         self._cfg = dict(
@@ -400,6 +401,8 @@ class FeedForwardTransformer(nn.Module):
         il = torch.as_tensor(ilens).detach().to("cpu", torch.int64).contiguous()   # host lengths (reference: .tolist())
         if il.numel() != B:
             raise ValueError("ilens has %d entries for a batch of %d" % (il.numel(), B))
+        if self.reduction_factor > 1 and ("after_packed" in want or packed_out is not None):
+            raise NotImplementedError("the packed (multi-GPU) output form is implemented for reduction_factor = 1")
         prec = _lib.PRECISIONS[self.precision]
         L = self._ensure_ready(dev, Tmax)
         h = self._handle
@@ -446,7 +449,7 @@ class FeedForwardTransformer(nn.Module):
                     raise ValueError("the device-driven layout serves free-running synthesis")
                 dio = _lib.DecodeIO(
                     batch, None, Lcap, 0, None, None, 0, 0,
-                    cbuf("before", (B, Lcap, odim)), cbuf("after", (B, Lcap, odim)),
+                    cbuf("before", (B, Lcap * self.reduction_factor, odim)), cbuf("after", (B, Lcap * self.reduction_factor, odim)),
                     cbuf("e_outs", (B, Lcap)), cbuf("p_outs", (B, Lcap)),
                     cbuf("qe", (B, Lcap), torch.int32), cbuf("qp", (B, Lcap), torch.int32),
                     cbuf("lr_index", (B, Lcap), torch.int32), cbuf("decoder_out", (B, Lcap, self._cfg["ddim"])),
@@ -495,7 +498,7 @@ class FeedForwardTransformer(nn.Module):
                 batch, ol_arr, Lmax, masked,
                 es_dev.data_ptr() if es_dev is not None else None, ps_dev.data_ptr() if ps_dev is not None else None,
                 es_dev.shape[1] if es_dev is not None else 0, ps_dev.shape[1] if ps_dev is not None else 0,
-                buf("before", (B, Lmax, odim)), buf("after", (B, Lmax, odim)),
+                buf("before", (B, Lmax * self.reduction_factor, odim)), buf("after", (B, Lmax * self.reduction_factor, odim)),
                 buf("e_outs", (B, Lmax)), buf("p_outs", (B, Lmax)),
                 buf("qe", (B, Lmax), torch.int32), buf("qp", (B, Lmax), torch.int32),
                 buf("lr_index", (B, Lmax), torch.int32), buf("decoder_out", (B, Lmax, self._cfg["ddim"])),
@@ -535,6 +538,9 @@ class FeedForwardTransformer(nn.Module):
         _require_device(xs)
         dev = xs.device
         il = torch.as_tensor(ilens).to("cpu", torch.int64)
+        if self.reduction_factor > 1:
+            raise NotImplementedError("loss path with reduction_factor > 1 (the reference's own length handling for it is commented "
+                                      "out, fastspeech.py:275-276); _forward / inference are implemented")
         ol = torch.as_tensor(olens).to("cpu", torch.int64)
         xs = xs[:, : int(il.max())]
         ys = ys[:, : int(ol.max())].to(dev)
@@ -582,14 +588,15 @@ class FeedForwardTransformer(nn.Module):
             if int(st[2]) == 0:
                 L = int(st[3])
                 self._learn_ratio(il, torch.tensor([L]), alpha)
-                return r["after"][0, :L]
+                return r["after"][0, :L * self.reduction_factor]
         r = self._run(xs, il, is_inference=True, want=("after",), alpha=alpha)
         self._learn_ratio(il, r["olens"], alpha)
         return r["after"][0]
 
     def inference_batch(self, xs, ilens, d_override=None, packed=False, sync=True, capacity=None, alpha=1.0, packed_out=None):
         """Batched free-running synthesis (not in the reference, which only has single-utterance
-        ``inference``): per-utterance semantics; returns (mels [B, Lmax, odim], olens [B] on the host), or with
+        ``inference``): per-utterance semantics; returns (mels [B, Lmax, odim], olens [B] on the host = MEL frames per utterance,
+        i.e. decoder frames x reduction_factor), or with
         ``packed=True`` (valid frames back to back [sum(olens), odim], olens): the form the multi-GPU gather ships.
         An empty batch (B = 0, e.g. a rank that got no utterance) returns empty tensors without touching the GPU.
 
@@ -614,16 +621,17 @@ class FeedForwardTransformer(nn.Module):
             key = "after_packed" if packed else "after"         # (packed: the padded mels are neither built nor written)
             r = self._run(xs, il, is_inference=True, compat=False, want=(key,), d_override=d_override, capacity=(total, Lcap), alpha=alpha,
                           packed_out=packed_out if packed else None)
+            mel_lens = r["olens"] if self.reduction_factor == 1 else r["olens"] * self.reduction_factor     # mel frames per utterance
             if torch.cuda.is_current_stream_capturing():     # graph capture: no host-side bookkeeping inside the graph
-                return AsyncMels(r[key], r["olens"], r["status"], None)
-            return AsyncMels(r[key], r["olens"], r["status"], self._record_async(il, r, xs.device, alpha))
+                return AsyncMels(r[key], mel_lens, r["status"], None)
+            return AsyncMels(r[key], mel_lens, r["status"], self._record_async(il, r, xs.device, alpha))
         want = ("after", "after_packed") if packed else ("after",)
         r = self._run(xs, il, is_inference=True, compat=False, want=want, d_override=d_override, alpha=alpha)
         if d_override is None:
             self._learn_ratio(il, r["olens"], alpha)
         else:
             self._learn_ratio(il, r["olens"], 1.0)
-        return (r["after_packed"] if packed else r["after"]), r["olens"]
+        return (r["after_packed"] if packed else r["after"]), r["olens"] * self.reduction_factor
 
     def capture_graph(self, xs, ilens, d_override=None):
         """HIP-graph replay of the whole free-running forward for a fixed batch shape (``xs.shape`` and ``ilens``): the

@@ -67,7 +67,8 @@ typedef struct fs2_config {
     int32_t n_bins;                     /* 256 quantisation levels                            */
     int32_t postnet_layers, postnet_chans, postnet_filts, use_batch_norm;
     int32_t use_scaled_pos_enc;
-    int32_t reduction_factor;           /* only 1 is implemented                              */
+    int32_t reduction_factor;           /* r in [1, 8]: feat_out emits r mel frames per decoder frame; the mel outputs
+                                           (before / after) then hold Lmax * r frames; after_packed needs r = 1 */
     int32_t device;                     /* HIP device ordinal                                 */
     int32_t decoder_input_layer;        /* 1: Linear -> LN -> ReLU -> +pe (fastspeech.py:120-135, encoder.py:118-125);
                                            0: +pe only (the TorchScript twin, utils/fastspeech2_script.py:112-127;

@@ -282,7 +282,10 @@ def per_utterance_forward(sd, cfg, xs, ilens, ds=None, es=None, ps=None, is_infe
         return o
 
     out = dict(olens=olens, lr_index=[r["lr_index"][0] for r in res])
-    for key in ("before", "after", "e_outs", "p_outs", "qe", "qp", "decoder_out", "lr_out", "decoder_in"):
+    rf = int(cfg.get("reduction_factor", 1))     # feat_out emits r mel frames per decoder frame (reference fastspeech.py:228-230)
+    for key in ("before", "after"):
+        out[key] = pad(key, Lmax * rf)
+    for key in ("e_outs", "p_outs", "qe", "qp", "decoder_out", "lr_out", "decoder_in"):
         out[key] = pad(key, Lmax)
     for key in ("d_outs", "encoder_out"):
         out[key] = pad(key, Tmax)

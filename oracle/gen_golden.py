@@ -261,6 +261,50 @@ def block_variants():
     print("G7 written; worst %.3e" % worst)
 
 
+def reduction_factor_fixture():
+    """G8: reduction_factor = 2 (reference fastspeech.py:153,228-230: feat_out emits r mel frames per decoder frame, the Postnet runs
+    on L*r frames).  Real reference, one utterance at a time, teacher-forced and free-running; also checks the oracle."""
+    from fastspeech2_amd.synthetic import portable_state_dict, bias_durations
+    from oracle import fs2_oracle as O
+    hp, idim, Ref = import_reference()
+    odim = hp.audio.num_mels
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    hp.model.reduction_factor = 2
+    torch.manual_seed(0)
+    ref = Ref(idim, odim, hp).eval()
+    sd = bias_durations(portable_state_dict(ref.state_dict(), seed=23), math_log(1 + 3.0))
+    ref.load_state_dict(sd)
+    cfg = O.config_from_hp(hp, idim, odim)
+    b = small_batch(19, [19, 9], 7)
+    arrays = dict(xs=b["xs"].numpy(), ilens=b["ilens"].numpy(), olens=b["olens"].numpy(), ds=b["ds"].numpy(), es=b["es"].numpy(), ps=b["ps"].numpy(),
+                  reduction_factor=np.array(2))
+    worst = 0.0
+    with torch.no_grad():
+        o = O.per_utterance_forward(sd, cfg, b["xs"], b["ilens"], b["ds"], b["es"], b["ps"])
+        f = O.per_utterance_forward(sd, cfg, b["xs"], b["ilens"], is_inference=True)
+        for i in range(2):
+            T, L = int(b["ilens"][i]), int(b["olens"][i])
+            r = ref._forward(b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], b["olens"][i:i + 1], b["ds"][i:i + 1, :T].clone(),
+                             b["es"][i:i + 1, :L], b["ps"][i:i + 1, :L], is_inference=False)
+            arrays["tf_after_%d" % i] = r[1][0].numpy()
+            arrays["tf_before_%d" % i] = r[0][0].numpy()
+            assert r[1].shape[1] == 2 * L
+            d = float((o["after"][i, :2 * L] - r[1][0]).abs().max())
+            worst = max(worst, d)
+            print("G8 teacher-forced utterance %d (L=%d -> %d mel frames): oracle vs reference max-abs %.3e" % (i, L, 2 * L, d))
+            y = ref.inference(b["xs"][i, :T])
+            arrays["free_after_%d" % i] = y.numpy()
+            Lf = int(f["olens"][i])
+            assert y.shape[0] == 2 * Lf, (y.shape, Lf)
+            d = float((f["after"][i, :2 * Lf] - y).abs().max())
+            worst = max(worst, d)
+            print("G8 free-running   utterance %d (%d decoder frames -> %d mel frames): oracle vs reference max-abs %.3e" % (i, Lf, 2 * Lf, d))
+    hp.model.reduction_factor = 1
+    np.savez_compressed(os.path.join(out_dir, "g8_reduction_factor2_b2.npz"), **arrays)
+    assert worst < 2e-5, "oracle restatement of reduction_factor = 2 drifted from the reference"
+    print("G8 written; worst %.3e" % worst)
+
+
 def math_log(v):
     import math
     return math.log(v)
@@ -269,6 +313,9 @@ def math_log(v):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g7":
         block_variants()          # only the block-variant fixture (leaves G1-G6 untouched)
+    elif len(sys.argv) > 1 and sys.argv[1] == "g8":
+        reduction_factor_fixture()
     else:
         main()
         block_variants()
+        reduction_factor_fixture()

@@ -99,7 +99,10 @@ def test_cpu_inputs_raise_not_fallback():
 def test_unsupported_configs_raise():
     from fastspeech2_amd import FeedForwardTransformer
     _, hp = _model()
-    hp.model.reduction_factor = 2
+    hp.model.reduction_factor = 2                     # implemented (fixture G8): feat_out is Linear(ddim, 2 * odim)
+    m2 = FeedForwardTransformer(68, 80, hp)
+    assert m2._cfg["reduction_factor"] == 2 and m2.feat_out.out_features == 160
+    hp.model.reduction_factor = 9
     with pytest.raises(NotImplementedError):
         FeedForwardTransformer(68, 80, hp)
     hp.model.reduction_factor = 1

@@ -709,6 +709,45 @@ def test_g7_block_variants_on_device(name, precision, golden_dir):
         assert mel.shape == tuple(oi["after"][0].shape) and _maxabs(mel, oi["after"][0]) <= MEL_TOL
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_g8_reduction_factor_on_device(precision, golden_dir):
+    """reduction_factor = 2 (reference fastspeech.py:153,228-230): the HIP path against the real reference's outputs (fixture G8),
+    teacher-forced (_forward) and free-running (inference, inference_batch in both layout modes); mel frames = 2 x decoder frames."""
+    from tests.test_oracle_golden import reduction_setup
+    g = np.load(golden_dir + "/g8_reduction_factor2_b2.npz")
+    hp, model, sd, cfg = reduction_setup()
+    model.load_state_dict(sd)
+    model = model.cuda()
+    model.precision = precision
+    tol = 1e-3
+    xs, il = torch.from_numpy(g["xs"]), torch.from_numpy(g["ilens"])
+    with torch.no_grad():
+        for i in range(2):
+            T, L = int(il[i]), int(g["olens"][i])
+            r = model._forward(xs[i:i + 1, :T].cuda(), il[i:i + 1], torch.from_numpy(g["olens"][i:i + 1]), torch.from_numpy(g["ds"][i:i + 1, :T]).cuda(),
+                               torch.from_numpy(g["es"][i:i + 1, :L]).cuda(), torch.from_numpy(g["ps"][i:i + 1, :L]).cuda(), is_inference=False)
+            assert r[1].shape[1] == 2 * L
+            assert float((r[1][0].cpu() - torch.from_numpy(g["tf_after_%d" % i])).abs().max()) < tol
+            assert float((r[0][0].cpu() - torch.from_numpy(g["tf_before_%d" % i])).abs().max()) < tol
+            y = model.inference(xs[i, :T].cuda()).cpu()
+            want = torch.from_numpy(g["free_after_%d" % i])
+            assert y.shape == want.shape
+            assert float((y - want).abs().max()) < tol
+        mels, ol = model.inference_batch(xs.cuda(), il)                       # host-driven layout
+        am = model.inference_batch(xs.cuda(), il, sync=False)                  # device-driven layout
+        mels2, ol2 = am
+        assert am.ok()
+        for i in range(2):
+            want = torch.from_numpy(g["free_after_%d" % i])
+            assert int(ol[i]) == want.shape[0] and int(ol2[i]) == want.shape[0]
+            assert float((mels[i, : want.shape[0]].cpu() - want).abs().max()) < tol
+            assert torch.equal(mels[i, : want.shape[0]], mels2[i, : want.shape[0]])
+            assert float(mels[i, want.shape[0]:].abs().max()) == 0.0 if mels.shape[1] > want.shape[0] else True
+        with pytest.raises(NotImplementedError):
+            model.inference_batch(xs.cuda(), il, packed=True)
+
+
 def test_packed_output_and_unpack_kernel(env):
     """`after_packed` (valid frames back to back, what the multi-GPU all-gather ships) and its inverse
     fs2_op_unpack_rows reproduce the padded output bit-for-bit."""

@@ -140,3 +140,33 @@ def test_g7_block_variants(name, golden_dir):
         L = int(g["olens"][i])
         assert float((o["after"][i, :L] - _t(g["%s_after_%d" % (name, i)])).abs().max()) <= TOL
         assert float((o["before"][i, :L] - _t(g["%s_before_%d" % (name, i)])).abs().max()) <= TOL
+
+
+def reduction_setup():
+    """hp, model, portable weights (seed 23, duration bias ln(1 + 1.386...)) and oracle config of fixture G8 (reduction_factor = 2)."""
+    import math
+    from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
+    from fastspeech2_amd.synthetic import portable_state_dict, bias_durations
+    from oracle import fs2_oracle as O
+    hp = default_hparams()
+    hp.model.reduction_factor = 2
+    model = FeedForwardTransformer(N_PHONEME_SYMBOLS, hp.audio.num_mels, hp).eval()
+    sd = bias_durations(portable_state_dict(model.state_dict(), seed=23), math.log(1 + 3.0))
+    return hp, model, sd, O.config_from_hp(hp, N_PHONEME_SYMBOLS, hp.audio.num_mels)
+
+
+def test_g8_reduction_factor(golden_dir):
+    """reduction_factor = 2 (reference fastspeech.py:153,228-230): oracle vs the real reference, teacher-forced and free-running."""
+    from oracle import fs2_oracle as O
+    g = np.load(golden_dir + "/g8_reduction_factor2_b2.npz")
+    hp, model, sd, cfg = reduction_setup()
+    assert cfg["reduction_factor"] == 2
+    o = O.per_utterance_forward(sd, cfg, _t(g["xs"]), _t(g["ilens"]), _t(g["ds"]), _t(g["es"]), _t(g["ps"]))
+    f = O.per_utterance_forward(sd, cfg, _t(g["xs"]), _t(g["ilens"]), is_inference=True)
+    for i in range(2):
+        L = 2 * int(g["olens"][i])
+        assert float((o["after"][i, :L] - _t(g["tf_after_%d" % i])).abs().max()) <= TOL
+        assert float((o["before"][i, :L] - _t(g["tf_before_%d" % i])).abs().max()) <= TOL
+        y = _t(g["free_after_%d" % i])
+        assert y.shape[0] == 2 * int(f["olens"][i])
+        assert float((f["after"][i, : y.shape[0]] - y).abs().max()) <= TOL
