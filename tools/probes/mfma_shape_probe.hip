@@ -10,6 +10,7 @@
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
 
 __device__ long long g_clk[4];
 
@@ -32,6 +33,25 @@ __global__ __launch_bounds__(256, 2) void burn(const uint4* __restrict__ src, fl
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[(i + (i >> 2)) & 3], c[i], 0, 0, 0);      // 8 x 16384 FLOP
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) out += c[i][0] + c[i][3];
+    } else if constexpr (SHAPE == 128) {      // block-scaled fp8 16x16x128 (random e4m3 bytes with the exponent kept mid-range)
+        v8i a8[2], b8[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                a8[i][w] = (int)((__builtin_bit_cast(uint4, a[2 * i + (w >> 2)])[w & 3] & 0x87878787u) | 0x38383838u);
+                b8[i][w] = (int)((__builtin_bit_cast(uint4, b[2 * i + (w >> 2)])[w & 3] & 0x87878787u) | 0x30303030u);
+            }
+        f32x4 c[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)      // 8 x 65536 FLOP
+                c[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8[i & 1], b8[(i >> 1) & 1], c[i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) out += c[i][0] + c[i][3];
@@ -62,8 +82,8 @@ int run(const uint4* src, float* sink, const char* what) {
         hipEventRecord(e1); CK(hipDeviceSynchronize());
         float ms; hipEventElapsedTime(&ms, e0, e1);
         long long clk[4]; CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof clk));
-        const double flop = (double)wgs * 4 * iters * 8 * 16384.0;
-        printf("%-9s %8.2f ms  %7.1f TFLOP/s  effective clock %.0f MHz\n", what, ms, flop / (ms * 1e-3) * 1e-12, clk[0] / (clk[1] * 0.01));
+        const double flop = (double)wgs * 4 * iters * 8 * (SHAPE == 128 ? 65536.0 : 16384.0);
+        printf("%-17s %8.2f ms  %7.1f TFLOP/s  effective clock %.0f MHz\n", what, ms, flop / (ms * 1e-3) * 1e-12, clk[0] / (clk[1] * 0.01));
     }
     return 0;
 }
@@ -80,5 +100,7 @@ int main() {
     if (run<16>(src, sink, "16x16x32")) return 1;
     if (run<32>(src, sink, "32x32x16")) return 1;
     if (run<16>(src, sink, "16x16x32")) return 1;
-    return run<32>(src, sink, "32x32x16");
+    if (run<32>(src, sink, "32x32x16")) return 1;
+    if (run<128>(src, sink, "mx fp8 16x16x128")) return 1;
+    return run<16>(src, sink, "16x16x32");
 }
