@@ -267,6 +267,12 @@ def main():
                     frac=round(achieved / peak, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
                     share_of_kernel_time=round(scout[dom_name] / kernel_ms_per_step, 3),
                     kernel_ms_per_step_scouted=round(kernel_ms_per_step, 3))
+    if args.precision != "fp32":
+        # what the chip sustains on random bf16 operands with nothing but MFMAs in flight (tools/probes/mfma_shape_probe.hip,
+        # profiles/r02_mfma_shape_power_probe.txt: 1.8-2.1 PFLOP/s at 1.8-2.1 GHz, power-limited); `peak` stays the nominal figure
+        roofline["measured_mfma_peak"] = 1950.0
+        roofline["issued_frac_of_measured_peak"] = round(achieved * {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1}.get(args.precision, 1) / 1950.0, 4) \
+            if dom_name.endswith("ffn1") or args.precision == "bf16x3" else None
     try:    # HBM-side bytes per launch: rocprofv3 PMC passes of this same command (tools/profile_round.sh -> profiles/)
         tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
         if tr["workload"] == workload and tr["precision"] == args.precision and tr["kernel_site"] == dom_name and world == 1:
