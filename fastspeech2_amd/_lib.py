@@ -26,8 +26,16 @@ class Fs2Error(RuntimeError):
         self.code = code
 
 
-class Config(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in (
+class _Sized(C.Structure):
+    """ABI structs that start with ``struct_size`` (include/fs2.h): filled in here, so call sites construct the mirrors with the
+    header's remaining fields only; the library refuses a struct whose size differs from its own sizeof."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(type(self)), *args, **kw)
+
+
+class Config(_Sized):
+    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_int32) for n in (
         "idim", "odim", "adim", "aheads", "elayers", "eunits", "ddim", "dlayers", "dunits", "ffn_kernel",
         "dur_layers", "dur_chans", "dur_kernel", "var_layers", "var_chans", "var_kernel", "n_bins",
         "postnet_layers", "postnet_chans", "postnet_filts", "use_batch_norm", "use_scaled_pos_enc",
@@ -44,14 +52,14 @@ class Batch(C.Structure):
                 ("compat_padded", C.c_int32), ("precision", C.c_int32)]
 
 
-class EncodeIO(C.Structure):
-    _fields_ = [("batch", Batch), ("xs", C.c_void_p), ("ds", C.c_void_p), ("d_log", C.c_void_p),
+class EncodeIO(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("batch", Batch), ("xs", C.c_void_p), ("ds", C.c_void_p), ("d_log", C.c_void_p),
                 ("d_int", C.c_void_p), ("olens", C.c_void_p), ("enc_out", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("duration_alpha", C.c_float)]
 
 
-class DecodeIO(C.Structure):
-    _fields_ = [("batch", Batch), ("olens", C.POINTER(C.c_int64)), ("Lmax", C.c_int32), ("masked", C.c_int32),
+class DecodeIO(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("batch", Batch), ("olens", C.POINTER(C.c_int64)), ("Lmax", C.c_int32), ("masked", C.c_int32),
                 ("es", C.c_void_p), ("ps", C.c_void_p), ("es_stride", C.c_int32), ("ps_stride", C.c_int32),
                 ("before", C.c_void_p), ("after", C.c_void_p), ("e_out", C.c_void_p), ("p_out", C.c_void_p),
                 ("qe", C.c_void_p), ("qp", C.c_void_p), ("lr_index", C.c_void_p), ("dec_out", C.c_void_p),
@@ -59,8 +67,8 @@ class DecodeIO(C.Structure):
                 ("after_packed", C.c_void_p), ("row_capacity", C.c_int64), ("status", C.c_void_p)]
 
 
-class OpGemmArgs(C.Structure):
-    _fields_ = [("R", C.c_int32), ("C", C.c_int32), ("N", C.c_int32), ("ktaps", C.c_int32), ("precision", C.c_int32),
+class OpGemmArgs(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("R", C.c_int32), ("C", C.c_int32), ("N", C.c_int32), ("ktaps", C.c_int32), ("precision", C.c_int32),
                 ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("resid", C.c_void_p),
                 ("relu_pre", C.c_int32), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
                 ("act_post", C.c_int32), ("dot_w", C.c_void_p), ("dot_b", C.c_void_p), ("dot_out", C.c_void_p),
@@ -68,7 +76,9 @@ class OpGemmArgs(C.Structure):
 
 
 # every symbol include/fs2.h declares (tests check the library exports all of them)
-EXPORTS = ["fs2_create", "fs2_destroy", "fs2_last_error", "fs2_load_weights", "fs2_token_workspace_bytes",
+ABI_VERSION = 3      # FS2_ABI_VERSION of the include/fs2.h these mirrors were written against (checked in lib())
+
+EXPORTS = ["fs2_abi_version", "fs2_create", "fs2_destroy", "fs2_last_error", "fs2_load_weights", "fs2_token_workspace_bytes",
            "fs2_encode", "fs2_frame_workspace_bytes", "fs2_row_capacity", "fs2_frame_workspace_bytes_cap", "fs2_decode", "fs2_set_profiling", "fs2_set_profile_filter", "fs2_get_profile",
            "fs2_op_conv_gemm", "fs2_op_attention", "fs2_op_length_regulate", "fs2_op_unpack_rows", "fs2_op_unpack_rows_dev", "fs2_op_transpose", "fs2_op_bucketize", "fs2_op_duration", "fs2_set_option"]
 
@@ -108,6 +118,14 @@ def lib():
     except OSError as e:
         raise Fs2LibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
     vp, i32, i64p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
+    try:
+        L.fs2_abi_version.restype = C.c_int32
+        got = int(L.fs2_abi_version())
+    except AttributeError:
+        got = None
+    if got != ABI_VERSION:
+        raise Fs2LibraryError("%s implements ABI revision %s, this binding revision %d: rebuild it with "
+                              "`python -c 'import __graft_entry__ as g; g.build()'`" % (LIB_PATH, got, ABI_VERSION))
     L.fs2_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.fs2_create.restype = C.c_int
     L.fs2_destroy.argtypes = [vp]

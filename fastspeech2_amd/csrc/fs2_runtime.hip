@@ -1166,9 +1166,21 @@ int unpack(fs2_handle* h, hipStream_t s, const T* src, int W, const int* start, 
 // =====================================================================================================
 extern "C" {
 
+int32_t fs2_abi_version(void) { return FS2_ABI_VERSION; }
+
+// every caller-filled struct starts with its own sizeof as the caller's header saw it: a binding built against another revision
+// of include/fs2.h is refused here instead of having its fields read at the wrong offsets
+#define ABI_CHECK(h, what, ptr, type)                                                                                         \
+    do {                                                                                                                      \
+        if ((ptr)->struct_size != (uint32_t)sizeof(type))                                                                     \
+            return fail(h, FS2_ERR_ARG, "%s: " #type ".struct_size is %u but this library (ABI %d) expects %zu: the binding " \
+                        "does not match include/fs2.h", what, (unsigned)(ptr)->struct_size, FS2_ABI_VERSION, sizeof(type));     \
+    } while (0)
+
 int fs2_create(const fs2_config* cfg, fs2_handle** out) {
     if (!cfg || !out) return fail(nullptr, FS2_ERR_ARG, "fs2_create: null argument");
     *out = nullptr;
+    ABI_CHECK(nullptr, "fs2_create", cfg, fs2_config);
     if (cfg->reduction_factor < 1 || cfg->reduction_factor > 8) return fail(nullptr, FS2_ERR_UNSUPPORTED, "reduction_factor %d outside [1, 8]", cfg->reduction_factor);
     if (cfg->adim % cfg->aheads || cfg->ddim % cfg->aheads) return fail(nullptr, FS2_ERR_ARG, "adim/ddim not divisible by aheads");
     if (!cfg->decoder_input_layer && cfg->ddim != cfg->adim) return fail(nullptr, FS2_ERR_ARG, "decoder_input_layer = 0 needs ddim == adim");
@@ -1297,6 +1309,7 @@ size_t fs2_token_workspace_bytes(const fs2_handle* h, const fs2_batch* b) {
 
 int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
     if (!h || !io) return fail(h, FS2_ERR_ARG, "fs2_encode: null argument");
+    ABI_CHECK(h, "fs2_encode", io, fs2_encode_io);
     if (!h->loaded) return fail(h, FS2_ERR_STATE, "fs2_encode: weights not loaded");
     int rc = check_batch(h, io->batch);
     if (rc) return rc;
@@ -1378,6 +1391,7 @@ size_t fs2_frame_workspace_bytes_cap(const fs2_handle* h, const fs2_batch* b, in
 
 int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     if (!h || !io) return fail(h, FS2_ERR_ARG, "fs2_decode: null argument");
+    ABI_CHECK(h, "fs2_decode", io, fs2_decode_io);
     if (!h->encoded) return fail(h, FS2_ERR_STATE, "fs2_decode called without a preceding fs2_encode");
     const fs2_batch& b = io->batch;
     int rc = check_batch(h, b);
@@ -1577,7 +1591,9 @@ struct DevTmp {
 };
 
 int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
-    if (!o || !o->x || !o->w || o->R <= 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_conv_gemm: bad arguments");
+    if (!o) return fail(nullptr, FS2_ERR_ARG, "fs2_op_conv_gemm: null argument");
+    ABI_CHECK(nullptr, "fs2_op_conv_gemm", o, fs2_op_gemm_args);
+    if (!o->x || !o->w || o->R <= 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_conv_gemm: bad arguments");
     if (o->precision < FS2_PREC_FP32 || o->precision > FS2_PREC_MIX_MX) return fail(nullptr, FS2_ERR_ARG, "unknown precision %d", o->precision);
     const bool mx = o->precision == FS2_PREC_MIX_MX;   // THIS operator in the fp16 + block-scaled-fp8 arithmetic (9-tap convolutions)
     const int f16t = mx ? 1 : ffn_f16_terms(o->precision);      // mixed modes: THIS operator on fp16 operands with 2 / 1 MFMAs per fragment pair

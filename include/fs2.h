@@ -54,9 +54,17 @@ extern "C" {
 
 typedef struct fs2_handle fs2_handle;
 
+/* ABI revision of this header.  Every struct a caller fills and passes by pointer starts with `struct_size`, which the
+ * library compares with its own sizeof: a caller built against a different revision gets FS2_ERR_ARG (and a message
+ * naming both sizes) instead of fields read at the wrong offsets.  fs2_abi_version() returns the library's revision. */
+#define FS2_ABI_VERSION 3
+int32_t fs2_abi_version(void);
+
 /* Model hyper-parameters: the hp.model / hp.data fields FeedForwardTransformer.__init__ reads
  * (reference fastspeech.py:53-160). */
 typedef struct fs2_config {
+    uint32_t struct_size;               /* = sizeof(fs2_config): checked by fs2_create (FS2_ERR_ARG on mismatch), so a
+                                           binding compiled against another revision of this header is rejected, not misread */
     int32_t idim, odim;                 /* phoneme symbols (68), mel bins (80)               */
     int32_t adim, aheads, elayers, eunits;
     int32_t ddim, dlayers, dunits;
@@ -99,6 +107,7 @@ typedef struct fs2_batch {
 } fs2_batch;
 
 typedef struct fs2_encode_io {
+    uint32_t struct_size;     /* = sizeof(fs2_encode_io); fs2_encode returns FS2_ERR_ARG on mismatch         */
     fs2_batch batch;
     const int64_t *xs;        /* device [B, Tmax] phoneme ids (0 = pad)                         */
     const int64_t *ds;        /* device [B, Tmax] durations to use (teacher forcing / override),
@@ -116,6 +125,7 @@ typedef struct fs2_encode_io {
 } fs2_encode_io;
 
 typedef struct fs2_decode_io {
+    uint32_t struct_size;     /* = sizeof(fs2_decode_io); fs2_decode returns FS2_ERR_ARG on mismatch         */
     fs2_batch batch;
     const int64_t *olens;     /* HOST [B]: the values fs2_encode wrote to its device olens       */
     int32_t Lmax;             /* padded frame length of the outputs (>= max olens)               */
@@ -189,6 +199,7 @@ int fs2_get_profile(fs2_handle *h, const char **names, float *ms, double *flops,
  * act_post (0 none,1 relu,2 tanh), dot with dot_w (+dot_b) -> dot_out[R].  row_valid[R] (int32, may be NULL)
  * marks rows to be written as zeros when 0.  (reference modules.py:237-248, encoder.py:60-69) */
 typedef struct fs2_op_gemm_args {
+    uint32_t struct_size;     /* = sizeof(fs2_op_gemm_args) */
     int32_t R, C, N, ktaps, precision;
     const float *x, *w, *bias, *resid;
     int32_t relu_pre;

@@ -27,20 +27,106 @@ def test_header_symbols_exported(libpath):
     assert sorted(_lib.EXPORTS) == declared
 
 
-def test_struct_sizes_match_header():
-    """ctypes mirrors of the ABI structs: field counts as in the header (cheap drift detector)."""
+def _c_probe(tmp_path, structs):
+    """sizeof / offsetof of every field of `structs` = [(c_name, [field, ...])] as gcc sees include/fs2.h."""
+    import subprocess
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "fs2.h"', "int main(void) {",
+           '  printf("abi %d\\n", FS2_ABI_VERSION);']
+    for cname, fields in structs:
+        src.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in fields:
+            src.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    src += ["  return 0;", "}"]
+    c = tmp_path / "probe.c"
+    c.write_text("\n".join(src))
+    exe = str(tmp_path / "probe")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    return {k: int(v) for k, v in (line.split() for line in out.splitlines())}
+
+
+def _header_structs():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import gen_binding_doc
+    finally:
+        sys.path.pop(0)
+    return gen_binding_doc, gen_binding_doc.parse_structs()
+
+
+def _assert_mirror(probe, cname, fields, mirror):
+    assert ctypes.sizeof(mirror) == probe[cname], (cname, ctypes.sizeof(mirror), probe[cname])
+    assert [f for f, _ in fields] == [f[0] for f in mirror._fields_], cname          # same fields, same order
+    for f, _ in fields:
+        assert getattr(mirror, f).offset == probe["%s.%s" % (cname, f)], (cname, f)
+
+
+def test_ctypes_mirrors_match_compiled_header(tmp_path):
+    """Every struct of include/fs2.h, compiled by gcc: sizeof and the offset of every field equal those of the ctypes mirrors in
+    fastspeech2_amd/_lib.py (a reordered, retyped, added or dropped field fails here, not at run time on the GPU)."""
     from fastspeech2_amd import _lib
-    hdr = open(os.path.join(ROOT, "include", "fs2.h")).read()
-    body = re.search(r"typedef struct fs2_config \{(.*?)\} fs2_config;", hdr, re.S).group(1)
-    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    n = sum(len(decl.split(",")) for decl in re.findall(r"int32_t\s+([^;]+);", body))
-    assert n == len(_lib.Config._fields_)
-    assert ctypes.sizeof(_lib.Batch) == 24 and ctypes.sizeof(_lib.TensorDesc) == 56
-    for cname, mirror in (("fs2_encode_io", _lib.EncodeIO), ("fs2_decode_io", _lib.DecodeIO), ("fs2_op_gemm_args", _lib.OpGemmArgs)):
-        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
-        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-        nfields = sum(len(decl.split(",")) for decl in re.findall(r"([^;{}]+);", body) if decl.strip())
-        assert nfields == len(mirror._fields_), (cname, nfields, len(mirror._fields_))
+    gen, structs = _header_structs()
+    probe = _c_probe(tmp_path, [(c, [f for f, _ in fl]) for c, fl in structs])
+    assert probe["abi"] == _lib.ABI_VERSION == gen.abi_version()
+    mirrors = {"fs2_config": _lib.Config, "fs2_tensor_desc": _lib.TensorDesc, "fs2_batch": _lib.Batch, "fs2_encode_io": _lib.EncodeIO,
+               "fs2_decode_io": _lib.DecodeIO, "fs2_op_gemm_args": _lib.OpGemmArgs}
+    assert sorted(mirrors) == sorted(c for c, _ in structs)
+    for cname, fields in structs:
+        _assert_mirror(probe, cname, fields, mirrors[cname])
+    for m in (_lib.Config, _lib.EncodeIO, _lib.DecodeIO, _lib.OpGemmArgs):      # struct_size is filled in by the mirror itself
+        assert m().struct_size == ctypes.sizeof(m)
+
+
+def _integration_blocks():
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    gen, _ = _header_structs()
+    i, j = doc.index(gen.BEGIN), doc.index(gen.END) + len(gen.END)
+    generated = doc[i:j]
+    u0, u1 = doc.index("<!-- BEGIN usage -->"), doc.index("<!-- END usage -->")
+    code = lambda block: re.search(r"```python\n(.*?)```", block, re.S).group(1)
+    return gen, generated, code(generated), code(doc[u0:u1])
+
+
+def test_integration_md_binding_is_generated_from_the_header_and_executes(tmp_path, libpath):
+    """the struct mirrors are byte-for-byte what tools/gen_binding_doc.py derives from include/fs2.h, they
+    match the compiled header field by field, and the documented usage runs against the built library -- here (no GPU) up to
+    fs2_create's "no HIP device" error; tests/test_gpu_parity.py runs it to the end on the GPU."""
+    gen, generated, mirrors_src, usage_src = _integration_blocks()
+    assert generated == gen.doc_block(), "INTEGRATION.md is stale: run `python tools/gen_binding_doc.py --write`"
+    ns = {}
+    exec(compile(mirrors_src, "INTEGRATION.md[mirrors]", "exec"), ns)
+    exec(compile(usage_src, "INTEGRATION.md[usage]", "exec"), ns)
+    _, structs = _header_structs()
+    probe = _c_probe(tmp_path, [(c, [f for f, _ in fl]) for c, fl in structs])
+    for cname, fields in structs:
+        _assert_mirror(probe, cname, fields, ns[gen.PY_NAMES[cname]])
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the full run is in tests/test_gpu_parity.py")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        ns["fs2_synthesize"](libpath, {}, torch.ones(5, dtype=torch.int64))
+
+
+def test_struct_size_mismatch_is_rejected(libpath):
+    """A binding written against an older header (round 2's 25-field fs2_config, no struct_size) is refused with FS2_ERR_ARG
+    before any field is interpreted."""
+    from fastspeech2_amd import _lib
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+
+    class OldCfg(ctypes.Structure):
+        _fields_ = [("f%d" % i, ctypes.c_int32) for i in range(25)]
+    old = OldCfg(68, 80, 256, 2, 4, 1024, 384, 4, 1024, 9, 2, 256, 3, 2, 256, 3, 256, 5, 256, 5, 1, 1, 1, 0, 1)
+    fn = ctypes.CDLL(libpath).fs2_create          # untyped handle: argtypes of the typed one would refuse OldCfg in Python already
+    assert fn(ctypes.byref(old), ctypes.byref(h)) == -1 and b"struct_size" in L.fs2_last_error(None)
+    short = _lib.Config(68, 80, 256, 2, 4, 1024, 384, 4, 1024, 9, 2, 256, 3, 2, 256, 3, 256, 5, 256, 5, 1, 1, 1, 0, 1)
+    short.struct_size -= 16
+    assert L.fs2_create(ctypes.byref(short), ctypes.byref(h)) == -1 and b"struct_size" in L.fs2_last_error(None)
+    assert L.fs2_abi_version() == _lib.ABI_VERSION
+    # the operator entry point checks its argument struct before touching any pointer
+    a = _lib.OpGemmArgs()
+    a.struct_size = 8
+    assert L.fs2_op_conv_gemm(None, ctypes.byref(a)) == -1 and b"struct_size" in L.fs2_last_error(None)
 
 
 def test_create_without_gpu_fails_loudly(libpath):

@@ -804,3 +804,34 @@ def test_vocoder_hand_off(env):
         packed, ol = model.inference_batch(b["xs"].cuda(), b["ilens"], d_override=b["ds"].cuda(), packed=True)
     v = vocoder_input(packed)
     assert v.shape == (1, 80, int(ol.sum())) and torch.equal(v[0], packed.t())
+
+
+def test_integration_md_usage_runs_end_to_end(env):
+    """INTEGRATION.md section 2 (the generated struct mirrors + the documented usage) executed verbatim against the built library:
+    one free-running utterance through fs2_create / fs2_load_weights / fs2_encode / fs2_decode equals the module's inference()
+    bit for bit, and the oracle within the tolerance."""
+    import os
+    import re
+    model, sd, cfg, O = env
+    from fastspeech2_amd import _lib
+    from fastspeech2_amd.synthetic import bias_durations
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"<!-- BEGIN (?:generated[^>]*|usage) -->\n```python\n(.*?)```", doc, re.S)
+    assert len(blocks) == 2
+    ns = {}
+    for b in blocks:
+        exec(compile(b, "INTEGRATION.md", "exec"), ns)
+    sdb = bias_durations(sd, 4.0)
+    ids = torch.from_numpy(np.random.RandomState(11).randint(1, 68, size=31)).to("cuda:0")
+    dev_sd = {k: v.to("cuda:0") for k, v in sdb.items()}
+    mel = ns["fs2_synthesize"](_lib.LIB_PATH, dev_sd, ids, precision=_lib.FS2_PREC_FP32)
+    model.load_state_dict(sdb)
+    try:
+        with torch.no_grad():
+            ref = model.inference(ids)
+    finally:
+        model.load_state_dict(sd)
+    assert mel.shape == ref.shape and torch.equal(mel, ref)
+    want = O.padded_forward(sdb, cfg, ids.cpu().unsqueeze(0), [ids.numel()], is_inference=True)["after"][0]
+    assert _maxabs(mel, want) <= MEL_TOL
