@@ -51,18 +51,26 @@ class AsyncMels(tuple):
 
 
 class _AsyncRecord:
-    """Frame counts and flags of one asynchronous call, copied to pinned host memory behind its kernels."""
-    __slots__ = ("il", "event", "olens_pin", "status_pin", "harvested")
+    """Frame counts and flags of one asynchronous call, copied to pinned host memory behind its kernels.  The pinned slot belongs
+    to a ring and is re-used by later calls: the first look after the event has fired moves the call's own values into the
+    record (``_record_async`` folds a record before it hands its slot to another call), so ``flags()`` / ``olens`` never show a
+    later call's status."""
+    __slots__ = ("il", "event", "olens_pin", "status_pin", "harvested", "_flags", "olens")
 
     def __init__(self, il, event, olens_pin, status_pin):
         self.il, self.event, self.olens_pin, self.status_pin, self.harvested = il, event, olens_pin, status_pin, False
+        self._flags, self.olens = None, None
 
     def flags(self, block):
-        if block:
-            self.event.synchronize()
-        elif not self.event.query():
-            return None
-        return int(self.status_pin[2])
+        if self._flags is None:
+            if block:
+                self.event.synchronize()
+            elif not self.event.query():
+                return None
+            self._flags = int(self.status_pin[2])
+            self.olens = self.olens_pin[: self.il[0].numel()].clone()
+            self.olens_pin = self.status_pin = None
+        return self._flags
 
 
 # ----------------------------------------------------------------------------------------------
@@ -327,9 +335,14 @@ class FeedForwardTransformer(nn.Module):
         call); ``load_state_dict`` / ``_apply`` (``.to()``, ``.cuda()``, ``.float()``) and ``refresh_weights`` drop the cache.
         Assigning a new ``nn.Parameter`` object to a submodule needs ``refresh_weights()``."""
         refs = self.__dict__.get("_fp_refs")
+        # the positional tables are REPLACED when they grow (_PositionalTable.ensure, the reference's extend_pe): a cached list
+        # would keep the old tensors alive and hide the change (round-2 advisor finding)
+        pes = (self.encoder.embed[-1].pe, self.decoder.embed[-1].pe)
+        if refs is not None and (self.__dict__["_fp_pes"][0] is not pes[0] or self.__dict__["_fp_pes"][1] is not pes[1]):
+            refs = None
         if refs is None:
             refs = list(self.state_dict(keep_vars=True).values())
-            self.__dict__["_fp_refs"] = refs
+            self.__dict__["_fp_refs"], self.__dict__["_fp_pes"] = refs, pes
         return tuple([(v.data_ptr(), v._version) for v in refs])
 
     def load_state_dict(self, *args, **kwargs):
@@ -579,6 +592,8 @@ class FeedForwardTransformer(nn.Module):
         """reference fastspeech.py:339-357: x [T] int64 phoneme ids -> mel [L, odim].  ``alpha`` (not in the reference's
         ``inference``, but in its LengthRegulator, length_regulator.py:57-59) scales the durations: > 1 slower speech."""
         xs, il = x.unsqueeze(0), torch.tensor([x.shape[0]])
+        if not float(alpha) > 0.0:
+            raise ValueError("alpha must be > 0 (reference length_regulator.py:57), got %r" % (alpha,))
         if self._frames_per_token is not None:
             # device-driven layout inside capacities learnt from earlier utterances: the GPU runs the whole forward without
             # waiting for the host; the frame count is read once, at the end (it is needed for the shape of the result)
@@ -611,6 +626,8 @@ class FeedForwardTransformer(nn.Module):
         asynchronous calls may be in flight; ``async_ok()`` waits for all of them and tells whether every one since the last
         ``async_ok()`` was valid.  The first call of a model is always synchronous.  ``alpha``: duration scale."""
         il = torch.as_tensor(ilens).detach().to("cpu", torch.int64).reshape(-1)
+        if not float(alpha) > 0.0:
+            raise ValueError("alpha must be > 0 (reference length_regulator.py:57), got %r" % (alpha,))
         if il.numel() == 0:
             _require_device(xs)
             empty = torch.zeros((0, self.odim) if packed else (0, 1, self.odim), device=xs.device)
@@ -735,7 +752,7 @@ class FeedForwardTransformer(nn.Module):
             rec.harvested = True
             il, alpha = rec.il
             if flags == 0:
-                self._learn_ratio(il, rec.olens_pin[: il.numel()].clone(), alpha)
+                self._learn_ratio(il, rec.olens, alpha)
             else:
                 self._overflow_seen = True
             if rec in self._pending:

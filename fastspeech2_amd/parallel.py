@@ -165,8 +165,10 @@ def gather_packed(packed_local, olens_local, index_local, total, group=None):
 
 
 def meta_rows(bmax, odim):
-    """Rows of a [*, odim] float32 pack that hold ``bmax`` int64 frame counts (bit-cast)."""
-    return -(-(8 * int(bmax)) // (4 * int(odim)))
+    """Rows of a [*, odim] float32 pack that hold ``bmax`` int64 frame counts (bit-cast).  The tail must be a whole number of
+    8-byte words for the int64 view, so with an odd ``odim`` the row count is made even."""
+    rows = -(-(8 * int(bmax)) // (4 * int(odim)))
+    return rows + ((rows * int(odim)) & 1)
 
 
 def row_capacity(n_utt, total_frames):
@@ -199,7 +201,7 @@ def _scatter_table(parts, bmax, total, dev):
     return gi
 
 
-def gather_shards(packed_cap, olens_dev, parts, Lout, cap=None, group=None, send_buf=None):
+def gather_shards(packed_cap, olens_dev, parts, Lout, cap=None, group=None, send_buf=None, unpack=True):
     """The ONE collective of the sharded path, sync-free (for ``inference_batch(sync=False, packed=True)``): nothing is read
     back to the host.
 
@@ -213,7 +215,10 @@ def gather_shards(packed_cap, olens_dev, parts, Lout, cap=None, group=None, send
     the result (>= the longest utterance of any rank, e.g. the agreed per-utterance capacity).
     ``send_buf``: the [cap + meta_rows(bmax, odim), odim] buffer whose leading rows ARE ``packed_cap`` (the model wrote its pack
     straight into it: no staging copy); otherwise one is allocated and the pack copied in.
-    Returns (mels [total, Lout, odim] in global utterance order, olens [total] int64 on the device)."""
+    Returns (mels [total, Lout, odim] in global utterance order, olens [total] int64 on the device); with ``unpack=False`` the
+    padded result is not built: returns ``(recv, starts, olens)`` = the gathered packs [world * (cap + meta rows), odim], the first row
+    of every utterance inside them (device int32 [total], global utterance order) and the frame counts -- for consumers that read
+    frames in place (a vocoder that takes packed frames) and skip the [total, Lout, odim] tensor (c5: 0.2 GB valid in 0.6 GB)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = packed_cap.device
@@ -227,8 +232,11 @@ def gather_shards(packed_cap, olens_dev, parts, Lout, cap=None, group=None, send
     if olens_dev.numel() != b:
         raise ValueError("rank %d holds %d utterances but passed %d frame counts" % (rank, b, olens_dev.numel()))
     mrows = meta_rows(bmax, odim)
+    if (cap * odim) % 2:
+        raise ValueError("the frame counts ride behind cap * odim floats as int64: cap * odim = %d * %d must be even" % (cap, odim))
     if send_buf is not None and send_buf.shape[0] == cap + mrows and send_buf.data_ptr() == packed_cap.data_ptr():
         send = send_buf                                      # rows beyond the valid frames are never read (lengths are clamped)
+        send[cap:].zero_()                                   # the buffer came from torch.empty: unused count slots = 0
     else:
         send = packed_cap.new_zeros(cap + mrows, odim)
         send[:rows].copy_(packed_cap)
@@ -244,6 +252,8 @@ def gather_shards(packed_cap, olens_dev, parts, Lout, cap=None, group=None, send
     gi = _scatter_table(parts, bmax, total, dev)
     starts_g = torch.zeros(total + 1, dtype=torch.int32, device=dev).scatter_(0, gi, starts.reshape(-1).to(torch.int32))[:total]
     lens_g = torch.zeros(total + 1, dtype=torch.int32, device=dev).scatter_(0, gi, ol.reshape(-1).to(torch.int32))[:total]
+    if not unpack:
+        return recv, starts_g, lens_g.to(torch.int64)
     if packed_cap.is_cuda:
         import ctypes as C
         from . import _lib
@@ -284,7 +294,7 @@ class ShardedSynthesizer:
         self.overlap = bool(overlap)
         self._comm = None
         self._ratio = None          # (mean, max) frames per phoneme agreed between the ranks
-        self._last = None
+        self._last = None           # the most recent sync-free call's AsyncMels (introspection; ok() is cumulative)
 
     def _world(self):
         """(world size, rank, collective in use).  With an initialised process group the collective runs even at world size
@@ -293,9 +303,12 @@ class ShardedSynthesizer:
         on = dist.is_available() and dist.is_initialized()
         return (dist.get_world_size(self.group), dist.get_rank(self.group), True) if on else (1, 0, False)
 
-    def capacities(self, ilens, parts):
-        """(total frames, per-utterance frames) reserved on every rank for this batch: the largest shard's prediction."""
-        mean_r, max_r = self._ratio
+    def capacities(self, ilens, parts, alpha=1.0):
+        """(total frames, per-utterance frames) reserved on every rank for this batch: the largest shard's prediction, the
+        frames-per-phoneme ratios scaled by the duration scale ``alpha`` exactly as ``model.predict_capacity`` does."""
+        a = float(alpha)
+        extra = 0.5 if a != 1.0 else 0.0      # round(d * alpha) can add half a frame per phoneme
+        mean_r, max_r = self._ratio[0] * a + extra, self._ratio[1] * a + extra
         il = torch.as_tensor(ilens).to("cpu", torch.int64)
         tok = max(int(il[torch.as_tensor(p, dtype=torch.int64)].sum()) if p else 0 for p in parts)
         nmax = max(max(len(p) for p in parts), 1)
@@ -303,8 +316,13 @@ class ShardedSynthesizer:
         Lcap = -(-int(float(il.max()) * max_r * 1.25 + 64) // 32) * 32
         return max(total, Lcap), Lcap
 
-    def __call__(self, xs, ilens, sync=False, **kw):
+    def __call__(self, xs, ilens, sync=False, packed=False, **kw):
+        """``packed=True`` (sync-free calls with a collective only): skip the padded [B, Lcap, odim] result and return
+        ``(recv, starts, olens)`` as :func:`gather_shards` does with ``unpack=False``."""
+        if "alpha" in kw and not float(kw["alpha"]) > 0.0:
+            raise ValueError("alpha must be > 0 (reference length_regulator.py:57), got %r" % (kw["alpha"],))
         world, rank, coll = self._world()
+        skip_unpack = bool(packed)
         self._dev = xs.device
         il = torch.as_tensor(ilens).to("cpu", torch.int64)
         parts = shard_indices(il.tolist(), world)
@@ -345,7 +363,7 @@ class ShardedSynthesizer:
                 return unpack_rows(packed, st.tolist(), olens.tolist(), L), olens.to(xs.device)
             mel, ol = gather_packed(packed, olens, mine, xs.shape[0], self.group)
             return mel, ol.to(xs.device)
-        total, Lcap = self.capacities(il, parts)
+        total, Lcap = self.capacities(il, parts, kw.get("alpha", 1.0))
         cap = max(row_capacity(len(p), total) for p in parts)
         send_buf = None
         if len(mine):
@@ -368,11 +386,11 @@ class ShardedSynthesizer:
                 self._comm = torch.cuda.Stream(device=xs.device)
             self._comm.wait_stream(cur)                       # the pack of this batch is complete
             with torch.cuda.stream(self._comm):
-                out = gather_shards(packed, olens_dev, parts, Lcap, cap=cap, group=self.group, send_buf=send_buf)
+                out = gather_shards(packed, olens_dev, parts, Lcap, cap=cap, group=self.group, send_buf=send_buf, unpack=not skip_unpack)
             packed.record_stream(self._comm)                  # allocated on the compute stream, read by the side stream
             olens_dev.record_stream(self._comm)
             return out
-        return gather_shards(packed, olens_dev, parts, Lcap, cap=cap, group=self.group, send_buf=send_buf)
+        return gather_shards(packed, olens_dev, parts, Lcap, cap=cap, group=self.group, send_buf=send_buf, unpack=not skip_unpack)
 
     def wait(self):
         """Make the current stream wait for the gathers issued in overlap mode (no host synchronisation)."""
@@ -380,9 +398,10 @@ class ShardedSynthesizer:
             torch.cuda.current_stream(self._dev).wait_stream(self._comm)
 
     def ok(self):
-        """True if the capacities of the last sync-free call sufficed on EVERY rank (waits for the GPU; collective)."""
+        """True if the capacities of EVERY sync-free call since the previous ``ok()`` sufficed on EVERY rank (overlap mode keeps
+        several calls in flight: an overflow of any of them returned NaN-filled mels).  Waits for the GPU; collective."""
         _, _, coll = self._world()
-        good = 1 if (self._last is None or self._last.ok()) else 0
+        good = 1 if (self.model is None or self.model.async_ok()) else 0      # cumulative: drains every call in flight
         if coll:
             t = torch.tensor([good], dtype=torch.int32, device=self._dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)

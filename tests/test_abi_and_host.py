@@ -173,6 +173,21 @@ def test_state_dict_layout_matches_reference():
     assert float(sd["encoder.embed.0.weight"][0].abs().max()) == 0.0      # padding_idx row
 
 
+def test_grown_positional_table_changes_the_weight_fingerprint():
+    """extend_pe (reference core/embedding.py:50-56): a longer table is a NEW tensor; the cached fingerprint must notice, or the
+    library keeps the 5000-row table and an utterance beyond it fails (round-2 advisor finding)."""
+    model, _ = _model()
+    fp0 = model._weights_fingerprint()
+    assert model._weights_fingerprint() == fp0
+    assert model.decoder.embed[-1].ensure(6000) and not model.decoder.embed[-1].ensure(5500)
+    fp1 = model._weights_fingerprint()
+    assert fp1 != fp0 and model.state_dict()["decoder.embed.4.pe"].shape[1] == 6000
+    assert model.encoder.embed[-1].ensure(5001)
+    assert model._weights_fingerprint() != fp1
+    with pytest.raises(ValueError, match="alpha"):
+        model.inference_batch(torch.ones(1, 5, dtype=torch.int64), [5], alpha=0.0)
+
+
 def test_cpu_inputs_raise_not_fallback():
     model, _ = _model()
     model.eval()

@@ -35,11 +35,26 @@ class FakeModel:
     sync=False form -> ([row_capacity, odim] pack with the valid frames first and garbage behind, olens 'device' tensor)."""
     odim = ODIM
     _frames_per_token = None
+    _overflow_seen = False
+    overflow_next = False        # test hook: the next sync-free call behaves like a capacity overflow (NaN pack, flagged)
 
-    def inference_batch(self, xs, ilens, packed=False, sync=True, capacity=None):
+    def async_ok(self):
+        ok = not self._overflow_seen
+        self._overflow_seen = False
+        return ok
+
+    def inference_batch(self, xs, ilens, packed=False, sync=True, capacity=None, alpha=1.0):
         from fastspeech2_amd.parallel import row_capacity
         assert packed and xs.shape[0] == len(ilens) > 0, "the synthesizer must not call the model with an empty shard"
         mel, ol = _fake_run_local(xs, ilens)
+        if alpha != 1.0:         # duration scale: every utterance gets round(L * alpha) frames (its first frame repeated behind)
+            ol2 = torch.round(ol.float() * alpha).long()
+            m2 = torch.zeros(mel.shape[0], int(ol2.max()), ODIM)
+            for b in range(len(ol)):
+                n = min(int(ol[b]), int(ol2[b]))
+                m2[b, :n] = mel[b, :n]
+                m2[b, n:int(ol2[b])] = mel[b, 0]
+            mel, ol = m2, ol2
         valid = torch.cat([mel[i, : int(ol[i])] for i in range(len(ol))])
         il = torch.as_tensor(ilens)
         if sync:
@@ -48,6 +63,9 @@ class FakeModel:
         rows = row_capacity(len(ol), capacity[0])
         assert valid.shape[0] <= rows and int(ol.max()) <= capacity[1], "capacities from ShardedSynthesizer.capacities() too small"
         pk = torch.full((rows, ODIM), float("nan"))          # rows beyond the valid frames must never be read
+        if self.overflow_next:
+            self.overflow_next, self._overflow_seen = False, True
+            return _Async((pk, ol.clone()))
         pk[: valid.shape[0]] = valid
         return _Async((pk, ol.clone()))
 
@@ -90,6 +108,26 @@ def _worker(rank, world, port, q):
     assert synth.ok()
     assert torch.equal(ol4, want_ol) and torch.equal(mel4[:, :L], want_mel) and float(mel4[:, L:].abs().sum()) == 0.0
     assert not torch.isnan(mel4).any()
+    # (3b) packed return form: no padded [B, Lcap, odim] tensor, frames are read in place from the gathered packs
+    recv, starts, ol5 = synth(xs, il, packed=True)
+    assert torch.equal(ol5, want_ol)
+    for g in range(xs.shape[0]):
+        s0, n = int(starts[g]), int(ol5[g])
+        assert torch.equal(recv[s0:s0 + n], want_mel[g, :n])
+    # (3c) ok() is cumulative: an overflow on ONE rank in an EARLIER call is still reported after a later good call, once
+    if rank == world - 1:
+        synth.model.overflow_next = True
+    synth(xs, il)
+    synth(xs, il)
+    assert not synth.ok() and synth.ok()
+    # (3d) duration scale: the capacities follow alpha (1.6x the frames would overflow capacities sized for alpha = 1)
+    m6, o6 = synth(xs, il, alpha=1.6)
+    assert synth.ok() and torch.equal(o6, torch.round(want_ol.float() * 1.6).long()) and not torch.isnan(m6).any()
+    try:
+        synth(xs, il, alpha=0.0)
+        raise AssertionError("alpha = 0 must be rejected")
+    except ValueError:
+        pass
     # (4) fewer utterances than ranks: some rank has an EMPTY shard and still takes part in the collectives
     for form in (ShardedSynthesizer(_fake_run_local), synth):
         for _ in range(2):
@@ -129,6 +167,15 @@ def test_sharded_equals_unsharded_gloo():
 
 def test_sharded_equals_unsharded_gloo_three_ranks():
     _run_world(3)
+
+
+def test_meta_rows_hold_int64_counts_for_any_width():
+    from fastspeech2_amd.parallel import meta_rows
+    for odim in (1, 3, 7, 8, 80, 81):
+        for bmax in (1, 2, 5, 128):
+            r = meta_rows(bmax, odim)
+            assert r * odim * 4 >= 8 * bmax and (r * odim) % 2 == 0, (odim, bmax, r)
+    assert meta_rows(128, 80) == 4
 
 
 def test_shard_balance():
