@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "mix_f16x2": 2500.0, "mix_f16x1": 2500.0, "mix_mx": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
 DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3", "bf16": "bf16", "mix_f16x2": "bf16x3 (FFN conv: f16x2)", "mix_f16x1": "bf16x3 (FFN conv: f16)",
               "mix_mx": "bf16x3 (FFN conv: f16 + block-scaled fp8 corrections)"}
-MFMA_PER_PRODUCT = {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1, "mix_mx": 2.19}       # MFMAs issued per algorithmic product in the dominant kernel (the FFN conv)
+MFMA_PER_PRODUCT = {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1, "mix_mx": 2.0}       # MFMAs issued per algorithmic product in the dominant kernel (the FFN conv)
 HBM_PEAK_GBPS = 8000.0
 WORKLOAD_TEXT = {
     "c1": "c1: 1 utterance, 80 phonemes",

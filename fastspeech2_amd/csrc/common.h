@@ -61,10 +61,10 @@ struct GemmArgs {
     // convolution.  yp_f16: write Yp as fp16 planes; f16_terms: 0 = bf16 arithmetic, else Xp / W are fp16 images and
     // the kernel issues f16_terms MFMAs per fragment pair (3: lo*hi + hi*lo + hi*hi, 2: lo*hi + hi*hi = weights rounded once, 1: hi*hi)
     int yp_f16; int f16_terms;
-    // "mx" arithmetic of the FFN convolution (gemm_mx.h): yp_f16 == 2 writes Yp in the f16mx format with the static scale yp_scale = 2^ka;
-    // mx != 0: Xp is f16mx, W the fp16 image, W8 the fp8 correction image, mx_scale / mx_scale_b the E8M0 bytes (x 0x01010101) of the
+    // "mx" arithmetic of the FFN convolution (gemm_mx.h): yp_f16 == 2 writes Yp as mx planes with the static scale yp_scale = 2^ka;
+    // mx != 0: Xp are mx planes, W the mx weight image (same unit order), mx_scale / mx_scale_b the E8M0 bytes (x 0x01010101) of the
     // A / B side of the scaled MFMA (127 - ka - 11 and 127 - kw)
-    float yp_scale; int mx; const void* W8; int mx_scale, mx_scale_b;
+    float yp_scale; int mx; int mx_scale, mx_scale_b;
     // deterministic split-K (small grids with a long K: the loop is a serial chain of k-steps): workgroup z of grid.z accumulates the
     // 32-channel chunks [z, z+1) * Cpad/32/ksplit (all taps of them); split 0 (which also adds bias + residual) writes Y, split z > 0
     // writes kpart + (z-1) * kpart_stride; the row kernel that follows (ln_rows) adds the partials in a fixed order and applies the
@@ -131,7 +131,9 @@ __device__ __forceinline__ void split4_f16(const f32x4 v, uint2& hi, uint2& lo) 
     hi = *reinterpret_cast<uint2*>(&h);
     lo = *reinterpret_cast<uint2*>(&l);
 }
-// f16mx planes (gemm_mx.h): [ah: 32 fp16, kperm order | ah8: 32 e4m3 of a 2^ka, channel order | ra8: 32 e4m3 of (a - ah) 2^(ka+11)]
+// "mx" planes (gemm_mx.h): a row of C channels is 4C bytes = C/32 units of 128 B, the LDS row images of the conv loop:
+//   [ fp16(a): C/64 units of 64 channels | ra8: C/128 units = e4m3((a - fp16(a)) 2^(ka+11)) | ah8: C/128 units = e4m3(fp16(a) 2^ka) ],
+// channels in their natural order inside every unit (requires C % 128 == 0; nchunks = C/32 as for the split planes).
 __device__ __forceinline__ unsigned pack_fp8x4(const f32x4 v) {
     int w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[0], -448.f), 448.f), fminf(fmaxf(v[1], -448.f), 448.f), 0, false);
     w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[2], -448.f), 448.f), fminf(fmaxf(v[3], -448.f), 448.f), w, true);
@@ -148,12 +150,13 @@ __device__ __forceinline__ void store_planes4_mx(void* planes, size_t row, int n
         hs[j] = (float)hb * sa;
         rs[j] = (x - (float)hb) * (sa * 2048.f);
     }
-    char* p = reinterpret_cast<char*>(planes) + (row * nchunks + (c >> 5)) * 128;
-    *reinterpret_cast<uint2*>(p + ((((c & 15) >> 2) << 4) + (((c >> 4) & 1) << 3))) = *reinterpret_cast<uint2*>(&h);
-    *reinterpret_cast<unsigned*>(p + 64 + (c & 31)) = pack_fp8x4(hs);
-    *reinterpret_cast<unsigned*>(p + 96 + (c & 31)) = pack_fp8x4(rs);
+    const size_t C = (size_t)nchunks * 32;
+    char* p = reinterpret_cast<char*>(planes) + row * (4 * C);
+    *reinterpret_cast<uint2*>(p + 2 * c) = *reinterpret_cast<uint2*>(&h);
+    *reinterpret_cast<unsigned*>(p + 2 * C + c) = pack_fp8x4(rs);
+    *reinterpret_cast<unsigned*>(p + 3 * C + c) = pack_fp8x4(hs);
 }
-// planes of 4 consecutive channels in the format `mode`: 0 split-bf16, 1 split-fp16, 2 f16mx (scale = 2^ka)
+// planes of 4 consecutive channels in the format `mode`: 0 split-bf16, 1 split-fp16, 2 mx (scale = 2^ka)
 __device__ __forceinline__ void store_planes4m(void* planes, size_t row, int nchunks, int c, const f32x4 v, int mode, float scale);
 
 __device__ __forceinline__ void store_planes4(void* planes, size_t row, int nchunks, int c, const f32x4 v, bool f16 = false) {

@@ -35,7 +35,7 @@ struct Gemm {          // one repacked Linear / Conv1d
     float* w = nullptr;      // [Npad][ktaps][Cpad]
     void* wb = nullptr;      // split-bf16 image [Npad][ktaps][Cpad/32][hi 32 | lo 32]
     void* wf = nullptr;      // the same image in fp16 (FFN w_1 only): operand of the two- / one-term arithmetic modes
-    void* w8 = nullptr;      // fp8 correction image of the "mx" mode (gemm_mx.h; 9-tap FFN w_1 only) ...
+    void* wm = nullptr;      // weight image of the "mx" mode (gemm_mx.h; FFN w_1 convolutions with C % 128 == 0 and N % 128 == 0) ...
     int kw = 0;              // ... and the exponent of its static scale: |w| 2^kw <= 448
     float* bias = nullptr;   // [N] or null
     int N = 0, C = 0, Cpad = 0, ktaps = 1;
@@ -251,13 +251,13 @@ hipError_t launch_tile(hipStream_t s, const GemmArgs& a) {
 
 bool rows_supported(int N) { return N == 80 || N == 256 || N == 384; }
 
-template <int NSPLIT, int BM, bool K1, bool F16 = false>
+template <int NSPLIT, int BM, bool K1, int ARITH = 0>
 hipError_t launch_pl_t(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
     constexpr size_t lds = pl_lds_bytes<BM, K1>();
-    allow_lds(reinterpret_cast<const void*>(&gemm_pl_bf16<NSPLIT, BM, K1, F16>), lds, attr);
+    allow_lds(reinterpret_cast<const void*>(&gemm_pl_bf16<NSPLIT, BM, K1, ARITH>), lds, attr);
     dim3 grid((a.N + kB16BN - 1) / kB16BN, ((a.qk_hi ? a.Rvt : a.R) + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : 1);
-    hipLaunchKernelGGL((gemm_pl_bf16<NSPLIT, BM, K1, F16>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_pl_bf16<NSPLIT, BM, K1, ARITH>), grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -323,22 +323,13 @@ hipError_t launch_pl(hipStream_t s, const GemmArgs& a) {
     return bm == 128 ? launch_pl_t<NSPLIT, 128, false>(s, a) : launch_pl_t<NSPLIT, 64, false>(s, a);
 }
 
-// fp16 + block-scaled-fp8 form of the 9-tap conv (gemm_mx.h)
-template <int BM>
-hipError_t launch_mx_t(hipStream_t s, const GemmArgs& a) {
-    static LdsAttr attr;
-    constexpr size_t lds = pl_lds_bytes<BM, false>();
-    allow_lds(reinterpret_cast<const void*>(&gemm_mx_conv9<BM>), lds, attr);
-    dim3 grid((a.N + kB16BN - 1) / kB16BN, (a.R + BM - 1) / BM, 1);
-    hipLaunchKernelGGL((gemm_mx_conv9<BM>), grid, dim3(256), lds, s, a);
-    return hipGetLastError();
-}
+// fp16 + block-scaled-fp8 form of the conv (gemm_mx.h): the planes kernel on mx planes / the mx weight image
 hipError_t launch_mx(hipStream_t s, const GemmArgs& a) {
-    // 128-row tiles at most: the 256-row instantiation needs > 512 VGPRs (measured: 758 spilled, 7x slower)
     const int force = opts().bm > 0 ? opts().bm : 0;
     const long nN = (a.N + kB16BN - 1) / kB16BN;
-    const int bm = force ? (force >= 128 ? 128 : 64) : (nN * ((a.R + 127) / 128) >= 400 ? 128 : 64);
-    return bm == 128 ? launch_mx_t<128>(s, a) : launch_mx_t<64>(s, a);
+    const int bm = force ? force : (nN * ((a.R + 255) / 256) >= 512 ? 256 : (nN * ((a.R + 127) / 128) >= 400 ? 128 : 64));
+    if (bm == 256) return launch_pl_t<1, 256, false, 2>(s, a);
+    return bm == 128 ? launch_pl_t<1, 128, false, 2>(s, a) : launch_pl_t<1, 64, false, 2>(s, a);
 }
 
 // fp16-operand form of the conv kernel (FFN w_1 in the mixed modes): NSPLIT MFMAs per fragment pair
@@ -347,8 +338,8 @@ hipError_t launch_pl_f16(hipStream_t s, const GemmArgs& a) {
     const int force = opts().bm > 0 ? opts().bm : 0;
     const long nN = (a.N + kB16BN - 1) / kB16BN;
     const int bm = force ? force : (nN * ((a.R + 255) / 256) >= 512 ? 256 : (nN * ((a.R + 127) / 128) >= 400 ? 128 : 64));
-    if (bm == 256) return launch_pl_t<NSPLIT, 256, false, true>(s, a);
-    return bm == 128 ? launch_pl_t<NSPLIT, 128, false, true>(s, a) : launch_pl_t<NSPLIT, 64, false, true>(s, a);
+    if (bm == 256) return launch_pl_t<NSPLIT, 256, false, 1>(s, a);
+    return bm == 128 ? launch_pl_t<NSPLIT, 128, false, 1>(s, a) : launch_pl_t<NSPLIT, 64, false, 1>(s, a);
 }
 
 // Picks the kernel.  fp32: row-complete tiles when the epilogue needs whole rows and N is small, 128x128 tiles (+ ln_rows) otherwise.
@@ -404,7 +395,7 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
             t.kpart_stride = (size_t)a.R * t.ldy;
         }
         if ((a.f16_terms || a.mx) && (a.ktaps == 1 || need_rows || a.qk_hi)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: the fp16 arithmetic exists for plain convolutions only", name);
-        if (a.mx && (a.ktaps != kMxTaps || !a.W8 || a.N % 128 != 0)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: the mx arithmetic needs a 9-tap convolution with N %% 128 == 0 and its fp8 image", name);
+        if (a.mx && (a.ktaps < 3 || a.C % 128 != 0 || a.N % 128 != 0)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: the mx arithmetic needs a convolution with C %% 128 == 0 and N %% 128 == 0", name);
 
         if (!a.Xp) {
             char nm[112];
@@ -697,7 +688,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         a = gemm_args(ly.out, b.ctx, D, R, dl.row_pos, b.x1, D);
         a.Rp = dl.dims; a.regime_rows = regime_rows;
         a.resid = b.x0; a.ldr = D; a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
-        const bool mxl = pl && ffn_terms == kFfnMx && ly.w1.w8 && ly.w1.wf;                      // this layer's FFN conv in the mx arithmetic?
+        const bool mxl = pl && ffn_terms == kFfnMx && ly.w1.wm;                                   // this layer's FFN conv in the mx arithmetic?
         const int f16t = (pl && ffn_terms && ffn_terms != kFfnMx && ly.w1.ktaps > 1 && ly.w1.wf) ? ffn_terms : 0;      // ... or on fp16 operands?
         if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; a.yp_f16 = mxl ? 2 : (f16t ? 1 : 0); a.yp_scale = mxl ? exp2f((float)ly.ka) : 1.f; }       // x1p feeds only that conv
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
@@ -707,7 +698,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         a.act_post = 1;
         if (pl) { a.Xp = b.x1p; a.Yp = hidp; a.yp_chunks = round_up(ly.w1.N, 32) / 32; }
         if (f16t) { a.f16_terms = f16t; a.Wb = ly.w1.wf; }
-        if (mxl) { a.mx = 1; a.Wb = ly.w1.wf; a.W8 = ly.w1.w8; a.mx_scale = scale_byte4(127 - ly.ka - 11); a.mx_scale_b = scale_byte4(127 - ly.w1.kw); }
+        if (mxl) { a.mx = 1; a.Wb = ly.w1.wm; a.mx_scale = scale_byte4(127 - ly.ka - 11); a.mx_scale_b = scale_byte4(127 - ly.w1.kw); }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.ffn2_ln", tag);
         a = gemm_args(ly.w2, b.hid, ly.w1.N, R, dl.row_pos, b.x0, D);
@@ -911,18 +902,18 @@ struct Loader {
             g.wb = pb;
             hipMemsetAsync(pb, 0, wb_elems * 2, s);
         }
-        if (f16_image && k == kMxTaps && parts == 1 && !linear && g.N % 128 == 0) {      // "mx" mode: fp8 correction image (gemm_mx.h)
+        if (f16_image && k > 1 && parts == 1 && !linear && g.N % 128 == 0 && C % 128 == 0 && bn_prefix.empty()) {      // "mx" mode: its weight image (gemm_mx.h)
             const fs2_tensor_desc* d = get(wnames[0], {Neach, C, k});
             if (!d) return g;
             if (!absmax_scratch && hipMalloc((void**)&absmax_scratch, 16) != hipSuccess) { if (!rc) rc = fail(h, FS2_ERR_HIP, "hipMalloc failed"); return g; }
             g.kw = fp8_scale_exponent(device_absmax(s, (const float*)d->data, (int64_t)Neach * C * k, absmax_scratch));
-            const size_t bytes = mx_w8_bytes(Npad, nchunks);
-            void* p8 = nullptr;
-            if (hipMalloc(&p8, bytes) != hipSuccess) { if (!rc) rc = fail(h, FS2_ERR_HIP, "hipMalloc of fp8 weights failed"); return g; }
-            h->allocs.push_back(p8);
-            g.w8 = p8;
-            hipLaunchKernelGGL(repack_weight_mx8, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, s, (const float*)d->data, g.N, C, Npad, nchunks, g.kw,
-                               reinterpret_cast<unsigned char*>(p8));
+            const size_t bytes = mx_image_bytes(Npad, C, k);
+            void* pm = nullptr;
+            if (hipMalloc(&pm, bytes) != hipSuccess) { if (!rc) rc = fail(h, FS2_ERR_HIP, "hipMalloc of the mx weight image failed"); return g; }
+            h->allocs.push_back(pm);
+            g.wm = pm;
+            hipLaunchKernelGGL(repack_weight_mx, dim3((unsigned)((bytes / 2 + 255) / 256)), dim3(256), 0, s, (const float*)d->data, g.N, C, k, Npad, g.kw,
+                               reinterpret_cast<unsigned short*>(pm));
         }
         if (f16_image) {
             void* pf = nullptr;
@@ -986,7 +977,7 @@ void load_stack(Loader& L, Stack& st, const std::string& pre, int nlayers, int D
             ly.cat_a = L.gemm({p + ".concat_linear.weight"}, {}, D, D, 1, true, "", false, /*col_off=*/D, /*src_cols=*/2 * D);
         }
         ly.ln1g = L.copy(p + ".norm1.weight", {D}); ly.ln1b = L.copy(p + ".norm1.bias", {D});
-        if (ly.w1.w8 && ly.ln1g && ly.ln1b && L.absmax_scratch) {      // a-priori bound of the LayerNorm output that feeds the FFN conv
+        if (ly.w1.wm && ly.ln1g && ly.ln1b && L.absmax_scratch) {      // a-priori bound of the LayerNorm output that feeds the FFN conv
             const float gm = device_absmax(L.s, ly.ln1g, D, L.absmax_scratch), bm = device_absmax(L.s, ly.ln1b, D, L.absmax_scratch);
             ly.ka = fp8_scale_exponent(std::sqrt((float)D) * gm + bm);
         }
@@ -1595,7 +1586,7 @@ int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
     ABI_CHECK(nullptr, "fs2_op_conv_gemm", o, fs2_op_gemm_args);
     if (!o->x || !o->w || o->R <= 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_conv_gemm: bad arguments");
     if (o->precision < FS2_PREC_FP32 || o->precision > FS2_PREC_MIX_MX) return fail(nullptr, FS2_ERR_ARG, "unknown precision %d", o->precision);
-    const bool mx = o->precision == FS2_PREC_MIX_MX;   // THIS operator in the fp16 + block-scaled-fp8 arithmetic (9-tap convolutions)
+    const bool mx = o->precision == FS2_PREC_MIX_MX;   // THIS operator in the fp16 + block-scaled-fp8 arithmetic (convolutions, C % 128 == 0)
     const int f16t = mx ? 1 : ffn_f16_terms(o->precision);      // mixed modes: THIS operator on fp16 operands with 2 / 1 MFMAs per fragment pair
     hipStream_t s = (hipStream_t)stream;
     Gemm g; g.N = o->N; g.C = o->C; g.ktaps = o->ktaps; g.Cpad = round_up(o->C, kBK);
@@ -1635,16 +1626,16 @@ int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
     a.xp_scratch = xps;
     a.f16_terms = mx ? 0 : f16t;
     if (mx) {
-        if (o->ktaps != kMxTaps || Npad != o->N) return fail(nullptr, FS2_ERR_UNSUPPORTED, "the mx arithmetic needs a 9-tap convolution with N %% 128 == 0");
+        if (o->ktaps < 3 || Npad != o->N || o->C % 128 != 0) return fail(nullptr, FS2_ERR_UNSUPPORTED, "the mx arithmetic needs a convolution with C %% 128 == 0 and N %% 128 == 0");
         unsigned* scr = nullptr;
         OP_TRY(tmp.alloc((void**)&scr, 16));
         const int ka = fp8_scale_exponent(device_absmax(s, o->x, (int64_t)o->R * o->C, scr));
         const int kw = fp8_scale_exponent(device_absmax(s, o->w, (int64_t)o->N * o->C * o->ktaps, scr));
-        void* w8 = nullptr;
-        const size_t bytes = mx_w8_bytes(Npad, nchunks);
-        OP_TRY(tmp.alloc(&w8, bytes));
-        hipLaunchKernelGGL(repack_weight_mx8, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, s, o->w, o->N, o->C, Npad, nchunks, kw, reinterpret_cast<unsigned char*>(w8));
-        a.mx = 1; a.W8 = w8; a.yp_scale = exp2f((float)ka); a.mx_scale = scale_byte4(127 - ka - 11); a.mx_scale_b = scale_byte4(127 - kw);
+        void* wm = nullptr;
+        const size_t bytes = mx_image_bytes(Npad, o->C, o->ktaps);
+        OP_TRY(tmp.alloc(&wm, bytes));
+        hipLaunchKernelGGL(repack_weight_mx, dim3((unsigned)((bytes / 2 + 255) / 256)), dim3(256), 0, s, o->w, o->N, o->C, o->ktaps, Npad, kw, reinterpret_cast<unsigned short*>(wm));
+        a.mx = 1; a.Wb = wm; a.yp_scale = exp2f((float)ka); a.mx_scale = scale_byte4(127 - ka - 11); a.mx_scale_b = scale_byte4(127 - kw);
     }
     return launch_gemm(nullptr, s, "op.conv_gemm", a, base_precision(o->precision));      // (tmp drains the stream and frees)
 }

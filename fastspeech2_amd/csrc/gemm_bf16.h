@@ -25,6 +25,8 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x8_t a, const bf16x8_t b, cons
     if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 // Barrier that also covers this wave's outstanding LDS-DMA (global_load_lds counts on vmcnt).  hipcc normally emits the
@@ -69,6 +71,13 @@ __device__ __forceinline__ SplitPair split8(const float4& p, const float4& q) {
 }
 
 __device__ __forceinline__ int swz(int row, int slot) { return (row << 7) + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+// the operand of one block-scaled 16x16x128 MFMA on e4m3 data: the 16-byte slots g and 4 + g of LDS row `row` as registers 0-3 | 4-7
+__device__ __forceinline__ v8i_t lds_frag8(const char* base, int row, int g) {
+    const v4i_t x0 = *reinterpret_cast<const v4i_t*>(base + swz(row, g));
+    const v4i_t x1 = *reinterpret_cast<const v4i_t*>(base + swz(row, 4 + g));
+    return __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
 // Channel order inside a 32-channel chunk of the bf16 images: the 16-byte slot g (k-group of lane-group g) holds channels
 // {4g..4g+3} and {16+4g..16+4g+3}.  Any permutation is legal as long as A and B agree (the MFMA sums over k); with this one a

@@ -87,9 +87,16 @@ __device__ long long g_gemm_phase[8];
 #define FS2_GT(i)
 #endif
 
-// F16: operands are fp16 images; NSPLIT = 3: lo*hi + hi*lo + hi*hi, 2: lo*hi + hi*hi (the weight's lo half is never read), 1: hi*hi.
-template <int NSPLIT, int BM, bool K1, bool F16 = false>
+// ARITH = 1: operands are fp16 images; NSPLIT = 3: lo*hi + hi*lo + hi*hi, 2: lo*hi + hi*hi (the weight's lo half is never read), 1: hi*hi.
+// ARITH = 2 ("mx", conv form only, NSPLIT ignored): operands are mx planes / the mx weight image (gemm_mx.h).  A 128-byte unit is then
+// either 64 fp16 channels (the first half of the units of a row: two fp16 MFMAs per fragment pair, a.w ~ ah.wh) or 128 e4m3 channels
+// (the second half: ONE block-scaled K = 128 MFMA per fragment pair; first the units of ra8 against wh8, then those of ah8 against
+// rw8 -- the two cross terms).  Everything else -- DMA pattern, swizzle, double buffering, barriers, the two 16-byte LDS reads per
+// fragment -- is exactly the split-bf16 loop: per k-step 64 fp16 MFMAs or 32 scaled ones (both 1024 MFMA cycles) instead of 96.
+template <int NSPLIT, int BM, bool K1, int ARITH = 0>
 __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs a) {
+    constexpr bool F16 = ARITH == 1;
+    static_assert(ARITH != 2 || !K1, "the mx arithmetic exists for the conv form");
     constexpr int MT = BM / 32;               // 16-row MFMA tiles per wave (wave tile = BM/2 x 64)
     constexpr int AROWS = pl_arows<BM, K1>();
     extern __shared__ __attribute__((aligned(16))) char smem_p[];
@@ -181,49 +188,103 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     long long tprev = __builtin_readcyclecounter();
     const long long t_begin = tprev, r_begin = __builtin_amdgcn_s_memrealtime();      // shader cycles vs the constant 100-MHz counter
 #endif
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-        for (int tap = 0; tap < ktaps; ++tap, ++it) {
-            dma_barrier();     // DMA of step `it` landed; every wave is done with step it-1
-            FS2_GT(0)
-            if (it + 1 < it_end) {
-                dma_B(it + 1, (it + 1) & 1);
-                if (K1) dma_A(it + 1, (it + 1) & 1);
-            }
-            FS2_GT(1)
-            const char* As = As0 + (K1 ? (it & 1) : 0) * (AROWS * 128);
-            const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
-            bf16x8_t bh[4], bl[4];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n = wn * 64 + nt * 16 + lp;
-                bh[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
-                if (NSPLIT == 3) bl[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
-            }
-            if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int r = wm * (BM / 2) + mt * 16 + lp + tap;
-                const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
-                if (NSPLIT >= 2) {
-                    const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(al, bh[nt], acc[mt][nt]);
+    // the k-loop over chunks [cb, ce) x taps; KIND (compile time) picks the MFMA body: 0 = split arithmetic per NSPLIT / ARITH, 1 = mx units
+    // of fp16 channels, 2 = mx units of e4m3 channels.  (Two instantiations for ARITH = 2 instead of a branch inside one loop: with both
+    // bodies in one loop hipcc ran out of registers -- 108 spilled at BM = 256.)
+    auto k_loop = [&](auto kind_tag, const int cb, const int ce) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        for (int chunk = cb; chunk < ce; ++chunk) {
+            for (int tap = 0; tap < ktaps; ++tap, ++it) {
+                dma_barrier();     // DMA of step `it` landed; every wave is done with step it-1
+                FS2_GT(0)
+                if (it + 1 < it_end) {
+                    dma_B(it + 1, (it + 1) & 1);
+                    if (K1) dma_A(it + 1, (it + 1) & 1);
                 }
-                if (NSPLIT == 3) {
+                FS2_GT(1)
+                const char* As = As0 + (K1 ? (it & 1) : 0) * (AROWS * 128);
+                const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
+                if constexpr (KIND == 2) {
+                    // a fragment = the two 16-byte pieces slot lg | slot 4 + lg of a row = registers 0-3 | 4-7 of the scaled MFMA
+                    // (k 16 lg .. + 15 | 64 + 16 lg .. + 15, measured in tools/probes/mx_probe.hip)
+                    v8i_t bv[4];
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(ah, bl[nt], acc[mt][nt]);
+                    for (int nt = 0; nt < 4; ++nt) bv[nt] = lds_frag8(Bs, wn * 64 + nt * 16 + lp, lg);
+                    if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const v8i_t av = lds_frag8(As, wm * (BM / 2) + mt * 16 + lp + tap, lg);
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv[nt], acc[mt][nt], 0, 0, 0, a.mx_scale, 0, a.mx_scale_b);
+                    }
+                    if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
+                } else if constexpr (KIND == 1) {
+                    // 64 fp16 channels per unit: slot lg = k 8 lg .. + 7 of the first 32, slot 4 + lg the same of the second 32
+                    bf16x8_t b0[4], b1[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int n = wn * 64 + nt * 16 + lp;
+                        b0[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
+                        b1[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
+                    }
+                    if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int r = wm * (BM / 2) + mt * 16 + lp + tap;
+                        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
+                        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<true>(a0, b0[nt], acc[mt][nt]);
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<true>(a1, b1[nt], acc[mt][nt]);
+                    }
+                    if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
+                } else {
+                    bf16x8_t bh[4], bl[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int n = wn * 64 + nt * 16 + lp;
+                        bh[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
+                        if (NSPLIT == 3) bl[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
+                    }
+                    if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int r = wm * (BM / 2) + mt * 16 + lp + tap;
+                        const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
+                        if (NSPLIT >= 2) {
+                            const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
+#pragma unroll
+                            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(al, bh[nt], acc[mt][nt]);
+                        }
+                        if (NSPLIT == 3) {
+#pragma unroll
+                            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(ah, bl[nt], acc[mt][nt]);
+                        }
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(ah, bh[nt], acc[mt][nt]);
+                    }
+                    if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
                 }
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(ah, bh[nt], acc[mt][nt]);
-            }
-            if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
-            FS2_GT(2)
-            if (!K1 && tap == ktaps - 1 && chunk + 1 < c_end) {
-                __syncthreads();              // every wave has read its last fragments of this chunk's A tile
-                dma_A(chunk + 1, 0);
-                FS2_GT(3)
+                FS2_GT(2)
+                if (!K1 && tap == ktaps - 1 && chunk + 1 < c_end) {
+                    __syncthreads();              // every wave has read its last fragments of this chunk's A tile
+                    dma_A(chunk + 1, 0);
+                    FS2_GT(3)
+                }
             }
         }
+    };
+    if constexpr (ARITH == 2) {
+#ifndef FS2_MX_SKIP      // (tools/probes/mx_conv_probe.hip: 1 = no fp16 units, 2 = no e4m3 units)
+#define FS2_MX_SKIP 0
+#endif
+        if (FS2_MX_SKIP != 1) k_loop(std::integral_constant<int, 1>{}, c_begin, nchunks >> 1);
+        if (FS2_MX_SKIP == 1) { it = (nchunks >> 1) * ktaps; __syncthreads(); dma_A(nchunks >> 1, 0); dma_B(it, it & 1); }
+        if (FS2_MX_SKIP != 2) k_loop(std::integral_constant<int, 2>{}, nchunks >> 1, c_end);
+    } else {
+        k_loop(std::integral_constant<int, 0>{}, c_begin, c_end);
     }
 #ifdef FS2_GEMM_TIMING
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {

@@ -151,23 +151,24 @@ def test_conv_gemm_fp16_two_and_one_term(case, precision, bm, fs2_option):
 
 
 @pytest.mark.parametrize("bm", ["64", "128", "256"])
-@pytest.mark.parametrize("shape", [(300, 384, 1024), (517, 256, 1024), (90, 384, 128)])
+@pytest.mark.parametrize("shape", [(300, 384, 1024, 9), (517, 256, 1024, 9), (90, 384, 128, 9), (260, 256, 256, 3), (150, 128, 128, 5)])
 def test_conv_gemm_mx_fp16_plus_block_scaled_fp8(shape, bm, fs2_option):
-    """gemm_mx_conv9: a.w = ah.wh (fp16 MFMA) + ra.wh + ah.rw (v_mfma_scale_f32_16x16x128_f8f6f4 on fp8 operands with static scales):
-    the 9-tap FFN convolution at ~2.2 MFMA-equivalents per product.  Accuracy class of split-bf16 (tolerance: 5 x measured)."""
+    """The "mx" arithmetic (gemm_mx.h; gemm_pl_bf16<.., ARITH = 2> on mx planes and the mx weight image): a.w = ah.wh (fp16 MFMA) +
+    ra.wh + ah.rw (v_mfma_scale_f32_16x16x128_f8f6f4 on e4m3 operands with static scales, K = 128 channels of one tap): two
+    MFMA-equivalents per product, any odd kernel size, C % 128 == 0.  Accuracy class of split-bf16 (tolerance: 5 x measured)."""
     fs2_option("FS2_BM", bm)
     from tests import ops_binding as ops
     from tests.conftest import record_measurement
-    R, C, N = shape
-    rs = np.random.RandomState(R + C + N)
+    R, C, N, k = shape
+    rs = np.random.RandomState(R + C + N + k)
     dev = _dev()
     x = _rand(rs, R, C) * torch.from_numpy(rs.uniform(0.2, 2.0, size=(1, C)).astype(np.float32))      # per-channel gains, LayerNorm-like
-    w = _rand(rs, N, C, 9, scale=1.0 / np.sqrt(C * 9))
+    w = _rand(rs, N, C, k, scale=1.0 / np.sqrt(C * k))
     bias = _rand(rs, N, scale=0.5)
     y = torch.relu(_ref_conv(x.double(), w.double(), bias.double())).float()
     yo, _ = ops.conv_gemm(x.to(dev), w.to(dev), bias.to(dev), None, False, None, 1e-5, 1, None, None, precision="mix_mx")
     err = float((yo.cpu() - y).abs().max())
-    print("mix_mx R=%d C=%d N=%d BM=%s max-abs %.2e" % (R, C, N, bm, err))
+    print("mix_mx R=%d C=%d N=%d k=%d BM=%s max-abs %.2e" % (R, C, N, k, bm, err))
     record_measurement("gemm_mix_mx", err)
     assert torch.isfinite(yo).all() and err < 2.5e-4
 

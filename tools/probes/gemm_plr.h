@@ -19,7 +19,7 @@
 // what a denser instruction stream gains in cycles the power manager takes back in clock.  Not adopted.
 // Weight image (frag_weight_image): [panel = n / 128][k-step][wn 2][n-tile 4][hi | lo][lane 64] x 16 B, where lane (lr, lg) of
 // n-tile nt holds channel 128 panel + 64 wn + 4 lr + nt, k-group lg: the bytes gemm_pl_bf16's lane reads from its LDS image.
-// The image pointer travels in GemmArgs::W8 (unused by the bf16 kernels).
+// The image pointer travels in GemmArgs::xp_scratch (unused by the kernels themselves).
 #pragma once
 #include <type_traits>
 #include "gemm_planes.h"
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void gemm_plr_bf16(GemmArgs a) {
         }
     };
     // B fragments of k-step `it`: 8 (NSPLIT == 3) or 4 vectors per lane, 1 KB contiguous per instruction
-    const bf16x8_t* b_src0 = reinterpret_cast<const bf16x8_t*>(a.W8) + ((size_t)blockIdx.x * niter * 2 + wn) * 512 + lane;
+    const bf16x8_t* b_src0 = reinterpret_cast<const bf16x8_t*>(a.xp_scratch) + ((size_t)blockIdx.x * niter * 2 + wn) * 512 + lane;
     bf16x8_t bh[2][4], bl[2][4];
     auto load_B = [&](int it, auto set_tag) {
         constexpr int S = decltype(set_tag)::value;

@@ -43,7 +43,7 @@ int run_plr(GemmArgs a, size_t wbytes) {
     const long long nvec = (long long)Npad * niter * 8;
     hipLaunchKernelGGL(frag_weight_image, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<const __bf16*>(a.Wb), Npad, niter, reinterpret_cast<uint4*>(wf));
     float* y2; CK(hipMalloc(&y2, (size_t)a.R * a.N * 4));
-    GemmArgs b = a; b.W8 = wf; b.Y = y2;
+    GemmArgs b = a; b.xp_scratch = wf; b.Y = y2;
     dim3 grid((a.N + 127) / 128, (a.R + BM - 1) / BM);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {

@@ -1,0 +1,104 @@
+// Phase timing of the conv form of gemm_pl_bf16 in the split-bf16 (ARITH 0, NSPLIT 3) and the mx (ARITH 2) arithmetic on synthetic
+// operands: ticks wave 0 of workgroup (0,0) spends per k-step in barrier wait | DMA issue | fragment reads + MFMAs | A refill, the
+// kernel time and the effective shader clock.  Random bit patterns (finite in every format they are read as).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DFS2_GEMM_TIMING [-DFS2_MX_SKIP=1|2] -I fastspeech2_amd/csrc tools/probes/mx_conv_probe.hip -o tools/probes/mx_conv_probe.bin
+//   mx_conv_probe.bin R C N ktaps BM arith(0|2)
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "gemm_mx.h"
+using namespace fs2;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+template <int NS, int BM, int AR>
+int run(GemmArgs a, int steps) {
+    constexpr size_t lds = pl_lds_bytes<BM, false>();
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pl_bf16<NS, BM, false, AR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((a.N + 127) / 128, (a.R + BM - 1) / BM);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+#ifdef FS2_GEMM_TIMING
+        long long zero[8] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_phase), zero, sizeof zero));
+#endif
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((gemm_pl_bf16<NS, BM, false, AR>), grid, dim3(256), lds, 0, a);
+        hipEventRecord(e1); CK(hipDeviceSynchronize());
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        long long ph[8] = {0};
+#ifdef FS2_GEMM_TIMING
+        CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_gemm_phase), sizeof ph));
+#endif
+        printf("arith=%d BM=%d k=%d R=%d C=%d N=%d: %.1f us, %u workgroups x %d steps; per step: barrier %lld | dma issue %lld | reads+mfma %lld | A refill (per step) %lld ticks\n",
+               AR, BM, a.ktaps, a.R, a.C, a.N, ms * 1e3, grid.x * grid.y, steps, ph[0] / steps, ph[1] / steps, ph[2] / steps, ph[3] / steps);
+        if (ph[7]) printf("   k-loop of workgroup 0: %lld shader cycles in %.2f us (100-MHz counter) -> %.0f MHz effective clock\n", ph[6], ph[7] * 0.01, ph[6] / (ph[7] * 0.01));
+    }
+    return 0;
+}
+int main(int argc, char** argv) {
+    const int R = argc > 1 ? atoi(argv[1]) : 30208, C = argc > 2 ? atoi(argv[2]) : 384, N = argc > 3 ? atoi(argv[3]) : 1024;
+    const int k = argc > 4 ? atoi(argv[4]) : 9, BM = argc > 5 ? atoi(argv[5]) : 256, AR = argc > 6 ? atoi(argv[6]) : 2;
+    const int nchunks = C / 32, Npad = (N + 127) / 128 * 128;
+    bool a_scale_real = false;
+    // every 128-byte unit is filled with patterns that are ordinary numbers as bf16 / fp16 (|x| in [1, 2)) and as e4m3 bytes (0x38-0x3f = 1 .. 1.875, random sign)
+    std::vector<unsigned char> h((size_t)(R + 64) * nchunks * 128), w((size_t)Npad * nchunks * k * 128);
+    auto fill = [&](std::vector<unsigned char>& v, int units_per_row) {
+        for (size_t i = 0; i < v.size(); i += 2) {
+            const size_t unit = (i / 128) % units_per_row;
+            const bool fp8 = AR == 2 && (int)(unit / (units_per_row / nchunks)) >= nchunks / 2;
+            if (fp8) { v[i] = 0x38 + (rand() & 7) + ((rand() & 1) << 7); v[i + 1] = 0x38 + (rand() & 7) + ((rand() & 1) << 7); }
+            else { const unsigned short s = (AR == 2 ? 0x3c00 : 0x3f80) + (rand() & (AR == 2 ? 0x3ff : 0x7f)) + ((rand() & 1) ? 0x8000 : 0); memcpy(&v[i], &s, 2); }
+        }
+    };
+    const int mode = argc > 7 ? atoi(argv[7]) : 0;      // 0: low-entropy patterns, 1: values distributed like the model's operands
+    if (mode == 0 || AR != 2) { fill(h, nchunks); fill(w, nchunks * k); }
+    else {
+        auto e4m3 = [](float x) -> unsigned char {      // round to nearest even, saturating at 448
+            const unsigned char sgn = x < 0 ? 0x80 : 0; x = fabsf(x);
+            if (!(x < 448.f)) return sgn | 0x7e;
+            if (x < 0.0009765625f) return sgn;          // < half the smallest subnormal (2^-9 / 2 ... close enough for a probe)
+            int e; float m = frexpf(x, &e);               // x = m 2^e, m in [0.5, 1)
+            int E = e - 1 + 7;                            // biased exponent of 1.f x 2^(e-1)
+            if (E <= 0) { const int q = (int)lrintf(x * 512.f); return sgn | (unsigned char)(q > 7 ? 8 : q); }      // subnormal: steps of 2^-9
+            int q = (int)lrintf((m * 2.f - 1.f) * 8.f);
+            if (q == 8) { q = 0; ++E; }
+            if (E > 15 || (E == 15 && q == 7)) return sgn | 0x7e;
+            return sgn | (unsigned char)((E << 3) | q);
+        };
+        auto gauss = [] { float s = 0; for (int i = 0; i < 12; ++i) s += (float)rand() / RAND_MAX; return s - 6.f; };
+        const int nmain = C / 64, ncorr = C / 128;
+        auto put = [&](unsigned char* row, int tapless_c, float v, float sc) {      // one channel of one row: fp16 | residual e4m3 | hi e4m3
+            const _Float16 hh = (_Float16)v;
+            memcpy(row + 2 * tapless_c, &hh, 2);
+            row[2 * C + tapless_c] = e4m3((v - (float)hh) * sc * 2048.f);
+            row[3 * C + tapless_c] = e4m3((float)hh * sc);
+        };
+        (void)nmain; (void)ncorr;
+        for (size_t r = 0; r < (size_t)(R + 64); ++r)
+            for (int c = 0; c < C; ++c) put(&h[r * 4 * C], c, gauss(), 16.f);
+        // weights: per n [unit][tap][128 B]; unit order fp16 | wh8 (meets ra8) | rw8 (meets ah8)
+        const float wb_ = 1.f / sqrtf((float)C * k);
+        for (int n = 0; n < Npad; ++n)
+            for (int t = 0; t < k; ++t)
+                for (int c = 0; c < C; ++c) {
+                    const float v = ((float)rand() / RAND_MAX * 2.f - 1.f) * wb_;
+                    const _Float16 hh = (_Float16)v;
+                    unsigned char* base = &w[(size_t)n * nchunks * k * 128];
+                    memcpy(base + ((size_t)(c / 64) * k + t) * 128 + 2 * (c % 64), &hh, 2);
+                    base[((size_t)(C / 64 + c / 128) * k + t) * 128 + c % 128] = e4m3((float)hh * 16384.f);
+                    base[((size_t)(C / 64 + C / 128 + c / 128) * k + t) * 128 + c % 128] = e4m3((v - (float)hh) * 16384.f * 2048.f);
+                }
+        a_scale_real = true;
+    }
+    void *xp, *wb; float* y;
+    CK(hipMalloc(&xp, h.size())); CK(hipMalloc(&wb, w.size())); CK(hipMalloc(&y, (size_t)R * N * 4));
+    CK(hipMemcpy(xp, h.data(), h.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(wb, w.data(), w.size(), hipMemcpyHostToDevice));
+    GemmArgs a;
+    memset(&a, 0, sizeof a);
+    a.C = C; a.Cpad = nchunks * 32; a.ktaps = k; a.N = N; a.R = R; a.W = (const float*)wb; a.Wb = wb; a.Xp = xp; a.Y = y; a.ldy = N; a.x_scale = 1.f;
+    a.mx_scale = 0x7f7f7f7f; a.mx_scale_b = 0x7f7f7f7f;
+    if (a_scale_real) { a.mx_scale = (127 - 4 - 11) * 0x01010101; a.mx_scale_b = (127 - 14) * 0x01010101; }
+    const int steps = nchunks * k;
+    if (AR == 2) return BM == 256 ? run<1, 256, 2>(a, steps) : (BM == 128 ? run<1, 128, 2>(a, steps) : run<1, 64, 2>(a, steps));
+    return BM == 256 ? run<3, 256, 0>(a, steps) : (BM == 128 ? run<3, 128, 0>(a, steps) : run<3, 64, 0>(a, steps));
+}
