@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "mix_f16x2": 2500.0, "mix_f16x1": 2500.0, "mix_mx": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
 DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3", "bf16": "bf16", "mix_f16x2": "bf16x3 (FFN conv: f16x2)", "mix_f16x1": "bf16x3 (FFN conv: f16)",
-              "mix_mx": "bf16x3 (FFN conv: f16 + block-scaled fp8 corrections)"}
+              "mix_mx": "bf16x3 (FFN conv: f16 x f16 + block-scaled e4m3 cross terms)"}
 MFMA_PER_PRODUCT = {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1, "mix_mx": 2.0}       # MFMAs issued per algorithmic product in the dominant kernel (the FFN conv)
 HBM_PEAK_GBPS = 8000.0
 WORKLOAD_TEXT = {
@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None, help="c1..c5 (default: c3 on one GPU, c5 = 128 utterances per GPU on several)")
-    ap.add_argument("--precision", default=os.environ.get("FS2_PRECISION", "bf16x3"))
+    ap.add_argument("--precision", default=os.environ.get("FS2_PRECISION", "mix_mx"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-kernels", action="store_true", help="print the per-kernel hipEvent table to stderr")
     ap.add_argument("--graph", action="store_true", help="replay the forward as one captured HIP graph (single GPU; the launch-bound small configs)")
@@ -146,12 +146,12 @@ def main():
 
     from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
     from fastspeech2_amd.parallel import ShardedSynthesizer, shard_indices, path_flops
-    from fastspeech2_amd.synthetic import portable_state_dict, bias_durations, make_batch
+    from fastspeech2_amd.synthetic import portable_state_dict, ljspeech_durations, make_batch
 
     hp = default_hparams()
     odim = hp.audio.num_mels
     model = FeedForwardTransformer(N_PHONEME_SYMBOLS, odim, hp).eval()
-    sd = bias_durations(portable_state_dict(model.state_dict(), seed=0))
+    sd = ljspeech_durations(portable_state_dict(model.state_dict(), seed=0))
     model.load_state_dict(sd)
     model = model.to(dev)
     model.precision = args.precision
@@ -271,7 +271,7 @@ def main():
         # what the chip sustains on random bf16 operands with nothing but MFMAs in flight (tools/probes/mfma_shape_probe.hip,
         # profiles/r02_mfma_shape_power_probe.txt: 1.8-2.1 PFLOP/s at 1.8-2.1 GHz, power-limited); `peak` stays the nominal figure
         roofline["measured_mfma_peak"] = 1950.0
-        roofline["issued_frac_of_measured_peak"] = round(achieved * {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1}.get(args.precision, 1) / 1950.0, 4) \
+        roofline["issued_frac_of_measured_peak"] = round(achieved * {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1, "mix_mx": 2}.get(args.precision, 1) / 1950.0, 4) \
             if dom_name.endswith("ffn1") or args.precision == "bf16x3" else None
     try:    # HBM-side bytes per launch: rocprofv3 PMC passes of this same command (tools/profile_round.sh -> profiles/)
         tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
@@ -318,7 +318,7 @@ def main():
             "ms_per_step_median": round(statistics.median(step_ms), 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[args.precision],
             "data": "synthetic",
-            "config": {"workload": "%s%s; default.yaml dims, free-running, random-init weights (seed 0), duration bias ln(1+7.87)"
+            "config": {"workload": "%s%s; default.yaml dims, free-running, random-init weights (seed 0), duration bias calibrated to 7.87 frames/phoneme"
                                    % (WORKLOAD_TEXT[workload], " -- here %d utterances on %d GPU(s)" % (B, world) if workload == "c5" else ""),
                        "utterances": B, "utterances_per_gpu": [len(p) for p in parts], "valid_frames_per_step": total_frames,
                        "phonemes": int(il.sum()),

@@ -260,7 +260,6 @@ hipError_t launch_pl_t(hipStream_t s, const GemmArgs& a) {
     hipLaunchKernelGGL((gemm_pl_bf16<NSPLIT, BM, K1, ARITH>), grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }
-
 template <int NSPLIT, int NB>
 hipError_t launch_row8_t(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
@@ -315,7 +314,7 @@ hipError_t launch_pl(hipStream_t s, const GemmArgs& a) {
     const long nN = (a.N + kB16BN - 1) / kB16BN;
     int bm;
     if (a.ktaps == 1) {
-        bm = (force == 64 || force == 128) ? force : 64;     // measured (c3): 64-row tiles win for every k = 1 GEMM (3 workgroups/CU hide the DMA round trips)
+        bm = (force == 128) ? force : 64;     // measured (c3): 64-row tiles win for every k = 1 GEMM (3 workgroups/CU hide the DMA round trips)
         return bm == 128 ? launch_pl_t<NSPLIT, 128, true>(s, a) : launch_pl_t<NSPLIT, 64, true>(s, a);
     }
     bm = force ? force : (nN * ((rows + 255) / 256) >= 512 ? 256 : (nN * ((rows + 127) / 128) >= 400 ? 128 : 64));

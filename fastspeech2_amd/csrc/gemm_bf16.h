@@ -38,6 +38,15 @@ __device__ __forceinline__ void dma_barrier() {
     __syncthreads();
 }
 
+// Counted form for ring-buffered loops (LDS-DMA completes in issue order): this wave's LDS-DMA except its newest N instructions has landed (and its LDS
+// reads returned), then the workgroup meets.
+template <int N> __device__ __forceinline__ void dma_wait_barrier() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // One LDS-DMA instruction (64 lanes x 16 B -> 1 KB of LDS at byte offset lds_off, which must be wave-uniform).  Written as
 // inline asm so that M0 comes from an SGPR operand: with __builtin_amdgcn_global_load_lds hipcc keeps the LDS pointer in a
 // VGPR and emits v_readfirstlane + s_mov m0 per instruction, and the phase probe (tools/probes/gemm_probe.hip) showed the 4-6

@@ -193,82 +193,72 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     // bodies in one loop hipcc ran out of registers -- 108 spilled at BM = 256.)
     auto k_loop = [&](auto kind_tag, const int cb, const int ce) {
         constexpr int KIND = decltype(kind_tag)::value;
+        constexpr bool kNeedB1 = KIND != 0 || NSPLIT == 3;      // second 16-byte piece of the B rows (lo half / second k-half)
         for (int chunk = cb; chunk < ce; ++chunk) {
             for (int tap = 0; tap < ktaps; ++tap, ++it) {
                 dma_barrier();     // DMA of step `it` landed; every wave is done with step it-1
                 FS2_GT(0)
-                if (it + 1 < it_end) {
+#ifndef FS2_PROBE_DMA      // (ablations for tools/probes/mx_conv_probe.hip: 1 = weight stages only on even steps, 2 = none, 3 = no A refills)
+#define FS2_PROBE_DMA 0
+#endif
+                if (it + 1 < it_end && !(FS2_PROBE_DMA == 1 && (it & 1)) && FS2_PROBE_DMA != 2) {
                     dma_B(it + 1, (it + 1) & 1);
                     if (K1) dma_A(it + 1, (it + 1) & 1);
                 }
                 FS2_GT(1)
                 const char* As = As0 + (K1 ? (it & 1) : 0) * (AROWS * 128);
                 const char* Bs = Bs0 + (it & 1) * (kB16BN * 128);
-                if constexpr (KIND == 2) {
-                    // a fragment = the two 16-byte pieces slot lg | slot 4 + lg of a row = registers 0-3 | 4-7 of the scaled MFMA
-                    // (k 16 lg .. + 15 | 64 + 16 lg .. + 15, measured in tools/probes/mx_probe.hip)
-                    v8i_t bv[4];
+                // a fragment = the two 16-byte pieces slot lg | slot 4 + lg of a row: split arithmetic: hi | lo of k 8 lg .. + 7; mx unit of fp16
+                // channels: k 8 lg .. + 7 | 32 + 8 lg ..; mx unit of e4m3 channels: registers 0-3 | 4-7 of the scaled MFMA = k 16 lg .. + 15 |
+                // 64 + 16 lg .. (measured in tools/probes/mx_probe.hip)
+                bf16x8_t b0[4], b1[4];
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) bv[nt] = lds_frag8(Bs, wn * 64 + nt * 16 + lp, lg);
-                    if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int n = wn * 64 + nt * 16 + lp;
+                    b0[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
+                    if (kNeedB1) b1[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
+                }
+                if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
+                // A fragments: the swizzle term ((row >> 1) & 7) of row wm BM/2 + 16 mt + lp + tap does not depend on mt, so the two pieces of
+                // m-tile mt sit at ONE per-step base address + mt * 2048 (an immediate offset of the LDS read) -- hipcc does not see this and
+                // spent ~9 VALU instructions per m-tile and step on the addresses (PMC: 2.2 VALU per MFMA in the mx loop)
+                const int rb = wm * (BM / 2) + lp + tap;
+                const char* ap0 = As + (rb << 7) + ((lg ^ ((rb >> 1) & 7)) << 4);
+                const char* ap1 = As + (rb << 7) + (((4 + lg) ^ ((rb >> 1) & 7)) << 4);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const v8i_t av = lds_frag8(As, wm * (BM / 2) + mt * 16 + lp + tap, lg);
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(ap0 + mt * 2048);
+                    if constexpr (KIND == 2) {
+                        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(ap1 + mt * 2048);
+                        const v8i_t av = __builtin_shufflevector(__builtin_bit_cast(v4i_t, a0), __builtin_bit_cast(v4i_t, a1), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                        for (int nt = 0; nt < 4; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv[nt], acc[mt][nt], 0, 0, 0, a.mx_scale, 0, a.mx_scale_b);
-                    }
-                    if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
-                } else if constexpr (KIND == 1) {
-                    // 64 fp16 channels per unit: slot lg = k 8 lg .. + 7 of the first 32, slot 4 + lg the same of the second 32
-                    bf16x8_t b0[4], b1[4];
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        const int n = wn * 64 + nt * 16 + lp;
-                        b0[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
-                        b1[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
-                    }
-                    if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const int r = wm * (BM / 2) + mt * 16 + lp + tap;
-                        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
-                        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const v8i_t bv = __builtin_shufflevector(__builtin_bit_cast(v4i_t, b0[nt]), __builtin_bit_cast(v4i_t, b1[nt]), 0, 1, 2, 3, 4, 5, 6, 7);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, acc[mt][nt], 0, 0, 0, a.mx_scale, 0, a.mx_scale_b);
+                        }
+                    } else if constexpr (KIND == 1) {
+                        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(ap1 + mt * 2048);
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<true>(a0, b0[nt], acc[mt][nt]);
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<true>(a1, b1[nt], acc[mt][nt]);
-                    }
-                    if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
-                } else {
-                    bf16x8_t bh[4], bl[4];
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        const int n = wn * 64 + nt * 16 + lp;
-                        bh[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
-                        if (NSPLIT == 3) bl[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
-                    }
-                    if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const int r = wm * (BM / 2) + mt * 16 + lp + tap;
-                        const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
+                    } else {
                         if (NSPLIT >= 2) {
-                            const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
+                            const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(ap1 + mt * 2048);
 #pragma unroll
-                            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(al, bh[nt], acc[mt][nt]);
+                            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(al, b0[nt], acc[mt][nt]);
                         }
                         if (NSPLIT == 3) {
 #pragma unroll
-                            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(ah, bl[nt], acc[mt][nt]);
+                            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(a0, b1[nt], acc[mt][nt]);
                         }
 #pragma unroll
-                        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(ah, bh[nt], acc[mt][nt]);
+                        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16<F16>(a0, b0[nt], acc[mt][nt]);
                     }
-                    if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
                 }
+                if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
                 FS2_GT(2)
-                if (!K1 && tap == ktaps - 1 && chunk + 1 < c_end) {
+                if (!K1 && tap == ktaps - 1 && chunk + 1 < c_end && FS2_PROBE_DMA != 3) {
                     __syncthreads();              // every wave has read its last fragments of this chunk's A tile
                     dma_A(chunk + 1, 0);
                     FS2_GT(3)
@@ -368,11 +358,15 @@ namespace fs2 {
 template <int NSPLIT, int MT, int NT>
 __device__ __forceinline__ void row8_mfma_step(const char* Bs, int nrow, int lg, const bf16x8_t (&ah)[MT], const bf16x8_t (&al)[MT], f32x4 (&acc)[MT][NT]) {
     constexpr int kReads = NSPLIT == 3 ? 4 : 2, kMfma = 2 * MT * NSPLIT;
+    // LDS row nrow + 16 n of n-tile n: the swizzle term ((row >> 1) & 7) does not depend on n, so the hi / lo pieces of every n-tile sit at
+    // one base address + n * 2048 (an immediate offset) -- spelled out because hipcc recomputed the swizzle per read (PMC: 3 VALU per MFMA)
+    const char* bp0 = Bs + swz(nrow, lg);
+    const char* bp1 = Bs + swz(nrow, 4 + lg);
     bf16x8_t bh[2][2], bl[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        bh[0][u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(nrow + u * 16, lg));
-        if (NSPLIT == 3) bl[0][u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(nrow + u * 16, 4 + lg));
+        bh[0][u] = *reinterpret_cast<const bf16x8_t*>(bp0 + u * 2048);
+        if (NSPLIT == 3) bl[0][u] = *reinterpret_cast<const bf16x8_t*>(bp1 + u * 2048);
     }
     // hipcc's scheduler otherwise sinks every read to just before its first use, whatever the source order: pin the order
     // [first B reads] ([next B reads] [this group's MFMAs])*   (the A reads sit in the caller, before s_setprio)
@@ -383,9 +377,8 @@ __device__ __forceinline__ void row8_mfma_step(const char* Bs, int nrow, int lg,
         if (n2 + 2 < NT) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int n = nrow + (n2 + 2 + u) * 16;
-                bh[nb][u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
-                if (NSPLIT == 3) bl[nb][u] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
+                bh[nb][u] = *reinterpret_cast<const bf16x8_t*>(bp0 + (n2 + 2 + u) * 2048);
+                if (NSPLIT == 3) bl[nb][u] = *reinterpret_cast<const bf16x8_t*>(bp1 + (n2 + 2 + u) * 2048);
             }
             __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
         }
@@ -484,10 +477,9 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
         const char* Bs = As + BM * 128;
         bf16x8_t ah[MT], al[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int r = wm * 32 + mt * 16 + lp;
-            ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
-            if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
+        for (int mt = 0; mt < MT; ++mt) {      // (one base address + mt * 2048: the swizzle term does not depend on mt)
+            ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * 32 + lp, lg) + mt * 2048);
+            if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * 32 + lp, 4 + lg) + mt * 2048);
         }
         if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
         row8_mfma_step<NSPLIT, MT, NT>(Bs, wn * (64 * NB) + lp, lg, ah, al, acc);
@@ -674,10 +666,9 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
             const char* Bs = Bs0 + (it & 1) * (BN * 128);
             bf16x8_t ah[MT], al[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int r = wm * 32 + mt * 16 + lp + tap;
-                ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
-                if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
+            for (int mt = 0; mt < MT; ++mt) {      // (one base address + mt * 2048: the swizzle term does not depend on mt)
+                ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * 32 + lp + tap, lg) + mt * 2048);
+                if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * 32 + lp + tap, 4 + lg) + mt * 2048);
             }
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
             row8_mfma_step<NSPLIT, MT, NT>(Bs, wn * (64 * NB) + lp, lg, ah, al, acc);
@@ -884,10 +875,9 @@ __global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
             const char* Bs = As + BM * 128;
             bf16x8_t ah[MT], al[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int r = wm * 32 + mt * 16 + lp;
-                ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, lg));
-                if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(r, 4 + lg));
+            for (int mt = 0; mt < MT; ++mt) {      // (one base address + mt * 2048: the swizzle term does not depend on mt)
+                ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * 32 + lp, lg) + mt * 2048);
+                if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * 32 + lp, 4 + lg) + mt * 2048);
             }
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
             row8_mfma_step<NSPLIT, MT, NT>(Bs, wn * (64 * NB) + lp, lg, ah, al, acc);

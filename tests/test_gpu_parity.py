@@ -139,7 +139,7 @@ def test_c2_mixed_modes_vs_oracle(env, precision):
         d = max(_maxabs(r["before"], o["before"]), _maxabs(r["after"], o["after"]))
         print("c2 [%s] mel max-abs vs oracle %.2e" % (precision, d))
         record_measurement("c2_mel_maxabs_" + precision, d)
-        assert d <= (2.5e-4 if precision == "mix_mx" else MEL_TOL)      # mix_mx is a parity-grade mode (split-bf16 class)
+        assert d <= (3e-5 if precision == "mix_mx" else MEL_TOL)      # mix_mx is a parity-grade mode: split-bf16 class (2.3e-5), measured 2.5e-5
     finally:
         model.precision = "fp32"
 
@@ -210,7 +210,10 @@ def test_batch_invariance_and_order(env):
     assert torch.equal(solo[0], a1[5, : int(ol1[5])])
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+C3_TOL = {"mix_mx": 5e-5}      # the default arithmetic of bench.py must stay in split-bf16's accuracy class (measured 2.8e-5; bf16x3 2.1e-5)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "mix_mx"])
 def test_full_size_c3_properties(env, precision):
     model = env[0]
     model.precision = precision
@@ -243,7 +246,7 @@ def _c3_body(env, precision):
         assert torch.equal(idx, torch.repeat_interleave(torch.arange(T), b["ds"][i, :T])), i          # bit-exact
         o = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], is_inference=True, d_override=b["ds"][i:i + 1, :T])
         d = float((after_h[i, :L] - o["after"][0]).abs().max())
-        assert d <= MEL_TOL, (i, d)
+        assert d <= C3_TOL.get(precision, MEL_TOL), (i, d)
         worst = max(worst, d)
     print("c3 [%s] all %d utterances (%d frames): worst mel max-abs vs oracle %.2e" % (precision, after.shape[0], int(b["olens"].sum()), worst))
     record_measurement("c3_all_utterances_mel_maxabs_" + precision, worst)
@@ -835,3 +838,75 @@ def test_integration_md_usage_runs_end_to_end(env):
     assert mel.shape == ref.shape and torch.equal(mel, ref)
     want = O.padded_forward(sdb, cfg, ids.cpu().unsqueeze(0), [ids.numel()], is_inference=True)["after"][0]
     assert _maxabs(mel, want) <= MEL_TOL
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "mix_mx"])
+def test_c1_single_utterance_inference_vs_oracle(env, precision):
+    """BASELINE config c1 -- the reference's production call (inference.py:111-130): ONE utterance of 80 phonemes through
+    `inference(x)`, free-running, with LJSpeech-like durations.  First call: host-driven layout (frame count read back between encode
+    and decode); second call: device-driven layout inside the capacities learnt from the first.  Both equal the CPU oracle's
+    free-running result: durations and frame count exactly, mel within the tolerance; the two layouts are bit-identical."""
+    model, sd, cfg, O = env
+    from fastspeech2_amd.synthetic import make_batch, ljspeech_durations
+    from tests.conftest import record_measurement
+    b = make_batch("c1")
+    x = b["xs"][0]
+    sdl = ljspeech_durations(sd)
+    o = O.padded_forward(sdl, cfg, x.unsqueeze(0), torch.tensor([80]), is_inference=True)
+    L = int(o["olens"][0])
+    assert 400 <= L <= 900, L                       # ~8 frames per phoneme
+    model.load_state_dict(sdl)
+    model.precision = precision
+    model._frames_per_token = None                  # the first call of a fresh model is synchronous (host-driven layout)
+    try:
+        with torch.no_grad():
+            m1 = model.inference(x.cuda())
+            assert model._frames_per_token is not None
+            m2 = model.inference(x.cuda())          # device-driven layout
+            r = model._run(x.cuda().unsqueeze(0), torch.tensor([80]), is_inference=True, want=("after",))
+    finally:
+        model.precision = "fp32"
+        model.load_state_dict(sd)
+        model._frames_per_token = None
+    assert m1.shape == (L, 80) and torch.equal(m1, m2)
+    assert torch.equal(r["d_int"][0].cpu(), o["d_outs"][0])
+    d = _maxabs(m1, o["after"][0])
+    print("c1 [%s] %d frames, mel max-abs vs oracle %.2e" % (precision, L, d))
+    record_measurement("c1_mel_maxabs_" + precision, d)
+    assert d <= C3_TOL.get(precision, MEL_TOL)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "mix_mx"])
+def test_c3_free_running_decisions_equal_the_oracles(env, precision):
+    """BASELINE config c3 with NOTHING forced (what bench.py times): every data-dependent integer decision of the GPU path --
+    durations clamp(round(exp(x) - 1), 0), frame counts, pitch / energy bucket indices -- equals the CPU oracle's own free-running
+    decision on all 64 utterances, and the mels agree within the tolerance.  (duration_predictor.py:77-84, variance_predictor.py:154-159)"""
+    model, sd, cfg, O = env
+    from fastspeech2_amd.synthetic import make_batch, ljspeech_durations
+    b = make_batch("c3")
+    xs, il = b["xs"], b["ilens"]
+    sdl = ljspeech_durations(sd)
+    model.load_state_dict(sdl)
+    model.precision = precision
+    try:
+        with torch.no_grad():
+            r = model._run(xs.cuda(), il, is_inference=True, want=("after", "qe", "qp"))
+    finally:
+        model.precision = "fp32"
+        model.load_state_dict(sd)
+    after, qe, qp, dint = r["after"].cpu(), r["qe"].cpu().long(), r["qp"].cpu().long(), r["d_int"].cpu()
+    tok = frames = 0
+    worst = 0.0
+    for i in range(xs.shape[0]):
+        T = int(il[i])
+        o = O.padded_forward(sdl, cfg, xs[i:i + 1, :T], il[i:i + 1], is_inference=True)
+        L = int(o["olens"][0])
+        assert torch.equal(dint[i, :T], o["d_outs"][0]), i
+        assert int(r["olens"][i]) == L
+        assert torch.equal(qe[i, :L], o["qe"][0]) and torch.equal(qp[i, :L], o["qp"][0]), i
+        worst = max(worst, float((after[i, :L] - o["after"][0]).abs().max()))
+        tok += T
+        frames += L
+    print("c3 free-running [%s]: %d phonemes -> %d frames (%.2f per phoneme), every decision equal, mel max-abs %.2e" % (precision, tok, frames, frames / tok, worst))
+    assert 7.6 <= frames / tok <= 8.1               # LJSpeech-like (SURVEY 8d: 7.87)
+    assert worst <= C3_TOL.get(precision, MEL_TOL)

@@ -1,14 +1,15 @@
 // Phase timing of the conv form of gemm_pl_bf16 in the split-bf16 (ARITH 0, NSPLIT 3) and the mx (ARITH 2) arithmetic on synthetic
 // operands: ticks wave 0 of workgroup (0,0) spends per k-step in barrier wait | DMA issue | fragment reads + MFMAs | A refill, the
 // kernel time and the effective shader clock.  Random bit patterns (finite in every format they are read as).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DFS2_GEMM_TIMING [-DFS2_MX_SKIP=1|2] -I fastspeech2_amd/csrc tools/probes/mx_conv_probe.hip -o tools/probes/mx_conv_probe.bin
-//   mx_conv_probe.bin R C N ktaps BM arith(0|2)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DFS2_GEMM_TIMING] [-DFS2_MX_SKIP=1|2] [-DFS2_PROBE_DMA=1|2|3] -I fastspeech2_amd/csrc -I tools/probes tools/probes/mx_conv_probe.hip -o tools/probes/mx_conv_probe.bin
+//   mx_conv_probe.bin R C N ktaps BM(64|128|256; 512 = the rejected 8-wave kernel) arith(0|2) data(0 low entropy | 1 model-like)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "gemm_mx.h"
+#include "rejected/gemm_planes8.h"      // the 8-wave ring-buffered variant (measured slower: DESIGN.md section 4)
 using namespace fs2;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 template <int NS, int BM, int AR>
@@ -32,6 +33,21 @@ int run(GemmArgs a, int steps) {
         printf("arith=%d BM=%d k=%d R=%d C=%d N=%d: %.1f us, %u workgroups x %d steps; per step: barrier %lld | dma issue %lld | reads+mfma %lld | A refill (per step) %lld ticks\n",
                AR, BM, a.ktaps, a.R, a.C, a.N, ms * 1e3, grid.x * grid.y, steps, ph[0] / steps, ph[1] / steps, ph[2] / steps, ph[3] / steps);
         if (ph[7]) printf("   k-loop of workgroup 0: %lld shader cycles in %.2f us (100-MHz counter) -> %.0f MHz effective clock\n", ph[6], ph[7] * 0.01, ph[6] / (ph[7] * 0.01));
+    }
+    return 0;
+}
+template <int NS, int AR>
+int run8(GemmArgs a, int steps) {
+    constexpr size_t lds = pl8_lds_bytes<4>();
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pl8_conv<NS, AR, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((a.N + 127) / 128, (a.R + 511) / 512);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((gemm_pl8_conv<NS, AR, 4>), grid, dim3(512), lds, 0, a);
+        hipEventRecord(e1); CK(hipDeviceSynchronize());
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("pl8 arith=%d k=%d R=%d C=%d N=%d: %.1f us, %u workgroups x %d steps\n", AR, a.ktaps, a.R, a.C, a.N, ms * 1e3, grid.x * grid.y, steps);
     }
     return 0;
 }
@@ -99,6 +115,7 @@ int main(int argc, char** argv) {
     a.mx_scale = 0x7f7f7f7f; a.mx_scale_b = 0x7f7f7f7f;
     if (a_scale_real) { a.mx_scale = (127 - 4 - 11) * 0x01010101; a.mx_scale_b = (127 - 14) * 0x01010101; }
     const int steps = nchunks * k;
+    if (BM == 512) return AR == 2 ? run8<1, 2>(a, steps) : run8<3, 0>(a, steps);
     if (AR == 2) return BM == 256 ? run<1, 256, 2>(a, steps) : (BM == 128 ? run<1, 128, 2>(a, steps) : run<1, 64, 2>(a, steps));
     return BM == 256 ? run<3, 256, 0>(a, steps) : (BM == 128 ? run<3, 128, 0>(a, steps) : run<3, 64, 0>(a, steps));
 }
