@@ -74,6 +74,7 @@ struct Options {
     int qkv8 = -1;       // FS2_QKV8     force / forbid the 8-wave fused QKV projection
     int nosplitk = 0;    // FS2_NOSPLITK no split-K of the token-level k = 1 GEMMs
     int f32_rows = 0;    // FS2_F32_ROWS row-complete fp32 GEMM for LayerNorm-terminated ops
+    int mt8 = -1;        // FS2_MT8      m-tiles per wave of the 8-wave row-complete kernels (2 | 3: 128 / 192-row workgroups)
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -83,7 +84,7 @@ Options& opts() {
     static Options o = [] {
         Options x;
         x.bm = env_int("FS2_BM", -1); x.row8 = env_int("FS2_ROW8", -1); x.qkv8 = env_int("FS2_QKV8", -1);
-        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0;
+        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1);
         return x;
     }();
     return o;
@@ -260,31 +261,59 @@ hipError_t launch_pl_t(hipStream_t s, const GemmArgs& a) {
     hipLaunchKernelGGL((gemm_pl_bf16<NSPLIT, BM, K1, ARITH>), grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }
-template <int NSPLIT, int NB>
+// Tile height of the 8-wave row-complete kernels (one workgroup per CU): 64 MT rows, MT = 2 or 3.  A launch of T tiles takes ceil(T / #CUs)
+// rounds, and a nearly empty second round costs as much as a full one (c3 at 7.87 frames per phoneme: 286 tiles of 128 rows = 256 + 30).
+// Same-box A/B: a 192-row tile costs 1.55-1.9 x a 128-row one (its epilogue spills), so it pays exactly when it turns two rounds into one
+// (c3: dec.ffn2_ln 0.174 -> 0.134 ms, step 5.68 -> 5.34 ms; c4, 15 rounds against 10: 68.0 -> 70.8 ms, so not there).  Results do not depend on MT.
+constexpr int kCus = 256;
+inline int row8_mt(long rows) {
+    const long t128 = (rows + 127) / 128, t192 = (rows + 191) / 192;
+    return (t128 > kCus && t192 <= kCus) ? 3 : 2;
+}
+
+template <int NSPLIT, int NB, int MT>
 hipError_t launch_row8_t(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
-    constexpr size_t lds = row8_lds_bytes<NB>();
-    allow_lds(reinterpret_cast<const void*>(&gemm_row8_bf16<NSPLIT, NB>), lds, attr);
-    hipLaunchKernelGGL((gemm_row8_bf16<NSPLIT, NB>), dim3((a.R + 127) / 128), dim3(512), lds, s, a);
+    constexpr size_t lds = row8_lds_bytes<NB, MT>();
+    allow_lds(reinterpret_cast<const void*>(&gemm_row8_bf16<NSPLIT, NB, MT>), lds, attr);
+    hipLaunchKernelGGL((gemm_row8_bf16<NSPLIT, NB, MT>), dim3((a.R + 64 * MT - 1) / (64 * MT)), dim3(512), lds, s, a);
     return hipGetLastError();
 }
-
 template <int NSPLIT, int NB>
+hipError_t launch_row8(hipStream_t s, const GemmArgs& a) {
+    const int mt = opts().mt8 > 0 ? opts().mt8 : row8_mt(a.R);
+    if (mt >= 3) return launch_row8_t<NSPLIT, NB, 3>(s, a);
+    return launch_row8_t<NSPLIT, NB, 2>(s, a);
+}
+
+template <int NSPLIT, int NB, int MT>
 hipError_t launch_row8c_t(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
-    constexpr size_t lds = row8c_lds_bytes<NB>();
-    allow_lds(reinterpret_cast<const void*>(&gemm_row8c_bf16<NSPLIT, NB>), lds, attr);
-    hipLaunchKernelGGL((gemm_row8c_bf16<NSPLIT, NB>), dim3((a.R + 127) / 128), dim3(512), lds, s, a);
+    constexpr size_t lds = row8c_lds_bytes<NB, MT>();
+    allow_lds(reinterpret_cast<const void*>(&gemm_row8c_bf16<NSPLIT, NB, MT>), lds, attr);
+    hipLaunchKernelGGL((gemm_row8c_bf16<NSPLIT, NB, MT>), dim3((a.R + 64 * MT - 1) / (64 * MT)), dim3(512), lds, s, a);
     return hipGetLastError();
 }
-
 template <int NSPLIT, int NB>
+hipError_t launch_row8c(hipStream_t s, const GemmArgs& a) {
+    const int mt = opts().mt8 > 0 ? opts().mt8 : row8_mt(a.R);
+    if (mt >= 3) return launch_row8c_t<NSPLIT, NB, 3>(s, a);
+    return launch_row8c_t<NSPLIT, NB, 2>(s, a);
+}
+
+template <int NSPLIT, int NB, int MT>
 hipError_t launch_qkv8_t(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
-    constexpr size_t lds = row8_lds_bytes<NB>();
-    allow_lds(reinterpret_cast<const void*>(&gemm_qkv8_bf16<NSPLIT, NB>), lds, attr);
-    hipLaunchKernelGGL((gemm_qkv8_bf16<NSPLIT, NB>), dim3((a.Rvt + 127) / 128), dim3(512), lds, s, a);
+    constexpr size_t lds = qkv8_lds_bytes<NB, MT>();
+    allow_lds(reinterpret_cast<const void*>(&gemm_qkv8_bf16<NSPLIT, NB, MT>), lds, attr);
+    hipLaunchKernelGGL((gemm_qkv8_bf16<NSPLIT, NB, MT>), dim3((a.Rvt + 64 * MT - 1) / (64 * MT)), dim3(512), lds, s, a);
     return hipGetLastError();
+}
+template <int NSPLIT, int NB>
+hipError_t launch_qkv8(hipStream_t s, const GemmArgs& a) {
+    const int mt = opts().mt8 > 0 ? opts().mt8 : row8_mt(a.Rvt);
+    if (mt >= 3) return launch_qkv8_t<NSPLIT, NB, 3>(s, a);
+    return launch_qkv8_t<NSPLIT, NB, 2>(s, a);
 }
 
 // Fused QKV projection on the 8-wave structure when there is about a CU's worth of 128-row tiles (FS2_QKV8=0|1 forces the choice)
@@ -307,6 +336,24 @@ bool use_row8(const GemmArgs& a) {
 
 // Tile height of the planes kernel: the largest one that still gives every CU its 2-3 resident workgroups
 // (FS2_BM=64|128|256 forces one; k = 1 GEMMs have no 256-row form: two 256-row A buffers would not fit two workgroups per CU).
+// In the 256-row regime the conv kernel runs two workgroups per CU: a launch of T y-tiles per N tile takes ceil(T nN / 512) rounds, and a nearly
+// empty last round costs as much as a full one (c3 at 7.87 frames per phoneme: 143 x 8 tiles = 2.2 rounds -> 3).  The smallest tile height (a
+// multiple of 32 rows, 160 .. 256) that keeps that number of rounds spreads the rows evenly instead (191 tiles of 192 rows: 3 full rounds of
+// tiles that are a quarter shorter).  Results do not depend on the tile height.
+inline int conv_bm_balanced(long rows, long nN) {
+    const long ypr = std::max<long>(1, 2 * kCus / nN);
+    const long rounds = std::max<long>(1, (rows + 256 * ypr - 1) / (256 * ypr));
+    const long h = (rows + rounds * ypr - 1) / (rounds * ypr);
+    return (int)std::min<long>(256, std::max<long>(160, (h + 31) / 32 * 32));
+}
+template <int NSPLIT, int ARITH>
+hipError_t launch_pl_tall(hipStream_t s, const GemmArgs& a, int bm) {
+    if (bm <= 160) return launch_pl_t<NSPLIT, 160, false, ARITH>(s, a);
+    if (bm <= 192) return launch_pl_t<NSPLIT, 192, false, ARITH>(s, a);
+    if (bm <= 224) return launch_pl_t<NSPLIT, 224, false, ARITH>(s, a);
+    return launch_pl_t<NSPLIT, 256, false, ARITH>(s, a);
+}
+
 template <int NSPLIT>
 hipError_t launch_pl(hipStream_t s, const GemmArgs& a) {
     const int force = opts().bm > 0 ? opts().bm : 0;
@@ -318,7 +365,11 @@ hipError_t launch_pl(hipStream_t s, const GemmArgs& a) {
         return bm == 128 ? launch_pl_t<NSPLIT, 128, true>(s, a) : launch_pl_t<NSPLIT, 64, true>(s, a);
     }
     bm = force ? force : (nN * ((rows + 255) / 256) >= 512 ? 256 : (nN * ((rows + 127) / 128) >= 400 ? 128 : 64));
-    if (bm == 256) return launch_pl_t<NSPLIT, 256, false>(s, a);
+    if (bm > 128) {
+        if (!force && a.ksplit <= 1) bm = conv_bm_balanced(rows, nN);
+        if constexpr (NSPLIT == 3) return launch_pl_tall<3, 0>(s, a, bm);
+        else return launch_pl_t<NSPLIT, 256, false>(s, a);
+    }
     return bm == 128 ? launch_pl_t<NSPLIT, 128, false>(s, a) : launch_pl_t<NSPLIT, 64, false>(s, a);
 }
 
@@ -326,8 +377,8 @@ hipError_t launch_pl(hipStream_t s, const GemmArgs& a) {
 hipError_t launch_mx(hipStream_t s, const GemmArgs& a) {
     const int force = opts().bm > 0 ? opts().bm : 0;
     const long nN = (a.N + kB16BN - 1) / kB16BN;
-    const int bm = force ? force : (nN * ((a.R + 255) / 256) >= 512 ? 256 : (nN * ((a.R + 127) / 128) >= 400 ? 128 : 64));
-    if (bm == 256) return launch_pl_t<1, 256, false, 2>(s, a);
+    int bm = force ? force : (nN * ((a.R + 255) / 256) >= 512 ? 256 : (nN * ((a.R + 127) / 128) >= 400 ? 128 : 64));
+    if (bm > 128) return launch_pl_tall<1, 2>(s, a, force ? bm : conv_bm_balanced(a.R, nN));
     return bm == 128 ? launch_pl_t<1, 128, false, 2>(s, a) : launch_pl_t<1, 64, false, 2>(s, a);
 }
 
@@ -411,14 +462,14 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
             } else if (a.f16_terms) {
                 e = a.f16_terms == 3 ? launch_pl_f16<3>(s, t) : (a.f16_terms == 2 ? launch_pl_f16<2>(s, t) : launch_pl_f16<1>(s, t));
             } else if (use_qkv8(t)) {
-                if (a.att_D == 384) e = (precision == FS2_PREC_BF16X3) ? launch_qkv8_t<3, 3>(s, t) : launch_qkv8_t<1, 3>(s, t);
-                else e = (precision == FS2_PREC_BF16X3) ? launch_qkv8_t<3, 2>(s, t) : launch_qkv8_t<1, 2>(s, t);
+                if (a.att_D == 384) e = (precision == FS2_PREC_BF16X3) ? launch_qkv8<3, 3>(s, t) : launch_qkv8<1, 3>(s, t);
+                else e = (precision == FS2_PREC_BF16X3) ? launch_qkv8<3, 2>(s, t) : launch_qkv8<1, 2>(s, t);
             } else if (row8 && a.ktaps > 1) {
-                if (a.N == 384) e = (precision == FS2_PREC_BF16X3) ? launch_row8c_t<3, 3>(s, t) : launch_row8c_t<1, 3>(s, t);
-                else e = (precision == FS2_PREC_BF16X3) ? launch_row8c_t<3, 2>(s, t) : launch_row8c_t<1, 2>(s, t);
+                if (a.N == 384) e = (precision == FS2_PREC_BF16X3) ? launch_row8c<3, 3>(s, t) : launch_row8c<1, 3>(s, t);
+                else e = (precision == FS2_PREC_BF16X3) ? launch_row8c<3, 2>(s, t) : launch_row8c<1, 2>(s, t);
             } else if (row8) {
-                if (a.N == 384) e = (precision == FS2_PREC_BF16X3) ? launch_row8_t<3, 3>(s, t) : launch_row8_t<1, 3>(s, t);
-                else e = (precision == FS2_PREC_BF16X3) ? launch_row8_t<3, 2>(s, t) : launch_row8_t<1, 2>(s, t);
+                if (a.N == 384) e = (precision == FS2_PREC_BF16X3) ? launch_row8<3, 3>(s, t) : launch_row8<1, 3>(s, t);
+                else e = (precision == FS2_PREC_BF16X3) ? launch_row8<3, 2>(s, t) : launch_row8<1, 2>(s, t);
             } else e = (precision == FS2_PREC_BF16X3) ? launch_pl<3>(s, t) : launch_pl<1>(s, t);
         }
         if (e == hipSuccess && rows_pass) {
@@ -1760,6 +1811,7 @@ int fs2_set_option(const char* name, int32_t value) {
     else if (n == "FS2_QKV8") o.qkv8 = value;
     else if (n == "FS2_NOSPLITK") o.nosplitk = value > 0;
     else if (n == "FS2_F32_ROWS") o.f32_rows = value > 0;
+    else if (n == "FS2_MT8") o.mt8 = value;
     else return fail(nullptr, FS2_ERR_ARG, "fs2_set_option: unknown option %s", name);
     return FS2_OK;
 }

@@ -400,11 +400,14 @@ __device__ __forceinline__ void row8_mfma_step(const char* Bs, int nrow, int lg,
     }
 }
 
-template <int NB> constexpr size_t row8_lds_bytes() { return 2 * (size_t)(128 + 128 * NB) * 128; }
+// MT = 16-row m-tiles per wave: the workgroup takes 64 MT rows (128 / 192).  With one workgroup per CU a launch of T 128-row tiles
+// takes ceil(T / 256) rounds -- 286 tiles (c3 at 7.87 frames per phoneme) ran as 256 + 30 and cost two rounds; the launcher picks the
+// smallest tile height that keeps the number of rounds (191 tiles of 192 rows: one round).  Results do not depend on MT.
+template <int NB, int MT = 2> constexpr size_t row8_lds_bytes() { return 2 * (size_t)(64 * MT + 128 * NB) * 128; }
 
-template <int NSPLIT, int NB>
+template <int NSPLIT, int NB, int MT = 2>
 __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
-    constexpr int MT = 2, NT = 4 * NB, BM = 128, BN = 128 * NB;
+    constexpr int NT = 4 * NB, BM = 64 * MT, BN = 128 * NB, RW = 16 * MT;      // RW: rows per wave
     constexpr int STAGE = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem_r[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
 
     const int niter = a.Cpad / 32;
     const int jrow = lane >> 3, jslot = lane & 7;
-    // A: 16 one-KB instructions per stage, wave w issues q = w and w + 8 (tile rows 8q + jrow)
+    // A: 8 MT one-KB instructions per stage, wave w issues q = w + 8i, i < MT (tile rows 8q + jrow)
     const int sA = jslot ^ (jrow >> 1) ^ ((wave & 1) << 2);
     const int arow0 = m0 + wave * 8 + jrow;
     const __bf16* a_src0 = Xp + (size_t)arow0 * niter * 64 + sA * 8;
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
         char* as = smem_r + buf * STAGE + wave * 1024;
         const __bf16* asrc = a_src0 + (size_t)it * 64;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MT; ++i) {
             const bool ok = arow0 + 64 * i < a.R;
             const void* sp = ok ? static_cast<const void*>(asrc + i * a_qstride) : static_cast<const void*>(g_zero16);
             __builtin_amdgcn_global_load_lds(sp, (lds_void_t*)(as + i * 8192), 16, 0, 0);
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rowi[mt][r] = m0 + wm * 32 + mt * 16 + rperm(lg * 4 + r);
+        for (int r = 0; r < 4; ++r) rowi[mt][r] = m0 + wm * RW + mt * 16 + rperm(lg * 4 + r);
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
         const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + col0 + 64 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -478,8 +481,8 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
         bf16x8_t ah[MT], al[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {      // (one base address + mt * 2048: the swizzle term does not depend on mt)
-            ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * 32 + lp, lg) + mt * 2048);
-            if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * 32 + lp, 4 + lg) + mt * 2048);
+            ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * RW + lp, lg) + mt * 2048);
+            if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * RW + lp, 4 + lg) + mt * 2048);
         }
         if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
         row8_mfma_step<NSPLIT, MT, NT>(Bs, wn * (64 * NB) + lp, lg, ah, al, acc);
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
             }
             rsum[mt][r] = wave16_sum(s);
         }
-    float* red = reinterpret_cast<float*>(smem_r);      // [2 passes][8 waves][32 rows]
+    float* red = reinterpret_cast<float*>(smem_r);      // [2 passes][8 waves][RW rows]
     float mean[MT][4], rstd[MT][4];
     if (a.ln_g) {
         __syncthreads();                                // operand buffers are dead
@@ -515,13 +518,13 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[wave * 32 + mt * 16 + lg * 4 + r] = rsum[mt][r];
+                for (int r = 0; r < 4; ++r) red[wave * RW + mt * 16 + lg * 4 + r] = rsum[mt][r];
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                mean[mt][r] = (rsum[mt][r] + red[(wave ^ 1) * 32 + mt * 16 + lg * 4 + r]) / (float)a.N;
+                mean[mt][r] = (rsum[mt][r] + red[(wave ^ 1) * RW + mt * 16 + lg * 4 + r]) / (float)a.N;
                 float q = 0.f;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) { const float d = acc[mt][n][r] - mean[mt][r]; q += d * d; }
@@ -531,13 +534,13 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[256 + wave * 32 + mt * 16 + lg * 4 + r] = rsum[mt][r];
+                for (int r = 0; r < 4; ++r) red[8 * RW + wave * RW + mt * 16 + lg * 4 + r] = rsum[mt][r];
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                rstd[mt][r] = 1.f / sqrtf((rsum[mt][r] + red[256 + (wave ^ 1) * 32 + mt * 16 + lg * 4 + r]) / (float)a.N + a.ln_eps);
+                rstd[mt][r] = 1.f / sqrtf((rsum[mt][r] + red[8 * RW + (wave ^ 1) * RW + mt * 16 + lg * 4 + r]) / (float)a.N + a.ln_eps);
     }
     const float alpha = (a.pe && a.pe_alpha) ? a.pe_alpha[0] : 1.f;
     // the two forms (with / without the positional-encoding add) are separate straight-line bodies: no load sits behind a
@@ -584,11 +587,11 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
 //   * 8 waves as 4(M) x 2(N), wave tile 32 rows x 64 NB columns, as gemm_row8_bf16; one workgroup per CU.
 //   * A: one tile of 128 + halo rows per 32-channel chunk, shared by the taps (single buffer, refilled behind a barrier at the
 //     end of a chunk, exactly as in gemm_pl_bf16's conv form); B: one 128 NB x 128 B tile per (chunk, tap), double-buffered.
-template <int NB> constexpr size_t row8c_lds_bytes() { return (size_t)(128 + kMaxHalo) * 128 + 2 * (size_t)(128 * NB) * 128; }
+template <int NB, int MT = 2> constexpr size_t row8c_lds_bytes() { return (size_t)(64 * MT + kMaxHalo) * 128 + 2 * (size_t)(128 * NB) * 128; }
 
-template <int NSPLIT, int NB>
+template <int NSPLIT, int NB, int MT = 2>
 __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
-    constexpr int MT = 2, NT = 4 * NB, BM = 128, BN = 128 * NB;
+    constexpr int NT = 4 * NB, BM = 64 * MT, BN = 128 * NB, RW = 16 * MT;
     constexpr int AROWS = BM + kMaxHalo;
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     char* As = smem_c;
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rowi[mt][r] = m0 + wm * 32 + mt * 16 + rperm(lg * 4 + r);
+        for (int r = 0; r < 4; ++r) rowi[mt][r] = m0 + wm * RW + mt * 16 + rperm(lg * 4 + r);
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
         const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + col0 + 64 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -667,8 +670,8 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
             bf16x8_t ah[MT], al[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {      // (one base address + mt * 2048: the swizzle term does not depend on mt)
-                ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * 32 + lp + tap, lg) + mt * 2048);
-                if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * 32 + lp + tap, 4 + lg) + mt * 2048);
+                ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * RW + lp + tap, lg) + mt * 2048);
+                if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * RW + lp + tap, 4 + lg) + mt * 2048);
             }
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
             row8_mfma_step<NSPLIT, MT, NT>(Bs, wn * (64 * NB) + lp, lg, ah, al, acc);
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
             }
             rsum[mt][r] = wave16_sum(s);
         }
-    float* red = reinterpret_cast<float*>(smem_c);      // [3 passes][8 waves][32 rows]
+    float* red = reinterpret_cast<float*>(smem_c);      // [3 passes][8 waves][RW rows]
     float mean[MT][4], rstd[MT][4];
     __syncthreads();                                    // operand buffers are dead
     if (a.ln_g) {
@@ -709,13 +712,13 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[wave * 32 + mt * 16 + lg * 4 + r] = rsum[mt][r];
+                for (int r = 0; r < 4; ++r) red[wave * RW + mt * 16 + lg * 4 + r] = rsum[mt][r];
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                mean[mt][r] = (rsum[mt][r] + red[(wave ^ 1) * 32 + mt * 16 + lg * 4 + r]) / (float)a.N;
+                mean[mt][r] = (rsum[mt][r] + red[(wave ^ 1) * RW + mt * 16 + lg * 4 + r]) / (float)a.N;
                 float q = 0.f;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) { const float d = acc[mt][n][r] - mean[mt][r]; q += d * d; }
@@ -725,13 +728,13 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[256 + wave * 32 + mt * 16 + lg * 4 + r] = rsum[mt][r];
+                for (int r = 0; r < 4; ++r) red[8 * RW + wave * RW + mt * 16 + lg * 4 + r] = rsum[mt][r];
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                rstd[mt][r] = 1.f / sqrtf((rsum[mt][r] + red[256 + (wave ^ 1) * 32 + mt * 16 + lg * 4 + r]) / (float)a.N + a.ln_eps);
+                rstd[mt][r] = 1.f / sqrtf((rsum[mt][r] + red[8 * RW + (wave ^ 1) * RW + mt * 16 + lg * 4 + r]) / (float)a.N + a.ln_eps);
     }
     float dsum[MT][4];
 #pragma unroll
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[512 + wave * 32 + mt * 16 + lg * 4 + r] = dsum[mt][r];
+                for (int r = 0; r < 4; ++r) red[16 * RW + wave * RW + mt * 16 + lg * 4 + r] = dsum[mt][r];
         __syncthreads();
         if (wn == 0 && lr == 0) {
             const float db = a.dot_b ? a.dot_b[0] : 0.f;
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = rowi[mt][r];
-                    if (row < a.R) a.dot_out[row] = pos[mt][r] >= 0 ? dsum[mt][r] + red[512 + (wave ^ 1) * 32 + mt * 16 + lg * 4 + r] + db : 0.f;
+                    if (row < a.R) a.dot_out[row] = pos[mt][r] >= 0 ? dsum[mt][r] + red[16 * RW + (wave ^ 1) * RW + mt * 16 + lg * 4 + r] + db : 0.f;
                 }
         }
     }
@@ -795,9 +798,13 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
 // k-step was 31 % DMA issue + 30 % barrier (tools/probes/gemm_probe.hip).  Q (x log2e / sqrt(d_k)) and K leave straight from the
 // registers as row-major split-bf16 planes [Rvt][2D]; V goes through LDS in three 128-column passes and leaves as V^T [D][Rvt]
 // (8 consecutive keys per 16-byte store).  Rows that are gaps or beyond R are written as zeros.
-template <int NSPLIT, int NB>
+template <int NB, int MT = 2> constexpr size_t qkv8_lds_bytes() {      // operand stages, or the [BM][132] fp32 tile of the V pass
+    return row8_lds_bytes<NB, MT>() > (size_t)64 * MT * kQkvLd * 4 ? row8_lds_bytes<NB, MT>() : (size_t)64 * MT * kQkvLd * 4;
+}
+
+template <int NSPLIT, int NB, int MT = 2>
 __global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
-    constexpr int MT = 2, NT = 4 * NB, BM = 128, BN = 128 * NB;
+    constexpr int NT = 4 * NB, BM = 64 * MT, BN = 128 * NB, RW = 16 * MT;
     constexpr int STAGE = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem_r[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -828,7 +835,7 @@ __global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
         char* as = smem_r + buf * STAGE + wave * 1024;
         const __bf16* asrc = a_src0 + (size_t)it * 64;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MT; ++i) {
             const bool ok = arow0 + 64 * i < a.R;
             const void* sp = ok ? static_cast<const void*>(asrc + i * a_qstride) : static_cast<const void*>(g_zero16);
             __builtin_amdgcn_global_load_lds(sp, (lds_void_t*)(as + i * 8192), 16, 0, 0);
@@ -847,7 +854,7 @@ __global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            rowi[mt][r] = m0 + wm * 32 + mt * 16 + rperm(lg * 4 + r);
+            rowi[mt][r] = m0 + wm * RW + mt * 16 + rperm(lg * 4 + r);
             rvalid[mt][r] = rowi[mt][r] < a.R && (a.row_pos == nullptr || a.row_pos[rowi[mt][r]] >= 0);
         }
     __bf16* qkh = reinterpret_cast<__bf16*>(a.qk_hi);
@@ -876,8 +883,8 @@ __global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
             bf16x8_t ah[MT], al[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {      // (one base address + mt * 2048: the swizzle term does not depend on mt)
-                ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * 32 + lp, lg) + mt * 2048);
-                if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * 32 + lp, 4 + lg) + mt * 2048);
+                ah[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * RW + lp, lg) + mt * 2048);
+                if (NSPLIT == 3) al[mt] = *reinterpret_cast<const bf16x8_t*>(As + swz(wm * RW + lp, 4 + lg) + mt * 2048);
             }
             if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
             row8_mfma_step<NSPLIT, MT, NT>(Bs, wn * (64 * NB) + lp, lg, ah, al, acc);
@@ -915,14 +922,14 @@ __global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const f32x4 v = f32x4{acc[mt][4 * g][r], acc[mt][4 * g + 1][r], acc[mt][4 * g + 2][r], acc[mt][4 * g + 3][r]};
-                            *reinterpret_cast<f32x4*>(tile + (wm * 32 + mt * 16 + rperm(lg * 4 + r)) * kQkvLd + (G & 1) * 64 + 4 * lr) =
+                            *reinterpret_cast<f32x4*>(tile + (wm * RW + mt * 16 + rperm(lg * 4 + r)) * kQkvLd + (G & 1) * 64 + 4 * lr) =
                                 rvalid[mt][r] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
                         }
                 }
                 __syncthreads();
                 // column c of the pass, rows 8j .. 8j+7: 4 consecutive lanes share a column (64-byte V^T segments)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2 * MT; ++u) {
                     const int idx = tid + u * 512;
                     const int c = (idx >> 2) & 127, j = ((idx >> 9) << 2) | (idx & 3);
                     const int row = m0 + 8 * j;

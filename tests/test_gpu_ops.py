@@ -99,7 +99,7 @@ def test_conv_gemm_fp32_row_complete_kernel(case, fs2_option):
     test_conv_gemm(case, "fp32")
 
 
-@pytest.mark.parametrize("bm", ["64", "128", "256"])
+@pytest.mark.parametrize("bm", ["64", "128", "160", "192", "224", "256"])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("case", CASES, ids=[c[-1] for c in CASES])
 def test_conv_gemm_planes_kernel_tile_heights(case, precision, bm, fs2_option):
@@ -112,13 +112,15 @@ def test_conv_gemm_planes_kernel_tile_heights(case, precision, bm, fs2_option):
 ROW8_CASES = [c for c in CASES if c[7] is not None and c[2] in (256, 384)]      # k = 1 (gemm_row8_bf16) and conv form (gemm_row8c_bf16, incl. the scalar head)
 
 
+@pytest.mark.parametrize("mt8", [2, 3])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("case", ROW8_CASES, ids=[c[-1] for c in ROW8_CASES])
-def test_conv_gemm_row_complete_ln_fused_kernel(case, precision, fs2_option):
-    """gemm_row8_bf16 / gemm_row8c_bf16 (128 rows x all N columns per workgroup, ReLU / LayerNorm / activation / scalar head in the
+def test_conv_gemm_row_complete_ln_fused_kernel(case, precision, mt8, fs2_option):
+    """gemm_row8_bf16 / gemm_row8c_bf16 (64 MT rows x all N columns per workgroup, ReLU / LayerNorm / activation / scalar head in the
     epilogue; k = 1 and k-tap conv form) are chosen by size in the model path; force them here on the small op cases (several row
-    tiles, ragged last tile, gap rows)."""
+    tiles, ragged last tile, gap rows) at every tile height (MT = 2 / 3: 128 / 192 rows)."""
     fs2_option("FS2_ROW8", 1)
+    fs2_option("FS2_MT8", mt8)
     test_conv_gemm(case, precision)
 
 
@@ -150,7 +152,7 @@ def test_conv_gemm_fp16_two_and_one_term(case, precision, bm, fs2_option):
     assert torch.isfinite(yo).all() and err < F16_TOL[precision]
 
 
-@pytest.mark.parametrize("bm", ["64", "128", "256"])
+@pytest.mark.parametrize("bm", ["64", "128", "160", "192", "224", "256"])
 @pytest.mark.parametrize("shape", [(300, 384, 1024, 9), (517, 256, 1024, 9), (90, 384, 128, 9), (260, 256, 256, 3), (150, 128, 128, 5)])
 def test_conv_gemm_mx_fp16_plus_block_scaled_fp8(shape, bm, fs2_option):
     """The "mx" arithmetic (gemm_mx.h; gemm_pl_bf16<.., ARITH = 2> on mx planes and the mx weight image): a.w = ah.wh (fp16 MFMA) +

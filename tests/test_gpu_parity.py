@@ -158,6 +158,26 @@ def test_c2_row_complete_kernel_choice(env, row8, fs2_option):
         model.precision = "fp32"
 
 
+def test_c2_row_complete_tile_heights_are_bit_identical(env, fs2_option):
+    """The 8-wave row-complete kernels (LayerNorm-fused k = 1 GEMMs, fused QKV, predictor convolutions) take 128 or 192 rows per
+    workgroup, whichever avoids a nearly empty last round: the choice must not change a single bit."""
+    model = env[0]
+    from fastspeech2_amd.synthetic import make_batch
+    b = make_batch("c2")
+    fs2_option("FS2_ROW8", 1)
+    fs2_option("FS2_QKV8", 1)
+    model.precision = "bf16x3"
+    try:
+        outs = []
+        for mt in (2, 3):
+            fs2_option("FS2_MT8", mt)
+            with torch.no_grad():
+                outs.append(model.inference_batch(b["xs"].cuda(), b["ilens"], d_override=b["ds"].cuda())[0])
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        model.precision = "fp32"
+
+
 @pytest.mark.parametrize("qkv8", ["0", "1"])
 def test_c2_qkv_kernel_choice(env, qkv8, fs2_option):
     """The fused QKV projection has two bf16 implementations (64 x 128 tiles / three 128 x D passes of an 8-wave workgroup,

@@ -1,9 +1,7 @@
 #!/bin/bash
-mkdir -p gpurun_out/r3c
-cd tools/probes
-{
-echo "--- before (st0)"; for ar in 2 0; do ./mx_conv_probe_st0.bin 30208 384 1024 9 256 $ar 1 | tail -1 | cut -c1-90; done
-echo "--- A-address hoist"; for ar in 2 0; do for bm in 256 128 64; do ./mx_conv_probe_addr.bin 30208 384 1024 9 $bm $ar 1 | tail -1 | cut -c1-90; done; done
-echo "--- c4 size"; for ar in 2 0; do ./mx_conv_probe_addr.bin 376832 384 1024 9 256 $ar 0 | tail -1 | cut -c1-90; done
-} > ../../gpurun_out/r3c/addr_probe.txt 2>&1
-cat ../../gpurun_out/r3c/addr_probe.txt
+mkdir -p gpurun_out/r3e
+for wl in c4 c3; do for mt in 2 -1; do
+FS2_MT8=$mt python bench.py --no-cpu-baseline --workload $wl > gpurun_out/r3e/ab_${wl}_mt$mt.json 2>/dev/null
+echo "$wl FS2_MT8=$mt: $(python -c "import json;d=json.load(open('gpurun_out/r3e/ab_${wl}_mt$mt.json'));print(d['value'], d['ms_per_step'])")"
+done; done
+FS2_MT8=2 python bench.py --no-cpu-baseline --workload c4 --profile-kernels 2>&1 >/dev/null | grep -v amdgpu | head -6
