@@ -101,6 +101,31 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+TORCH_OP_PATH = os.path.join(_HERE, "libfs2_torch.so")
+
+
+def build_torch_op(force=False, verbose=False):
+    """Compile csrc/fs2_torch_op.cpp (the C++ dispatcher op fs2::twin_inference behind the TorchScript twin) against this interpreter's
+    libtorch and libfs2_hip.so into fastspeech2_amd/libfs2_torch.so (in-tree; rpath $ORIGIN finds libfs2_hip.so next to it)."""
+    src = os.path.join(CSRC, "fs2_torch_op.cpp")
+    hdr = os.path.join(_HERE, "..", "include", "fs2.h")
+    build(force=False)
+    if not force and os.path.exists(TORCH_OP_PATH) and os.path.getmtime(TORCH_OP_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        return TORCH_OP_PATH
+    import torch
+    tdir = os.path.dirname(torch.__file__)
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % abi, "-Wno-deprecated-declarations",
+           "-I", os.path.join(tdir, "include"), "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"), "-I", "/opt/rocm/include",
+           src, "-o", TORCH_OP_PATH, "-L", os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip",
+           "-L", _HERE, "-lfs2_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return TORCH_OP_PATH
+
+
 _lib = None
 
 

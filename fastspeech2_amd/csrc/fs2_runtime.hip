@@ -56,6 +56,7 @@ struct Stack {
     std::vector<Layer> layers;
     float* pe = nullptr; int pe_rows = 0;
     float* alpha = nullptr;
+    int dk = 0, Dp = 0;                             // true head dim; attention width heads x padded head dim (= D when dk is a kernel size)
     bool pre_ln = false, concat = false;            // encoder.py:53-71: normalize_before / concat_after
     float *after_g = nullptr, *after_b = nullptr;   // after_norm (applied only when pre_ln, encoder.py:201-202)
 };
@@ -89,6 +90,13 @@ Options& opts() {
     }();
     return o;
 }
+
+// The attention kernels exist for head dims 64 / 128 / 192 / 256.  Any other adim / aheads the reference accepts (core/attention.py:18-20)
+// runs with the head dim zero-padded to the next of these: the Q / K / V projection weights get zero rows, the output projection zero
+// columns, at load time, so scores and context are unchanged (the softmax scale keeps the true d_k); the attention buffers are
+// heads x padded wide.  0: unsupported (d_k > 256).
+inline int padded_head_dim(int dk) { return dk <= 64 ? 64 : (dk <= 128 ? 128 : (dk <= 192 ? 192 : (dk <= 256 ? 256 : 0))); }
+inline int att_width(int D, int heads) { return heads * padded_head_dim(D / heads); }
 
 // Mixed modes: everything as bf16x3 except the FFN convolution w_1, which runs on fp16 operands with 2 or 1 MFMA per fragment pair.
 inline int base_precision(int p) { return (p == FS2_PREC_MIX_F16X2 || p == FS2_PREC_MIX_F16X1 || p == FS2_PREC_MIX_MX) ? FS2_PREC_BF16X3 : p; }
@@ -524,11 +532,12 @@ GemmArgs gemm_args(const Gemm& g, const float* X, int ldx, int R, const int* row
 }
 
 int launch_attention(fs2_handle* h, hipStream_t s, const char* name, const float* qkv, float* ctx, int D, int heads,
-                     const DevLayout& dl, int nwork, int mask_q, double flops) {
-    const int dk = D / heads;
+                     const DevLayout& dl, int nwork, int mask_q, double flops, int dk_true = 0) {
+    const int dk = D / heads;      // (D = heads x padded head dim; dk_true: the model's head dim, for the softmax scale)
+    if (!dk_true) dk_true = dk;
     AttnArgs a;
     a.qkv = qkv; a.ld = 3 * D; a.ctx = ctx; a.ldc = D; a.start = dl.start; a.len = dl.len; a.klen = dl.klen;
-    a.work = dl.work; a.nwork = dl.dims ? dl.dims + 1 : nullptr; a.D = D; a.mask_q = mask_q; a.scale = 1.0f / sqrtf((float)dk);
+    a.work = dl.work; a.nwork = dl.dims ? dl.dims + 1 : nullptr; a.D = D; a.mask_q = mask_q; a.scale = 1.0f / sqrtf((float)dk_true);
     if (nwork == 0) return FS2_OK;
     Scope sc(h, s, name, flops, 0.0);
     dim3 grid(nwork, heads);
@@ -544,8 +553,12 @@ int launch_attention(fs2_handle* h, hipStream_t s, const char* name, const float
         static LdsAttr attr;
         allow_lds(reinterpret_cast<const void*>(&attn_f32<64>), attn_lds_bytes<64>(), attr);
         hipLaunchKernelGGL(attn_f32<64>, grid, dim3(256), attn_lds_bytes<64>(), s, a);
+    } else if (dk == 256) {
+        static LdsAttr attr;
+        allow_lds(reinterpret_cast<const void*>(&attn_f32<256>), attn_lds_bytes<256>(), attr);
+        hipLaunchKernelGGL(attn_f32<256>, grid, dim3(256), attn_lds_bytes<256>(), s, a);
     } else {
-        return fail(h, FS2_ERR_UNSUPPORTED, "attention head dim %d not in {64,128,192}", dk);
+        return fail(h, FS2_ERR_UNSUPPORTED, "attention head dim %d not in {64,128,192,256} (the model path pads other head dims)", dk);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, FS2_ERR_HIP, "%s launch: %s", name, hipGetErrorString(e));
@@ -563,8 +576,9 @@ hipError_t launch_attn_b16_t(hipStream_t s, dim3 grid, const AttnB16Args& a) {
 // qkv fp32 [R,3D] -> split planes -> attention.  planes: qk_hi/lo [Rvt][2D], vt_hi/lo [D][Rvt] (Rvt % 32 == 0)
 int launch_attention_b16(fs2_handle* h, hipStream_t s, const char* name, const float* qkv, float* ctx, int D, int heads, int R, int Rvt,
                          const DevLayout& dl, int nwork, int mask_q, double flops, int precision, __bf16* qkh, __bf16* qkl, __bf16* vth,
-                         __bf16* vtl, void* ctxp = nullptr) {
+                         __bf16* vtl, void* ctxp = nullptr, int dk_true = 0) {
     const int dk = D / heads;
+    if (!dk_true) dk_true = dk;
     if (nwork == 0) return FS2_OK;
     if (qkv != nullptr) {
         char nm[112];
@@ -573,7 +587,7 @@ int launch_attention_b16(fs2_handle* h, hipStream_t s, const char* name, const f
         static LdsAttr attr;
         allow_lds(reinterpret_cast<const void*>(&qkv_split), 32 * (1024 + 1) * 4, attr);
         QkvSplitArgs q;
-        q.qkv = qkv; q.R = R; q.Rvt = Rvt; q.D = D; q.dk = dk; q.scale = 1.4426950408889634f / sqrtf((float)dk);   // log2(e)/sqrt(d_k): softmax in base 2
+        q.qkv = qkv; q.R = R; q.Rvt = Rvt; q.D = D; q.dk = dk; q.scale = 1.4426950408889634f / sqrtf((float)dk_true);   // log2(e)/sqrt(d_k): softmax in base 2
         q.qk_hi = qkh; q.qk_lo = qkl; q.vt_hi = vth; q.vt_lo = vtl;
         if (D > 1024) return fail(h, FS2_ERR_UNSUPPORTED, "attention dim %d > 1024", D);
         hipLaunchKernelGGL(qkv_split, dim3(Rvt / 32), dim3(256), (size_t)32 * (D + 1) * 4, s, q);
@@ -591,7 +605,8 @@ int launch_attention_b16(fs2_handle* h, hipStream_t s, const char* name, const f
     if (dk == 128) e = x3 ? launch_attn_b16_t<128, 3>(s, grid, a) : launch_attn_b16_t<128, 1>(s, grid, a);
     else if (dk == 192) e = x3 ? launch_attn_b16_t<192, 3>(s, grid, a) : launch_attn_b16_t<192, 1>(s, grid, a);
     else if (dk == 64) e = x3 ? launch_attn_b16_t<64, 3>(s, grid, a) : launch_attn_b16_t<64, 1>(s, grid, a);
-    else return fail(h, FS2_ERR_UNSUPPORTED, "attention head dim %d not in {64,128,192}", dk);
+    else if (dk == 256) e = x3 ? launch_attn_b16_t<256, 3>(s, grid, a) : launch_attn_b16_t<256, 1>(s, grid, a);
+    else return fail(h, FS2_ERR_UNSUPPORTED, "attention head dim %d not in {64,128,192,256} (the model path pads other head dims)", dk);
     if (e != hipSuccess) return fail(h, FS2_ERR_HIP, "%s launch: %s", name, hipGetErrorString(e));
     return FS2_OK;
 }
@@ -704,6 +719,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
               const HostLayout& L, const DevLayout& dl, int mask_q, const StackBufs& b, int prec, bool x0p_ready = false, bool allow_splitk = false,
               int regime_rows = 0, int ffn_terms = 0) {
     if (st.pre_ln || st.concat) return run_stack_general(h, s, tag, st, D, heads, R, L, dl, mask_q, b, prec, x0p_ready, regime_rows);
+    const int Dp = st.Dp;      // attention width (= D unless the head dim is padded)
     char nm[96];
     double att_flops = 0;
     for (size_t i = 0; i < L.klen.size(); ++i) att_flops += 4.0 * D * (double)L.klen[i] * std::min(L.len[i], mask_q ? L.klen[i] : L.len[i]);
@@ -721,21 +737,21 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         const Layer& ly = st.layers[li];
         int rc;
         snprintf(nm, sizeof nm, "%s.qkv", tag);
-        GemmArgs a = gemm_args(ly.qkv, b.x0, D, R, dl.row_pos, b.qkv, 3 * D);
+        GemmArgs a = gemm_args(ly.qkv, b.x0, D, R, dl.row_pos, b.qkv, 3 * Dp);
         a.Rp = dl.dims; a.regime_rows = regime_rows;
         if (pl) a.Xp = b.x0p;
-        const bool fused_split = prec != FS2_PREC_FP32 && D % kB16BN == 0;
+        const bool fused_split = prec != FS2_PREC_FP32 && Dp % kB16BN == 0;
         if (fused_split) {   // bf16 attention operands straight from the GEMM epilogue (no fp32 QKV round trip)
-            a.Y = nullptr; a.qk_hi = b.qkh; a.qk_lo = b.qkl; a.vt_hi = b.vth; a.vt_lo = b.vtl; a.att_D = D; a.Rvt = L.Rpad;
-            a.q_scale = 1.4426950408889634f / sqrtf((float)(D / heads));
+            a.Y = nullptr; a.qk_hi = b.qkh; a.qk_lo = b.qkl; a.vt_hi = b.vth; a.vt_lo = b.vtl; a.att_D = Dp; a.Rvt = L.Rpad;
+            a.q_scale = 1.4426950408889634f / sqrtf((float)st.dk);
         }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.attn", tag);
-        if (prec == FS2_PREC_FP32) rc = launch_attention(h, s, nm, b.qkv, b.ctx, D, heads, dl, L.nwork(), mask_q, att_flops);
-        else rc = launch_attention_b16(h, s, nm, fused_split ? nullptr : b.qkv, pl ? nullptr : b.ctx, D, heads, R, L.Rpad, dl, L.nwork(), mask_q, att_flops, prec, b.qkh, b.qkl, b.vth, b.vtl, ctxp);
+        if (prec == FS2_PREC_FP32) rc = launch_attention(h, s, nm, b.qkv, b.ctx, Dp, heads, dl, L.nwork(), mask_q, att_flops, st.dk);
+        else rc = launch_attention_b16(h, s, nm, fused_split ? nullptr : b.qkv, pl ? nullptr : b.ctx, Dp, heads, R, L.Rpad, dl, L.nwork(), mask_q, att_flops, prec, b.qkh, b.qkl, b.vth, b.vtl, ctxp, st.dk);
         if (rc) return rc;
         snprintf(nm, sizeof nm, "%s.out_ln", tag);
-        a = gemm_args(ly.out, b.ctx, D, R, dl.row_pos, b.x1, D);
+        a = gemm_args(ly.out, b.ctx, Dp, R, dl.row_pos, b.x1, D);
         a.Rp = dl.dims; a.regime_rows = regime_rows;
         a.resid = b.x0; a.ldr = D; a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
         const bool mxl = pl && ffn_terms == kFfnMx && ly.w1.wm;                                   // this layer's FFN conv in the mx arithmetic?
@@ -786,6 +802,7 @@ int run_stack_general(fs2_handle* h, hipStream_t s, const char* tag, const Stack
     for (size_t i = 0; i < L.klen.size(); ++i) att_flops += 4.0 * D * (double)L.klen[i] * std::min(L.len[i], mask_q ? L.klen[i] : L.len[i]);
     const bool pl = prec != FS2_PREC_FP32;
     const bool pre = st.pre_ln, cat = st.concat;
+    const int Dp = st.Dp;
     void* ctxp = pl ? (void*)b.ctx : nullptr;
     void* hidp = pl ? (void*)b.hid : nullptr;
     int rc;
@@ -802,23 +819,23 @@ int run_stack_general(fs2_handle* h, hipStream_t s, const char* tag, const Stack
             qin = b.hid; qinp = pl ? b.xps : nullptr;
         }
         snprintf(nm, sizeof nm, "%s.qkv", tag);
-        GemmArgs a = gemm_args(ly.qkv, qin, D, R, dl.row_pos, b.qkv, 3 * D);
+        GemmArgs a = gemm_args(ly.qkv, qin, D, R, dl.row_pos, b.qkv, 3 * Dp);
         a.Rp = dl.dims; a.regime_rows = regime_rows; a.Xp = qinp;
-        const bool fused_split = pl && D % kB16BN == 0;
+        const bool fused_split = pl && Dp % kB16BN == 0;
         if (fused_split) {
-            a.Y = nullptr; a.qk_hi = b.qkh; a.qk_lo = b.qkl; a.vt_hi = b.vth; a.vt_lo = b.vtl; a.att_D = D; a.Rvt = L.Rpad;
-            a.q_scale = 1.4426950408889634f / sqrtf((float)(D / heads));
+            a.Y = nullptr; a.qk_hi = b.qkh; a.qk_lo = b.qkl; a.vt_hi = b.vth; a.vt_lo = b.vtl; a.att_D = Dp; a.Rvt = L.Rpad;
+            a.q_scale = 1.4426950408889634f / sqrtf((float)st.dk);
         }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.attn", tag);
-        if (!pl) rc = launch_attention(h, s, nm, b.qkv, b.ctx, D, heads, dl, L.nwork(), mask_q, att_flops);
-        else rc = launch_attention_b16(h, s, nm, fused_split ? nullptr : b.qkv, nullptr, D, heads, R, L.Rpad, dl, L.nwork(), mask_q, att_flops, prec, b.qkh, b.qkl, b.vth, b.vtl, ctxp);
+        if (!pl) rc = launch_attention(h, s, nm, b.qkv, b.ctx, Dp, heads, dl, L.nwork(), mask_q, att_flops, st.dk);
+        else rc = launch_attention_b16(h, s, nm, fused_split ? nullptr : b.qkv, nullptr, Dp, heads, R, L.Rpad, dl, L.nwork(), mask_q, att_flops, prec, b.qkh, b.qkl, b.vth, b.vtl, ctxp, st.dk);
         if (rc) return rc;
         if (cat) {
             // a = linear_out(context) (no residual), then x1 = x0 + xq . Wc_x^T + bc, then x1 += a . Wc_a^T (+ LayerNorm when post-LN)
             float* att = b.qkv; void* attp = pl ? (void*)b.qkh : nullptr;       // both free once the attention kernel has run
             snprintf(nm, sizeof nm, "%s.out", tag);
-            a = gemm_args(ly.out, b.ctx, D, R, dl.row_pos, pl ? nullptr : att, D);
+            a = gemm_args(ly.out, b.ctx, Dp, R, dl.row_pos, pl ? nullptr : att, D);
             a.Rp = dl.dims; a.regime_rows = regime_rows;
             if (pl) { a.Xp = ctxp; a.Yp = attp; a.yp_chunks = D / 32; }
             if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
@@ -833,7 +850,7 @@ int run_stack_general(fs2_handle* h, hipStream_t s, const char* tag, const Stack
             if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         } else {
             snprintf(nm, sizeof nm, "%s.out", tag);
-            a = gemm_args(ly.out, b.ctx, D, R, dl.row_pos, b.x1, D);
+            a = gemm_args(ly.out, b.ctx, Dp, R, dl.row_pos, b.x1, D);
             a.Rp = dl.dims; a.regime_rows = regime_rows; a.resid = b.x0; a.ldr = D;
             if (pl) a.Xp = ctxp;
             if (!pre) { a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f; if (pl) { a.Yp = b.x1p; a.yp_chunks = D / 32; } }
@@ -894,12 +911,51 @@ int run_predictor(fs2_handle* h, hipStream_t s, const char* tag, const Predictor
 }
 
 // ------------------------------------------------------------------ weight loading
+// src [rows, cols] -> dst with every block of dk rows (by_cols: columns) moved to a block of dkp (dst pre-zeroed)
+__global__ void pad_heads(const float* src, int rows, int cols, int dk, int dkp, int by_cols, float* dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
+    if (by_cols) dst[(size_t)r * ((cols / dk) * dkp) + (c / dk) * dkp + c % dk] = src[i];
+    else dst[((size_t)(r / dk) * dkp + r % dk) * cols + c] = src[i];
+}
+
 struct Loader {
     fs2_handle* h; hipStream_t s;
     std::map<std::string, const fs2_tensor_desc*> m;
     int rc = FS2_OK;
     unsigned* absmax_scratch = nullptr;
-    ~Loader() { if (absmax_scratch) hipFree(absmax_scratch); }
+    std::vector<fs2_tensor_desc*> synth;      // head-padded copies of projection weights (padded_tensor): descriptors + device memory, released with the loader
+    std::vector<std::string*> synth_names;
+    std::vector<void*> synth_mem;
+    ~Loader() {
+        if (absmax_scratch) hipFree(absmax_scratch);
+        if (!synth_mem.empty()) hipStreamSynchronize(s);
+        for (void* p : synth_mem) hipFree(p);
+        for (auto* d : synth) delete d;
+        for (auto* n : synth_names) delete n;
+    }
+    // Registers "<name>#pad": the tensor `name` ([D, C] weight, or [D] bias when C == 0) with every head's dk rows (pad_cols: columns)
+    // moved to a block of dkp, zeros in between.  Returns the new name ("" on error).
+    std::string padded_tensor(const std::string& name, int heads, int dk, int dkp, int D, int C, bool pad_cols) {
+        const fs2_tensor_desc* d = C ? get(name, {D, pad_cols ? heads * dk : C}) : get(name, {D});
+        if (!d) return "";
+        const int Dp = heads * dkp;
+        const size_t n = C ? (pad_cols ? (size_t)D * Dp : (size_t)Dp * C) : (size_t)Dp;
+        float* p = nullptr;
+        if (hipMalloc((void**)&p, n * sizeof(float)) != hipSuccess) { if (!rc) rc = fail(h, FS2_ERR_HIP, "hipMalloc failed"); return ""; }
+        synth_mem.push_back(p);
+        hipMemsetAsync(p, 0, n * sizeof(float), s);
+        const int rows = pad_cols ? D : heads * dk, cols = C ? (pad_cols ? heads * dk : C) : 1;
+        hipLaunchKernelGGL(pad_heads, dim3((unsigned)(((size_t)rows * cols + 255) / 256)), dim3(256), 0, s, (const float*)d->data, rows, cols, dk, dkp, pad_cols ? 1 : 0, p);
+        auto* nd = new fs2_tensor_desc(*d);
+        auto* nn = new std::string(name + "#pad");
+        nd->name = nn->c_str(); nd->data = p;
+        if (C) { nd->shape[0] = pad_cols ? D : Dp; nd->shape[1] = pad_cols ? Dp : C; } else nd->shape[0] = Dp;
+        synth.push_back(nd); synth_names.push_back(nn);
+        m[*nn] = nd;
+        return *nn;
+    }
     const fs2_tensor_desc* get(const std::string& name, std::initializer_list<int64_t> shape) {
         auto it = m.find(name);
         if (it == m.end()) { if (!rc) rc = fail(h, FS2_ERR_WEIGHT, "missing tensor %s", name.c_str()); return nullptr; }
@@ -1005,17 +1061,32 @@ struct Loader {
     }
 };
 
-void load_stack(Loader& L, Stack& st, const std::string& pre, int nlayers, int D, int units, int k, const std::string& pe_pre,
+void load_stack(Loader& L, Stack& st, const std::string& pre, int nlayers, int D, int heads, int units, int k, const std::string& pe_pre,
                 bool scaled, bool pre_ln, bool concat) {
     st.layers.resize(nlayers);
+    st.dk = D / heads;
+    const int dkp = padded_head_dim(st.dk);
+    st.Dp = heads * dkp;
     st.pre_ln = pre_ln; st.concat = concat;
     if (pre_ln) { st.after_g = L.copy(pre + ".after_norm.weight", {D}); st.after_b = L.copy(pre + ".after_norm.bias", {D}); }
     for (int i = 0; i < nlayers; ++i) {
         const std::string p = pre + ".encoders_." + std::to_string(i);
         Layer& ly = st.layers[i];
-        ly.qkv = L.gemm({p + ".self_attn.linear_q.weight", p + ".self_attn.linear_k.weight", p + ".self_attn.linear_v.weight"},
-                        {p + ".self_attn.linear_q.bias", p + ".self_attn.linear_k.bias", p + ".self_attn.linear_v.bias"}, D, D, 1, true);
-        ly.out = L.gemm({p + ".self_attn.linear_out.weight"}, {p + ".self_attn.linear_out.bias"}, D, D, 1, true);
+        if (st.Dp == D) {
+            ly.qkv = L.gemm({p + ".self_attn.linear_q.weight", p + ".self_attn.linear_k.weight", p + ".self_attn.linear_v.weight"},
+                            {p + ".self_attn.linear_q.bias", p + ".self_attn.linear_k.bias", p + ".self_attn.linear_v.bias"}, D, D, 1, true);
+            ly.out = L.gemm({p + ".self_attn.linear_out.weight"}, {p + ".self_attn.linear_out.bias"}, D, D, 1, true);
+        } else {      // head dim padded to a kernel size: zero rows in W_q / W_k / W_v (and their biases), zero columns in W_out
+            std::vector<std::string> wn, bn;
+            for (const char* t : {"q", "k", "v"}) {
+                wn.push_back(L.padded_tensor(p + ".self_attn.linear_" + t + ".weight", heads, st.dk, dkp, D, D, false));
+                bn.push_back(L.padded_tensor(p + ".self_attn.linear_" + t + ".bias", heads, st.dk, dkp, D, 0, false));
+            }
+            const std::string wo = L.padded_tensor(p + ".self_attn.linear_out.weight", heads, st.dk, dkp, D, D, true);
+            if (L.rc) return;
+            ly.qkv = L.gemm(wn, bn, st.Dp, D, 1, true);
+            ly.out = L.gemm({wo}, {p + ".self_attn.linear_out.bias"}, D, st.Dp, 1, true);
+        }
         ly.w1 = L.gemm({p + ".feed_forward.w_1.weight"}, {p + ".feed_forward.w_1.bias"}, units, D, k, L.h->cfg.ffn_kernel == 1 && L.m.count(p + ".feed_forward.w_1.weight") && L.m[p + ".feed_forward.w_1.weight"]->ndim == 2,
                         "", /*f16_image=*/k > 1);
         {
@@ -1090,13 +1161,14 @@ size_t carve_tokens(const fs2_config& c, const fs2_batch& b, const HostLayout& L
     int* m = bp.take<int>(layout_dev_ints(L));
     float* x0 = bp.take<float>(R * c.adim);
     float* x1 = bp.take<float>(R * c.adim);
-    float* qkv = bp.take<float>(R * 3 * c.adim);
-    float* ctx = bp.take<float>(R * c.adim);
+    const size_t eDp = att_width(c.adim, c.aheads);      // attention width: heads x padded head dim
+    float* qkv = bp.take<float>(R * 3 * eDp);
+    float* ctx = bp.take<float>(R * eDp);
     float* hid = bp.take<float>(R * (size_t)round_up(c.eunits, 32));     // bf16 modes: hidden layer as planes (32-channel chunks)
-    __bf16* qkh = bp.take<__bf16>(R * 2 * c.adim);
-    __bf16* qkl = bp.take<__bf16>(R * 2 * c.adim);
-    __bf16* vth = bp.take<__bf16>(R * c.adim);
-    __bf16* vtl = bp.take<__bf16>(R * c.adim);
+    __bf16* qkh = bp.take<__bf16>(R * 2 * eDp);
+    __bf16* qkl = bp.take<__bf16>(R * 2 * eDp);
+    __bf16* vth = bp.take<__bf16>(R * eDp);
+    __bf16* vtl = bp.take<__bf16>(R * eDp);
     const size_t pw = round_up(c.adim, 32);
     float* x0p = bp.take<float>(R * pw);
     float* x1p = bp.take<float>(R * pw);
@@ -1142,13 +1214,14 @@ size_t carve_frames(const fs2_config& c, const HostLayout& L, void* ws, size_t c
     f.p_rows = bp.take<float>(R);
     f.sb.x0 = bp.take<float>(R * c.ddim);
     f.sb.x1 = bp.take<float>(R * c.ddim);
-    f.sb.qkv = bp.take<float>(R * 3 * c.ddim);
-    f.sb.ctx = bp.take<float>(R * c.ddim);
+    const size_t dDp = att_width(c.ddim, c.aheads);
+    f.sb.qkv = bp.take<float>(R * 3 * dDp);
+    f.sb.ctx = bp.take<float>(R * dDp);
     f.sb.hid = bp.take<float>(R * (size_t)std::max(round_up(c.dunits, 32), 2 * c.postnet_chans));
-    f.sb.qkh = bp.take<__bf16>(R * 2 * c.ddim);
-    f.sb.qkl = bp.take<__bf16>(R * 2 * c.ddim);
-    f.sb.vth = bp.take<__bf16>(R * c.ddim);
-    f.sb.vtl = bp.take<__bf16>(R * c.ddim);
+    f.sb.qkh = bp.take<__bf16>(R * 2 * dDp);
+    f.sb.qkl = bp.take<__bf16>(R * 2 * dDp);
+    f.sb.vth = bp.take<__bf16>(R * dDp);
+    f.sb.vtl = bp.take<__bf16>(R * dDp);
     f.sb.x0p = bp.take<float>(R * (size_t)round_up(std::max(c.ddim, c.postnet_chans), 32));
     f.sb.x1p = bp.take<float>(R * (size_t)round_up(std::max(std::max(c.adim, c.ddim), c.postnet_chans), 32));    // also holds the length-regulator output's planes
     f.sb.xps = bp.take<float>(R * (size_t)round_up(std::max(std::max(c.adim, c.ddim), std::max(std::max(c.var_chans, c.postnet_chans), c.odim)), 32));
@@ -1223,7 +1296,9 @@ int fs2_create(const fs2_config* cfg, fs2_handle** out) {
     *out = nullptr;
     ABI_CHECK(nullptr, "fs2_create", cfg, fs2_config);
     if (cfg->reduction_factor < 1 || cfg->reduction_factor > 8) return fail(nullptr, FS2_ERR_UNSUPPORTED, "reduction_factor %d outside [1, 8]", cfg->reduction_factor);
-    if (cfg->adim % cfg->aheads || cfg->ddim % cfg->aheads) return fail(nullptr, FS2_ERR_ARG, "adim/ddim not divisible by aheads");
+    if (cfg->aheads <= 0 || cfg->adim % cfg->aheads || cfg->ddim % cfg->aheads) return fail(nullptr, FS2_ERR_ARG, "adim/ddim not divisible by aheads");
+    if (!padded_head_dim(cfg->adim / cfg->aheads) || !padded_head_dim(cfg->ddim / cfg->aheads))
+        return fail(nullptr, FS2_ERR_UNSUPPORTED, "attention head dims above 256 (adim / aheads = %d, ddim / aheads = %d) are not implemented", cfg->adim / cfg->aheads, cfg->ddim / cfg->aheads);
     if (!cfg->decoder_input_layer && cfg->ddim != cfg->adim) return fail(nullptr, FS2_ERR_ARG, "decoder_input_layer = 0 needs ddim == adim");
     if (cfg->n_bins != cfg->adim) return fail(nullptr, FS2_ERR_ARG, "n_bins (%d) must equal adim (%d): the reference feeds one_hot(256) into Linear(adim, adim)", cfg->n_bins, cfg->adim);
     if (cfg->ffn_kernel % 2 == 0 || cfg->dur_kernel % 2 == 0 || cfg->var_kernel % 2 == 0 || (cfg->postnet_layers > 0 && cfg->postnet_filts % 2 == 0))
@@ -1270,9 +1345,9 @@ int fs2_load_weights(fs2_handle* h, const fs2_tensor_desc* t, int32_t n, void* s
     for (int i = 0; i < n; ++i) if (t[i].name) L.m[t[i].name] = &t[i];
 
     h->enc_embed = L.copy("encoder.embed.0.weight", {c.idim, c.adim});
-    load_stack(L, h->enc, "encoder", c.elayers, c.adim, c.eunits, c.ffn_kernel, "encoder.embed.1", c.use_scaled_pos_enc,
+    load_stack(L, h->enc, "encoder", c.elayers, c.adim, c.aheads, c.eunits, c.ffn_kernel, "encoder.embed.1", c.use_scaled_pos_enc,
                c.enc_normalize_before != 0, c.enc_concat_after != 0);
-    load_stack(L, h->dec, "decoder", c.dlayers, c.ddim, c.dunits, c.ffn_kernel, c.decoder_input_layer ? "decoder.embed.4" : "decoder.embed.0",
+    load_stack(L, h->dec, "decoder", c.dlayers, c.ddim, c.aheads, c.dunits, c.ffn_kernel, c.decoder_input_layer ? "decoder.embed.4" : "decoder.embed.0",
                c.use_scaled_pos_enc, c.dec_normalize_before != 0, c.dec_concat_after != 0);
     load_predictor(L, h->dur, "duration_predictor", c.dur_layers, c.adim, c.dur_chans, c.dur_kernel);
     load_predictor(L, h->energy, "energy_predictor.predictor", c.var_layers, c.adim, c.var_chans, c.var_kernel);

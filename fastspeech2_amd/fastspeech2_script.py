@@ -6,59 +6,52 @@ The reference keeps a second, inference-only ``FeedForwardTransformer`` for ``ex
 (utils/fastspeech2_script.py:112-127,145) -- and ``forward(x: [T] int64) -> [L, odim]``.
 
 Here the same HIP library runs it (``fs2_config.decoder_input_layer = 0``).  To be scriptable the forward
-cannot go through ctypes, so it is a registered dispatcher op with a schema,
+cannot go through ctypes, so it is a dispatcher op with a schema,
 
     fs2::twin_inference(Tensor x, Tensor flat_weights, str config_json) -> Tensor
 
-whose implementation rebuilds (and caches) the eager module from the flat weight buffer + JSON config that
-the scripted module carries.  ``torch.jit.script(model)``, ``torch.jit.trace`` and ``torch.jit.save/load``
-therefore work; a reloaded archive runs in any process that has imported this package (which registers the op).
+implemented in C++ (``csrc/fs2_torch_op.cpp`` -> ``libfs2_torch.so``, built by ``__graft_entry__.build()``): it cuts the flat
+weight buffer the scripted module carries by the manifest inside ``config_json``, keeps a libfs2_hip handle per weight buffer
+(an LRU of four) and runs fs2_encode / fs2_decode on torch's current stream.  ``torch.jit.script(model)``, ``torch.jit.trace``
+and ``torch.jit.save/load`` work, and a saved archive runs in ANY process that has loaded the op library -- Python or C++,
+without this package:
+
+    torch.ops.load_library("<repo>/fastspeech2_amd/libfs2_torch.so")
+    mel = torch.jit.load("fs2_twin.pt")(ids)
 """
 import json
+import os
 
 import torch
 
+from . import _lib
 from .fastspeech import FeedForwardTransformer as _Base
-from .hparams import DotDict
 
-__all__ = ["FeedForwardTransformer"]
+__all__ = ["FeedForwardTransformer", "OP_LIBRARY"]
 
-_LIBDEF = torch.library.Library("fs2", "DEF")
-_LIBDEF.define("twin_inference(Tensor x, Tensor flat_weights, str config_json) -> Tensor")
+OP_LIBRARY = _lib.TORCH_OP_PATH
 
-_CACHE = {}
+
+def _load_op_library():
+    """Load libfs2_torch.so (registers fs2::twin_inference).  There is no Python implementation to fall back to."""
+    if hasattr(torch.ops, "fs2") and hasattr(torch.ops.fs2, "twin_inference"):
+        try:
+            torch.ops.fs2.twin_inference.default      # already registered (library loaded earlier in this process)
+            return
+        except (AttributeError, RuntimeError):
+            pass
+    if not os.path.exists(OP_LIBRARY):
+        raise _lib.Fs2LibraryError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` (the TorchScript twin's op is "
+            "implemented in C++; there is no Python fallback)" % OP_LIBRARY)
+    torch.ops.load_library(OP_LIBRARY)
+
+
+_load_op_library()
 
 
 def _float_keys(module):
-    return [k for k, v in sorted(module.state_dict().items()) if v.dtype == torch.float32]
-
-
-def _twin_inference(x, flat_weights, config_json):
-    # The cache entry keeps a reference to the flat buffer it was built from: its storage therefore cannot be released and handed
-    # to another tensor while the entry lives, so (data_ptr, version) identifies the weights without reading them back.
-    key = (flat_weights.data_ptr(), flat_weights._version, flat_weights.numel(), flat_weights.device, config_json)
-    entry = _CACHE.get(key)
-    inner = entry[0] if entry is not None else None
-    if inner is None:
-        cfg = json.loads(config_json)
-        inner = _Base(cfg["idim"], cfg["odim"], DotDict(cfg["hp"]), _script_twin=True)
-        sd, off = inner.state_dict(), 0
-        flat = flat_weights.detach()
-        for k in _float_keys(inner):
-            n = sd[k].numel()
-            sd[k] = flat[off:off + n].view(sd[k].shape).clone()
-            off += n
-        if off != flat.numel():
-            raise RuntimeError("flat weight buffer has %d elements, the architecture needs %d" % (flat.numel(), off))
-        inner.load_state_dict(sd)
-        inner = inner.to(flat_weights.device).eval()
-        _CACHE.clear()          # one live model per process is the export use case
-        _CACHE[key] = (inner, flat_weights)
-    with torch.no_grad():
-        return inner.inference(x)
-
-
-torch.library.impl(_LIBDEF, "twin_inference", "CompositeExplicitAutograd")(_twin_inference)
+    return [k for k, v in sorted(module.state_dict().items()) if v.dtype == torch.float32 and k != "flat_weights"]
 
 
 class FeedForwardTransformer(_Base):
@@ -67,17 +60,20 @@ class FeedForwardTransformer(_Base):
 
     def __init__(self, idim: int, odim: int, hp):
         super().__init__(idim, odim, hp, _script_twin=True)
-        hp_plain = {"model": dict(hp.model), "data": {k: hp.data[k] for k in ("e_min", "e_max", "p_min", "p_max")}}
-        self.config_json = json.dumps({"idim": idim, "odim": odim, "hp": hp_plain}, sort_keys=True)
+        self._hp_plain = {"model": dict(hp.model), "data": {k: hp.data[k] for k in ("e_min", "e_max", "p_min", "p_max")}}
+        self.config_json = ""
         self.register_buffer("flat_weights", torch.zeros(0), persistent=False)
         self.pack_weights()
 
     def pack_weights(self):
-        """(Re)build the flat fp32 buffer the scripted forward ships to the op; call after changing parameters
-        by hand (``load_state_dict`` does it for you)."""
+        """(Re)build what the scripted forward ships to the op -- the flat fp32 weight buffer and ``config_json`` (hyper-parameters,
+        arithmetic mode, and the manifest [[name, shape], ...] that says how to cut the buffer); call after changing parameters or
+        ``precision`` by hand (``load_state_dict`` does it for you)."""
         sd = self.state_dict()
-        keys = [k for k in _float_keys(self) if k != "flat_weights"]
+        keys = _float_keys(self)
         self.flat_weights = torch.cat([sd[k].detach().reshape(-1).float() for k in keys]).to(self.feat_out.weight.device)
+        self.config_json = json.dumps({"idim": self.idim, "odim": self.odim, "hp": self._hp_plain, "precision": self.precision,
+                                       "tensors": [[k, list(sd[k].shape)] for k in keys]}, sort_keys=True)
 
     def load_state_dict(self, state_dict, strict: bool = True):
         r = super().load_state_dict(state_dict, strict)

@@ -4,6 +4,8 @@
  (3) size-independent properties at BASELINE.json's full sizes.
 Bar (BASELINE.json north_star): mel max-abs <= 1e-3 vs the reference CPU path; length-regulator indices
 and (teacher-forced) bucket indices bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -666,6 +668,11 @@ VARIANTS = {
     "no_postnet": dict(postnet_layers=0),
     "ddim256_arch": dict(ddim=256, dunits=1024, elayers=2, dlayers=3, postnet_layers=3),            # assets/model.txt era
     "conv_k3_ffn": dict(positionwise_conv_kernel_size=3, duration_predictor_layers=3),
+    # any adim % aheads == 0 the reference accepts (core/attention.py:18-20): head dims that are not a kernel size run zero-padded
+    "aheads4": dict(aheads=4),                                  # d_k 64 (encoder) / 96 -> padded to 128 (decoder)
+    "aheads8": dict(aheads=8),                                  # d_k 32 -> 64 / 48 -> 64
+    "aheads1_ddim256": dict(aheads=1, ddim=256),                # d_k 256 in both stacks (the 256-wide attention kernels)
+    "aheads4_pre_ln_concat": dict(aheads=4, decoder_normalize_before=True, decoder_concat_after=True),
 }
 
 
@@ -791,9 +798,13 @@ def test_packed_output_and_unpack_kernel(env):
 
 def test_g5_script_twin_eager_scripted_and_reloaded(golden_dir, tmp_path):
     """The TorchScript twin (reference utils/fastspeech2_script.py, export_torchscript.py:46-58) on the HIP path:
-    eager forward, scripted forward, traced forward and a save/load round trip all reproduce the reference's mel."""
+    eager forward, scripted forward, traced forward (with the reference's CPU example input) and a save/load round trip all
+    reproduce the reference's mel -- and the saved archive runs in a process that never imports this package: the op
+    fs2::twin_inference lives in libfs2_torch.so (C++)."""
+    import subprocess
+    import sys
     from fastspeech2_amd import default_hparams, N_PHONEME_SYMBOLS
-    from fastspeech2_amd.fastspeech2_script import FeedForwardTransformer as Twin
+    from fastspeech2_amd.fastspeech2_script import FeedForwardTransformer as Twin, OP_LIBRARY
     from fastspeech2_amd.synthetic import portable_state_dict, bias_durations
     g = np.load(golden_dir + "/g5_script_twin_t30.npz")
     twin = Twin(N_PHONEME_SYMBOLS, 80, default_hparams()).eval()
@@ -805,16 +816,37 @@ def test_g5_script_twin_eager_scripted_and_reloaded(golden_dir, tmp_path):
         direct = twin.inference(x)
         scripted = torch.jit.script(twin)
         s_out = scripted(x)
-        traced = torch.jit.trace(twin, torch.ones(50, dtype=torch.int64, device="cuda:0"))
+        traced = torch.jit.trace(twin, torch.ones(50, dtype=torch.int64))      # export_torchscript.py:53-56: a CPU example input
         t_out = traced(x)
         path = str(tmp_path / "twin.pt")
         scripted.save(path)
         r_out = torch.jit.load(path)(x)
+        # a second twin alive in the same process: the op's handle cache (an LRU) serves both without rebuilding either
+        twin2 = Twin(N_PHONEME_SYMBOLS, 80, default_hparams()).eval()
+        twin2.load_state_dict(portable_state_dict(twin2.state_dict(), seed=6))
+        twin2 = twin2.to("cuda:0")
+        other = twin2(x)
+        again = twin(x)
     d = _maxabs(eager, g["mel"])
     print("G5 twin mel max-abs %.2e (L=%d)" % (d, eager.shape[0]))
     assert eager.shape == tuple(g["mel"].shape) and d <= MEL_TOL
-    for o in (direct, s_out, t_out, r_out):
+    for o in (direct, s_out, t_out, r_out, again):
         assert torch.equal(o, eager)
+    assert other.shape[1] == 80 and not torch.equal(other[: min(len(other), len(eager))], eager[: min(len(other), len(eager))])
+    # the archive in a fresh interpreter that loads ONLY torch + the op library
+    out_path = str(tmp_path / "out.pt")
+    code = ("import sys, torch\n"
+            "assert not any(m.startswith('fastspeech2_amd') for m in sys.modules)\n"
+            "torch.ops.load_library(%r)\n"
+            "m = torch.jit.load(%r, map_location='cuda:0')\n"
+            "x = torch.tensor(%r, dtype=torch.int64)\n"
+            "y = m(x.cuda())\n"
+            "assert not any(m.startswith('fastspeech2_amd') for m in sys.modules)\n"
+            "torch.save(y.cpu(), %r)\n") % (OP_LIBRARY, path, g["x"].tolist(), out_path)
+    env_ = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    res = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env_, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert torch.equal(torch.load(out_path), eager.cpu())
 
 
 def test_vocoder_hand_off(env):

@@ -1,7 +1,4 @@
 #!/bin/bash
-mkdir -p gpurun_out/r3e
-for wl in c4 c3; do for mt in 2 -1; do
-FS2_MT8=$mt python bench.py --no-cpu-baseline --workload $wl > gpurun_out/r3e/ab_${wl}_mt$mt.json 2>/dev/null
-echo "$wl FS2_MT8=$mt: $(python -c "import json;d=json.load(open('gpurun_out/r3e/ab_${wl}_mt$mt.json'));print(d['value'], d['ms_per_step'])")"
-done; done
-FS2_MT8=2 python bench.py --no-cpu-baseline --workload c4 --profile-kernels 2>&1 >/dev/null | grep -v amdgpu | head -6
+mkdir -p gpurun_out/r3f
+python -m pytest tests/test_gpu_parity.py -x -q -k "config_variants or g5 or g7 or checkpoint" 2>&1 | tail -12 > gpurun_out/r3f/pytest_a.txt
+tail -n 12 gpurun_out/r3f/pytest_a.txt
