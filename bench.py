@@ -45,6 +45,16 @@ WORKLOAD_TEXT = {
 }
 
 
+def csrc_sha16():
+    """Fingerprint of the kernel sources (what profiles/r03_traffic.json was measured on)."""
+    import hashlib
+    hsh = hashlib.sha256()
+    d = os.path.join(ROOT, "fastspeech2_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        hsh.update(open(os.path.join(d, f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def cpu_baseline(sd, cfg, batch, gpu, budget_s=14.0):
     """Times the CPU oracle (the validated port of the reference's fp32 PyTorch path) on the host cores, on a bounded
     sample of the same batch: (i) per-utterance loop of B=1 calls, (ii) one padded batch of 16 utterances; returns the faster
@@ -256,8 +266,15 @@ def main():
     per_row = {"dec.ffn1": 2.0 * c["ffn_kernel"] * c["ddim"] * c["dunits"], "enc.ffn1": 2.0 * c["ffn_kernel"] * c["adim"] * c["eunits"],
                "dec.ffn2_ln": 2.0 * c["dunits"] * c["ddim"], "dec.qkv": 6.0 * c["ddim"] ** 2, "dec.out_ln": 2.0 * c["ddim"] ** 2}
     rows = local_tokens if dom_name.startswith("enc") or dom_name.startswith("dur") else local_frames
+    mine_t = torch.as_tensor(mine, dtype=torch.int64)
+    ol_mine = olens_all.cpu()[mine_t].double() if mine else torch.zeros(0, dtype=torch.float64)
+    il_mine = il[mine_t].double() if mine else torch.zeros(0, dtype=torch.float64)
+    per_launch = {"dec.attn": 4.0 * c["ddim"] * float((ol_mine * ol_mine).sum()),       # 4 D L^2 per utterance and layer
+                  "enc.attn": 4.0 * c["adim"] * float((il_mine * il_mine).sum())}
     if dom_name in per_row:
         algo = per_row[dom_name] * rows
+    elif dom_name in per_launch:
+        algo = per_launch[dom_name]
     else:   # fall back to the launch's own count (includes the ~1.5 % gap rows)
         algo = sum(fl for n_, ms, fl, by in prof if n_ == dom_name) / dom_n
     avg_ms = dom_ms / dom_n
@@ -265,19 +282,23 @@ def main():
     peak = PEAK_TFLOPS[args.precision]
     roofline = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
                     frac=round(achieved / peak, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
-                    share_of_kernel_time=round(scout[dom_name] / kernel_ms_per_step, 3),
-                    kernel_ms_per_step_scouted=round(kernel_ms_per_step, 3))
+                    launches_per_step=dom_n // max(args.steps, 1),
+                    # this site's launches (events around it alone, inside the timed region) as a share of the step's wall time: cannot exceed 1
+                    share_of_step_time=round(dom_ms / (1e3 * dt), 3))
     if args.precision != "fp32":
         # what the chip sustains on random bf16 operands with nothing but MFMAs in flight (tools/probes/mfma_shape_probe.hip,
         # profiles/r02_mfma_shape_power_probe.txt: 1.8-2.1 PFLOP/s at 1.8-2.1 GHz, power-limited); `peak` stays the nominal figure
         roofline["measured_mfma_peak"] = 1950.0
         roofline["issued_frac_of_measured_peak"] = round(achieved * {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1, "mix_mx": 2}.get(args.precision, 1) / 1950.0, 4) \
             if dom_name.endswith("ffn1") or args.precision == "bf16x3" else None
-    try:    # HBM-side bytes per launch: rocprofv3 PMC passes of this same command (tools/profile_round.sh -> profiles/)
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-        if tr["workload"] == workload and tr["precision"] == args.precision and tr["kernel_site"] == dom_name and world == 1:
+    try:    # HBM-side bytes per launch: rocprofv3 PMC passes of this same command (tools/profile_round.sh -> profiles/).  The record names the
+        # kernel sources it was measured on: after any change to them it is stale and `traffic` stays null instead of quoting an old kernel
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+        if (tr["workload"] == workload and tr["precision"] == args.precision and tr["kernel_site"] == dom_name and world == 1
+                and tr.get("csrc_sha16") == csrc_sha16()):
             roofline["traffic"] = tr["traffic_bytes"]
-            roofline["traffic_note"] = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r02_traffic.json (separate --pmc passes of this command); algorithmic HBM bytes %d" % tr["algorithmic_bytes"]
+            roofline["traffic_note"] = ("rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r03_traffic.json (separate --pmc passes of this "
+                                        "command on these kernel sources); algorithmic HBM bytes %d" % tr["algorithmic_bytes"])
     except (OSError, KeyError, ValueError):
         pass
     if args.precision in MFMA_PER_PRODUCT and dom_name.endswith("ffn1"):   # split operands: several MFMAs are issued per algorithmic product

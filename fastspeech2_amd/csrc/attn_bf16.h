@@ -208,9 +208,58 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
         const int d = idx >> 3;     /* head channel d -> LDS row 16 (4 (d >> 6) + (d & 3)) + ((d & 63) >> 2) */ \
         *reinterpret_cast<u32x4*>(Vs + swz((((d >> 6) << 2) | (d & 3)) * 16 + ((d & 63) >> 2), idx & 7)) = stg[u]; \
     }
+    // Full tiles (every tile but possibly the last of an utterance) take the FAST staging path: each 16-byte piece a lane moves is described by
+    // loop-invariant 32-bit offsets against a wave-uniform base that advances by a scalar add per tile -- a hi-plane and a lo-plane
+    // instruction share them -- so no per-tile address arithmetic runs on the VALU (PMC, round 2: 3.5 VALU instructions per MFMA, most of
+    // them the 64-bit address chains, the clamps and the masks of the macros above, which now serve the partial tile only).
+    constexpr int NH = NLD / 2;               // instructions per plane and operand tile
+    unsigned kgo[NH], vgo[NH];                // global element offsets inside a K tile / a V^T tile
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+        const int idx = tid + u * 256;
+        const int key = idx / KSL, sl = idx - key * KSL;
+        kgo[u] = (unsigned)(key * a.ldqk + sl * 8);
+        vgo[u] = (unsigned)((idx >> 2) * a.Rvt + (idx & 3) * 8);
+    }
+#define FS2_LOAD_K_FAST(key0_)                                                                              \
+    {                                                                                                       \
+        const __bf16* bh_ = kh_base + (size_t)(s0 + (key0_)) * a.ldqk;                                      \
+        const __bf16* bl_ = kl_base + (size_t)(s0 + (key0_)) * a.ldqk;                                      \
+        _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                    \
+            stg[u] = *reinterpret_cast<const u32x4*>(bh_ + kgo[u]);                                         \
+            stg[NH + u] = *reinterpret_cast<const u32x4*>(bl_ + kgo[u]);                                    \
+        }                                                                                                   \
+    }
+#define FS2_STORE_K_FAST()      /* (the 32-bit LDS addresses are recomputed: keeping them would cost 9 more registers at d_k = 192) */ \
+    _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                        \
+        const int idx = tid + u * 256;                                                                      \
+        const int key = idx / KSL, sl = idx - key * KSL;                                                    \
+        const int i = ((key >> 1) & 12) | (key & 3);                                                        \
+        *reinterpret_cast<u32x4*>(Ks + key * KROW + ((sl ^ i) << 4)) = stg[u];                              \
+        *reinterpret_cast<u32x4*>(Ks + key * KROW + (((KSL + sl) ^ i) << 4)) = stg[NH + u];                 \
+    }
+#define FS2_LOAD_V_FAST(key0_)                                                                              \
+    {                                                                                                       \
+        const __bf16* bh_ = vh_base + s0 + (key0_);                                                         \
+        const __bf16* bl_ = vl_base + s0 + (key0_);                                                         \
+        _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                    \
+            stg[u] = *reinterpret_cast<const u32x4*>(bh_ + vgo[u]);                                         \
+            stg[NH + u] = *reinterpret_cast<const u32x4*>(bl_ + vgo[u]);                                    \
+        }                                                                                                   \
+    }
+#define FS2_STORE_V_FAST()                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                        \
+        const int idx = tid + u * 256;                                                                      \
+        const int n = idx >> 2;                                                                             \
+        const int o_ = swz((((n >> 6) << 2) | (n & 3)) * 16 + ((n & 63) >> 2), idx & 3);                    \
+        *reinterpret_cast<u32x4*>(Vs + o_) = stg[u];                                                        \
+        *reinterpret_cast<u32x4*>(Vs + (o_ ^ 64)) = stg[NH + u];                                            \
+    }
+    // (a tile is "full" when all its 32 keys exist; the staging of tile t and of tile t + 1 may take different paths)
+    bool k_fast = false, v_fast = false;
     if (ntiles > 0) {
-        FS2_LOAD_K(0)
-        FS2_STORE_K()
+        k_fast = 32 <= klen;
+        if (k_fast) { FS2_LOAD_K_FAST(0) FS2_STORE_K_FAST() } else { FS2_LOAD_K(0) FS2_STORE_K() }
     }
 #ifdef FS2_ATT_TIMING
     long long tprev = __builtin_readcyclecounter();
@@ -220,7 +269,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
         FS2_T(5)
         __syncthreads();          // (A) K(kt) visible; every wave is done with P.V(kt-1), so the V^T buffer is free
         FS2_T(0)
-        FS2_LOAD_V(key0)          // in flight during Q.K^T and the softmax
+        v_fast = key0 + 32 <= klen;
+        if (v_fast) { FS2_LOAD_V_FAST(key0) } else { FS2_LOAD_V(key0) }          // in flight during Q.K^T and the softmax
         bf16x8_t ph, pl;
         if (wave_live) {          // (a wave whose 16 queries all lie beyond the utterance only helps with the staging)
         f32x4 st[2];
@@ -314,10 +364,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
         }
         }
         FS2_T(2)
-        FS2_STORE_V()
+        if (v_fast) { FS2_STORE_V_FAST() } else { FS2_STORE_V() }
         __syncthreads();          // (B) V^T(kt) visible; every wave is done with Q.K^T(kt), so the K buffer is free
         FS2_T(3)
-        if (kt + 1 < ntiles) FS2_LOAD_K(key0 + 32)     // in flight during P.V
+        k_fast = key0 + 64 <= klen;
+        if (kt + 1 < ntiles) { if (k_fast) { FS2_LOAD_K_FAST(key0 + 32) } else { FS2_LOAD_K(key0 + 32) } }     // in flight during P.V
         constexpr int PG = (DK > 128) ? 2 : 4;     // n-tiles in flight: independent accumulators between dependent MFMAs
         if (wave_live)
 #pragma unroll
@@ -339,8 +390,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
             for (int u = 0; u < PG; ++u) o[n4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[u], o[n4 + u], 0, 0, 0);
         }
         FS2_T(4)
-        if (kt + 1 < ntiles) FS2_STORE_K()
+        if (kt + 1 < ntiles) { if (k_fast) { FS2_STORE_K_FAST() } else { FS2_STORE_K() } }
     }
+#undef FS2_LOAD_K_FAST
+#undef FS2_STORE_K_FAST
+#undef FS2_LOAD_V_FAST
+#undef FS2_STORE_V_FAST
 #undef FS2_LOAD_K
 #undef FS2_STORE_K
 #undef FS2_LOAD_V

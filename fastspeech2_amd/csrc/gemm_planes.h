@@ -270,9 +270,11 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
 #ifndef FS2_MX_SKIP      // (tools/probes/mx_conv_probe.hip: 1 = no fp16 units, 2 = no e4m3 units)
 #define FS2_MX_SKIP 0
 #endif
-        if (FS2_MX_SKIP != 1) k_loop(std::integral_constant<int, 1>{}, c_begin, nchunks >> 1);
-        if (FS2_MX_SKIP == 1) { it = (nchunks >> 1) * ktaps; __syncthreads(); dma_A(nchunks >> 1, 0); dma_B(it, it & 1); }
-        if (FS2_MX_SKIP != 2) k_loop(std::integral_constant<int, 2>{}, nchunks >> 1, c_end);
+        // (split-K: this workgroup's units [c_begin, c_end) may lie in either half)
+        const int half = nchunks >> 1;
+        if (FS2_MX_SKIP != 1 && c_begin < half) k_loop(std::integral_constant<int, 1>{}, c_begin, c_end < half ? c_end : half);
+        if (FS2_MX_SKIP == 1) { it = half * ktaps; __syncthreads(); dma_A(half, 0); dma_B(it, it & 1); }
+        if (FS2_MX_SKIP != 2 && c_end > half) k_loop(std::integral_constant<int, 2>{}, c_begin > half ? c_begin : half, c_end);
     } else {
         k_loop(std::integral_constant<int, 0>{}, c_begin, c_end);
     }

@@ -581,7 +581,14 @@ class FeedForwardTransformer(nn.Module):
         energy_loss = F.mse_loss(e_outs, es)
         pitch_loss = F.mse_loss(p_outs, ps)
         if self.use_weighted_masking:
-            raise NotImplementedError("use_weighted_masking")
+            # reference fastspeech.py:308-325, quirks included: the weights multiply the already mean-reduced scalars, and they are built
+            # from ys.size(2) -- with use_masking as well, ys is 1-D by now and this raises IndexError exactly as the reference does
+            out_weights = out_masks.float() / out_masks.sum(dim=1, keepdim=True).float()
+            out_weights = out_weights / (ys.size(0) * ys.size(2))
+            duration_weights = in_masks.float() / in_masks.sum(dim=1, keepdim=True).float()
+            duration_weights = duration_weights / ds_t.size(0)
+            l1_loss = l1_loss.mul(out_weights).masked_select(out_masks).sum()
+            duration_loss = duration_loss.mul(duration_weights).masked_select(in_masks).sum()
         loss = l1_loss + duration_loss + energy_loss + pitch_loss
         report_keys = [{"l1_loss": l1_loss.item()}, {"before_loss": before_loss.item()}, {"after_loss": after_loss.item()},
                        {"duration_loss": duration_loss.item()}, {"energy_loss": energy_loss.item()},

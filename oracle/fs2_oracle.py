@@ -297,19 +297,34 @@ def flops(T, L):
     return T * (23855616 + 4096 * T) + L * (40383488 + 6144 * L)
 
 
-def loss_report(out, ys, ilens, olens, ds, es, ps):
-    """The reference's ``forward()`` loss algebra (fastspeech.py:281-333), use_masking=True."""
+def loss_report(out, ys, ilens, olens, ds, es, ps, use_masking=True, use_weighted_masking=False):
+    """The reference's ``forward()`` loss algebra (fastspeech.py:281-333).  ``use_weighted_masking`` re-weights the already
+    mean-reduced l1 / duration losses exactly as the reference does (:308-325; it needs the un-selected 3-D ``ys``, i.e.
+    ``use_masking=False`` -- with both flags the reference raises IndexError on ``ys.size(2)``)."""
     im = _len_mask(ilens, out["d_outs"].shape[1])
     om = _len_mask(olens, out["before"].shape[1])
-    before = out["before"].masked_select(om.unsqueeze(-1))
-    after = out["after"].masked_select(om.unsqueeze(-1))
-    y = ys.masked_select(om.unsqueeze(-1))
+    before, after, y, d_outs, ds_t, e_outs, p_outs = out["before"], out["after"], ys, out["d_outs"], ds, out["e_outs"], out["p_outs"]
+    es, ps = es[:, : before.shape[1]], ps[:, : before.shape[1]]
+    if use_masking:
+        before = before.masked_select(om.unsqueeze(-1))
+        after = after.masked_select(om.unsqueeze(-1))
+        y = ys.masked_select(om.unsqueeze(-1))
+        d_outs, ds_t = d_outs.masked_select(im), ds.masked_select(im)
+        e_outs, p_outs, es, ps = e_outs.masked_select(om), p_outs.masked_select(om), es.masked_select(om), ps.masked_select(om)
     before_loss = F.l1_loss(before, y)
     after_loss = F.l1_loss(after, y)
     l1 = before_loss + after_loss
-    dur = F.mse_loss(out["d_outs"].masked_select(im), torch.log(ds.masked_select(im).float() + 1.0))
-    en = F.mse_loss(out["e_outs"].masked_select(om), es.masked_select(om))
-    pi = F.mse_loss(out["p_outs"].masked_select(om), ps.masked_select(om))
+    dur = F.mse_loss(d_outs, torch.log(ds_t.float() + 1.0))
+    en = F.mse_loss(e_outs, es)
+    pi = F.mse_loss(p_outs, ps)
+    if use_weighted_masking:
+        out_masks = om.unsqueeze(-1)
+        out_weights = out_masks.float() / out_masks.sum(dim=1, keepdim=True).float()
+        out_weights = out_weights / (y.size(0) * y.size(2))
+        dw = im.float() / im.sum(dim=1, keepdim=True).float()
+        dw = dw / ds_t.size(0)
+        l1 = l1.mul(out_weights).masked_select(out_masks).sum()
+        dur = dur.mul(dw).masked_select(im).sum()
     loss = l1 + dur + en + pi
     return loss, [{"l1_loss": l1.item()}, {"before_loss": before_loss.item()}, {"after_loss": after_loss.item()},
                   {"duration_loss": dur.item()}, {"energy_loss": en.item()}, {"pitch_loss": pi.item()},

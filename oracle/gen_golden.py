@@ -305,6 +305,38 @@ def reduction_factor_fixture():
     print("G8 written; worst %.3e" % worst)
 
 
+def weighted_masking_fixture():
+    """G9: the reference's forward() with hp.model.use_weighted_masking = True (fastspeech.py:308-333) -- which only runs with
+    use_masking = False, because the weights are built from ys.size(2) and a masked-selected ys is 1-D.  The real reference's loss and
+    its 7 report values on the G2 batch."""
+    from fastspeech2_amd.synthetic import portable_state_dict
+    from oracle import fs2_oracle as O
+    hp, idim, Ref = import_reference()
+    hp.model.use_masking = False
+    hp.model.use_weighted_masking = True
+    odim = hp.audio.num_mels
+    ref = Ref(idim, odim, hp).eval()
+    sd = portable_state_dict(ref.state_dict(), seed=0)
+    ref.load_state_dict(sd)
+    cfg = O.config_from_hp(hp, idim, odim)
+    np_ = lambda t: t.detach().cpu().numpy()
+    with torch.no_grad():
+        b2 = small_batch(12, [16, 11, 7], 6)
+        r = ref._forward(b2["xs"], b2["ilens"], b2["olens"], b2["ds"].clone(), b2["es"], b2["ps"], is_inference=False)
+        ys = torch.from_numpy(np.random.RandomState(13).uniform(-2, 2, size=tuple(r[0].shape)).astype(np.float32))
+        loss, rep = ref(b2["xs"], b2["ilens"], ys, b2["olens"], b2["ds"].clone(), b2["es"], b2["ps"])
+        o = O.padded_forward(sd, cfg, b2["xs"], b2["ilens"], b2["olens"], b2["ds"], b2["es"], b2["ps"])
+        ol, orep = O.loss_report(o, ys, b2["ilens"], b2["olens"], b2["ds"], b2["es"], b2["ps"], use_masking=False, use_weighted_masking=True)
+    rep_names = [list(d.keys())[0] for d in rep]
+    rep_vals = np.array([list(d.values())[0] for d in rep], np.float64)
+    ovals = np.array([list(d.values())[0] for d in orep], np.float64)
+    print("G9 weighted masking: loss reference %.6f oracle %.6f; report max rel diff %.2e" % (loss.item(), ol.item(), float(np.abs(ovals / rep_vals - 1).max())))
+    assert np.allclose(ovals, rep_vals, rtol=1e-6)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "g9_weighted_masking_b3.npz"), xs=np_(b2["xs"]), ilens=np_(b2["ilens"]),
+                        olens=np_(b2["olens"]), ds=np_(b2["ds"]), es=np_(b2["es"]), ps=np_(b2["ps"]), ys=np_(ys),
+                        loss=np.float64(loss.item()), report_names=np.array(rep_names), report_values=rep_vals)
+
+
 def math_log(v):
     import math
     return math.log(v)
@@ -315,7 +347,10 @@ if __name__ == "__main__":
         block_variants()          # only the block-variant fixture (leaves G1-G6 untouched)
     elif len(sys.argv) > 1 and sys.argv[1] == "g8":
         reduction_factor_fixture()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g9":
+        weighted_masking_fixture()
     else:
         main()
         block_variants()
         reduction_factor_fixture()
+        weighted_masking_fixture()

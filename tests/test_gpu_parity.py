@@ -72,6 +72,30 @@ def test_g2_padded_compat_and_losses(env, golden_dir):
     assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
 
 
+def test_g9_weighted_masking_losses_on_device(golden_dir):
+    """forward() with hp.model.use_weighted_masking = True, use_masking = False against the REAL reference's loss and report values
+    (fixture G9, fastspeech.py:308-333); with both flags the reference itself raises IndexError (ys is 1-D after masked_select) and
+    so does this module."""
+    from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
+    from fastspeech2_amd.synthetic import portable_state_dict
+    g = np.load(golden_dir + "/g9_weighted_masking_b3.npz")
+    hp = default_hparams()
+    hp.model.use_masking, hp.model.use_weighted_masking = False, True
+    model = FeedForwardTransformer(N_PHONEME_SYMBOLS, 80, hp).eval()
+    model.load_state_dict(portable_state_dict(model.state_dict(), seed=0))
+    model = model.to("cuda:0")
+    with torch.no_grad():
+        loss, rep = model(_t(g["xs"]), _t(g["ilens"]), _t(g["ys"]), _t(g["olens"]), _t(g["ds"]), _t(g["es"]), _t(g["ps"]))
+    assert [list(x.keys())[0] for x in rep] == g["report_names"].tolist()
+    got = np.array([list(x.values())[0] for x in rep])
+    assert np.allclose(got, g["report_values"], rtol=1e-4), (got, g["report_values"])
+    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    model.use_masking = True
+    with pytest.raises(IndexError):
+        with torch.no_grad():
+            model(_t(g["xs"]), _t(g["ilens"]), _t(g["ys"]), _t(g["olens"]), _t(g["ds"]), _t(g["es"]), _t(g["ps"]))
+
+
 def test_g6_per_utterance_semantics_in_a_batch(env, golden_dir):
     """Default semantics: every utterance of a padded batch comes out as if it had been run alone."""
     model, sd, cfg, O = env

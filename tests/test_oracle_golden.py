@@ -46,6 +46,19 @@ def test_g2_and_losses(env, golden_dir):
     assert np.allclose([list(d.values())[0] for d in rep], g["report_values"], rtol=1e-5)
 
 
+def test_g9_weighted_masking_losses(env, golden_dir):
+    """hp.model.use_weighted_masking (reference fastspeech.py:308-333; runs only with use_masking = False): the oracle's loss algebra
+    against the real reference's loss and 7 report values."""
+    sd, cfg, O = env
+    g = np.load(golden_dir + "/g9_weighted_masking_b3.npz")
+    o = O.padded_forward(sd, cfg, _t(g["xs"]), _t(g["ilens"]), _t(g["olens"]), _t(g["ds"]), _t(g["es"]), _t(g["ps"]))
+    loss, rep = O.loss_report(o, _t(g["ys"]), _t(g["ilens"]), _t(g["olens"]), _t(g["ds"]), _t(g["es"]), _t(g["ps"]),
+                              use_masking=False, use_weighted_masking=True)
+    assert [list(d.keys())[0] for d in rep] == g["report_names"].tolist()
+    assert np.allclose([list(d.values())[0] for d in rep], g["report_values"], rtol=1e-5)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+
+
 def test_g6_per_utterance(env, golden_dir):
     sd, cfg, O = env
     g2 = np.load(golden_dir + "/g2_teacher_padded_b3.npz")
