@@ -74,6 +74,13 @@ struct GemmArgs {
     int regime_rows;                       // row count the kernel-variant choice is based on (0: R).  Frame-level launches pass an estimate derived from
                                            // the PHONEME count, which the host knows in both layout modes, so that the host- and the device-driven
                                            // layout of one batch always pick the same variants (-> bit-identical results); see fs2_decode
+    // grouped operands (the pitch and the energy predictor as ONE launch per layer, fs2_runtime.hip: run_predictors_fused):
+    //   xp_row_chunks: 32-channel chunks per row of the A planes when the GEMM contracts only a slice of them (0: Cpad / 32);
+    //   k_groups G > 1: the N outputs form G groups, group g contracts the chunks [g Cpad/32, (g+1) Cpad/32) of the plane row (a grouped conv);
+    //   ln_groups G > 1: ReLU / LayerNorm / scalar head apply to each of the G column groups of a row separately (their parameters are
+    //   stacked along N); the scalar head of group g goes to dot_out + g dot_gstride and uses dot_b[g]
+    int xp_row_chunks, k_groups, ln_groups, dot_gstride;
+    int yp_col_off;                        // column offset of this launch's outputs inside the rows of Yp (a layer that fills one group of a stacked plane buffer)
     const int* Rp;                         // device-driven layout: rows actually used (tiles at or beyond round_up(*Rp, 128) exit at once); nullptr: R
 };
 

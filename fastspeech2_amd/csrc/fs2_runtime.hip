@@ -52,6 +52,14 @@ struct Predictor {
     std::vector<float*> lng, lnb;
     float *lin_w = nullptr, *lin_b = nullptr;
 };
+// The energy and the pitch predictor read the same input (reference fastspeech.py:194-196,214-217): in the bf16 modes they run as ONE launch per
+// layer.  Layer 0: the two convolutions stacked along N (2 x chans outputs over one A tile).  Layer 1: a grouped convolution (group g
+// contracts the channels of predictor g's hidden layer) with both scalar heads.  Parameters stacked along N in the order energy | pitch.
+struct FusedPredictors {
+    bool ok = false;
+    Gemm c0, c1;
+    float *ln0g = nullptr, *ln0b = nullptr, *ln1g = nullptr, *ln1b = nullptr, *lin_w = nullptr, *lin_b = nullptr;
+};
 struct Stack {
     std::vector<Layer> layers;
     float* pe = nullptr; int pe_rows = 0;
@@ -75,6 +83,7 @@ struct Options {
     int qkv8 = -1;       // FS2_QKV8     force / forbid the 8-wave fused QKV projection
     int nosplitk = 0;    // FS2_NOSPLITK no split-K of the token-level k = 1 GEMMs
     int f32_rows = 0;    // FS2_F32_ROWS row-complete fp32 GEMM for LayerNorm-terminated ops
+    int fuse_var = 1;    // FS2_FUSE_VAR the pitch and the energy predictor as one launch per layer (0: separate launches)
     int mt8 = -1;        // FS2_MT8      m-tiles per wave of the 8-wave row-complete kernels (2 | 3: 128 / 192-row workgroups)
 };
 int env_int(const char* name, int dflt) {
@@ -85,7 +94,7 @@ Options& opts() {
     static Options o = [] {
         Options x;
         x.bm = env_int("FS2_BM", -1); x.row8 = env_int("FS2_ROW8", -1); x.qkv8 = env_int("FS2_QKV8", -1);
-        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1);
+        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.fuse_var = env_int("FS2_FUSE_VAR", 1);
         return x;
     }();
     return o;
@@ -159,6 +168,7 @@ struct fs2_handle {
     float* enc_embed = nullptr;
     Stack enc, dec;
     Predictor dur, energy, pitch;
+    FusedPredictors var2;
     float *ebins = nullptr, *pbins = nullptr, *Te = nullptr, *Tp = nullptr;
     Gemm dec_in; float *dec_in_lng = nullptr, *dec_in_lnb = nullptr;
     Gemm feat;
@@ -294,12 +304,12 @@ hipError_t launch_row8(hipStream_t s, const GemmArgs& a) {
     return launch_row8_t<NSPLIT, NB, 2>(s, a);
 }
 
-template <int NSPLIT, int NB, int MT>
+template <int NSPLIT, int NB, int MT, int GROUPS = 1>
 hipError_t launch_row8c_t(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
     constexpr size_t lds = row8c_lds_bytes<NB, MT>();
-    allow_lds(reinterpret_cast<const void*>(&gemm_row8c_bf16<NSPLIT, NB, MT>), lds, attr);
-    hipLaunchKernelGGL((gemm_row8c_bf16<NSPLIT, NB, MT>), dim3((a.R + 64 * MT - 1) / (64 * MT)), dim3(512), lds, s, a);
+    allow_lds(reinterpret_cast<const void*>(&gemm_row8c_bf16<NSPLIT, NB, MT, GROUPS>), lds, attr);
+    hipLaunchKernelGGL((gemm_row8c_bf16<NSPLIT, NB, MT, GROUPS>), dim3((a.R + 64 * MT - 1) / (64 * MT), a.k_groups > 1 ? a.k_groups : 1), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 template <int NSPLIT, int NB>
@@ -334,16 +344,17 @@ bool use_qkv8(const GemmArgs& a) {
 // Row-complete LN-fused kernel (gemm_row8_bf16) for k = 1 GEMMs that end in a row epilogue: one workgroup per CU, so it
 // needs about a CU's worth of 128-row tiles to pay (FS2_ROW8=0|1 forces the choice).
 bool use_row8(const GemmArgs& a) {
-    if (a.qk_hi || (a.N != 256 && a.N != 384)) return false;
+    const int Ng = a.k_groups > 1 ? a.N / a.k_groups : a.N;      // (grouped conv: one workgroup row per group, gemm_row8c_bf16's grid.y)
+    const bool two_ln_groups = a.ln_groups == 2 && a.k_groups <= 1 && a.N == 512 && a.ktaps > 1;      // two stacked 256-channel layers over one input
+    if (a.qk_hi || (!two_ln_groups && Ng != 256 && Ng != 384)) return false;
+    if (a.ln_groups > 1 && !two_ln_groups && a.ln_groups != a.k_groups) return false;
     if (a.ktaps > 1) {      // conv form (gemm_row8c_bf16): LayerNorm-terminated convolutions, optionally with the scalar head; no PE
         if (!a.ln_g || a.pe || a.f16_terms) return false;
-    } else if (a.dot_w || !(a.ln_g || a.pe)) return false;
+    } else if (a.dot_w || !(a.ln_g || a.pe) || a.k_groups > 1 || a.ln_groups > 1) return false;
     if (opts().row8 >= 0) return opts().row8 != 0;
     return ((a.regime_rows ? a.regime_rows : a.R) + 127) / 128 >= 128;
 }
 
-// Tile height of the planes kernel: the largest one that still gives every CU its 2-3 resident workgroups
-// (FS2_BM=64|128|256 forces one; k = 1 GEMMs have no 256-row form: two 256-row A buffers would not fit two workgroups per CU).
 // In the 256-row regime the conv kernel runs two workgroups per CU: a launch of T y-tiles per N tile takes ceil(T nN / 512) rounds, and a nearly
 // empty last round costs as much as a full one (c3 at 7.87 frames per phoneme: 143 x 8 tiles = 2.2 rounds -> 3).  The smallest tile height (a
 // multiple of 32 rows, 160 .. 256) that keeps that number of rounds spreads the rows evenly instead (191 tiles of 192 rows: 3 full rounds of
@@ -423,6 +434,7 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         if (!a.Xp && !a.xp_scratch) return fail(h, FS2_ERR_STATE, "%s: no activation planes and no scratch to build them", name);
         if (a.ldy % 4 != 0 || (a.resid && a.ldr % 4 != 0)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: bf16 path needs row strides that are multiples of 4", name);
         const bool row8 = use_row8(a);
+        if (a.yp_col_off && !(row8 && a.ktaps > 1)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: a plane column offset exists in the row-complete conv kernel only", name);
         const bool y_needed = (need_rows && !row8) || (!a.Yp && !a.qk_hi && !(row8 && a.dot_w));      // (row-complete + scalar head: nothing but dot_out leaves)
         if (!t.Y && y_needed) { t.Y = a.scratch; t.ldy = a.N; }
         if (!t.Y && y_needed) return fail(h, FS2_ERR_ARG, "%s: no output or scratch buffer", name);
@@ -472,8 +484,11 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
             } else if (use_qkv8(t)) {
                 if (a.att_D == 384) e = (precision == FS2_PREC_BF16X3) ? launch_qkv8<3, 3>(s, t) : launch_qkv8<1, 3>(s, t);
                 else e = (precision == FS2_PREC_BF16X3) ? launch_qkv8<3, 2>(s, t) : launch_qkv8<1, 2>(s, t);
+            } else if (row8 && a.ktaps > 1 && a.ln_groups == 2 && a.k_groups <= 1) {      // two stacked layers over one input: N = 512, LayerNorm per N-wave
+                e = (precision == FS2_PREC_BF16X3) ? launch_row8c_t<3, 4, 2, 2>(s, t) : launch_row8c_t<1, 4, 2, 2>(s, t);
             } else if (row8 && a.ktaps > 1) {
-                if (a.N == 384) e = (precision == FS2_PREC_BF16X3) ? launch_row8c<3, 3>(s, t) : launch_row8c<1, 3>(s, t);
+                if (a.k_groups > 1) { t.N = a.N / a.k_groups; t.ln_groups = 0; }      // grouped conv: a workgroup row per group (grid.y), N = one group's outputs
+                if (t.N == 384) e = (precision == FS2_PREC_BF16X3) ? launch_row8c<3, 3>(s, t) : launch_row8c<1, 3>(s, t);
                 else e = (precision == FS2_PREC_BF16X3) ? launch_row8c<3, 2>(s, t) : launch_row8c<1, 2>(s, t);
             } else if (row8) {
                 if (a.N == 384) e = (precision == FS2_PREC_BF16X3) ? launch_row8<3, 3>(s, t) : launch_row8<1, 3>(s, t);
@@ -486,7 +501,7 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
             Scope sc(h, s, nm, 0.0, 8.0 * a.R * a.N);
             GemmArgs r = a;
             r.Y = t.Y; r.ldy = t.ldy; r.ksplit = t.ksplit; r.kpart = t.kpart; r.kpart_stride = t.kpart_stride;
-            hipLaunchKernelGGL(ln_rows, dim3((a.R + 3) / 4), dim3(256), 0, s, r);
+            hipLaunchKernelGGL(ln_rows, dim3(((size_t)a.R * (a.ln_groups > 1 ? a.ln_groups : 1) + 3) / 4), dim3(256), 0, s, r);
             e = hipGetLastError();
         }
     } else if (need_rows && a.N >= 128 && a.N <= 1024 && a.N % 4 == 0 && (a.Y || a.scratch) && !opts().f32_rows) {
@@ -910,6 +925,38 @@ int run_predictor(fs2_handle* h, hipStream_t s, const char* tag, const Predictor
     return FS2_OK;
 }
 
+// The pitch and the energy predictor of the bf16 modes as one launch per layer (FusedPredictors).  Every output column is accumulated in the
+// order of the separate launches; the LayerNorm of a 256-column group may be summed in another order than the two-wave form (1e-7).
+int run_predictors_fused(fs2_handle* h, hipStream_t s, const FusedPredictors& v, const float* X, int ldx, int R, const int* row_pos, const int* Rp,
+                         const void* Xp, void* xps, float* vp, float* vs, float* e_rows, float* p_rows, int prec) {
+    const int chans = v.c0.N / 2;
+    int rc;
+    const long regime = h->cur_regime ? h->cur_regime : R;
+    const bool row8 = opts().row8 >= 0 ? opts().row8 != 0 : (regime + 127) / 128 >= 128;
+    if (row8 && (chans == 256 || chans == 384)) {
+        // big grids: layer 0 as two row-complete launches (the stacked 512-column form exists at 128-row tiles only -- 128 accumulator
+        // registers -- and pays a nearly empty second round where the 192-row form does not: c3 0.169 ms against 2 x 0.07), each filling its half
+        // of the stacked plane rows
+        const Predictor* ps[2] = {&h->energy, &h->pitch};
+        for (int g = 0; g < 2; ++g) {
+            GemmArgs a = gemm_args(ps[g]->conv[0], X, ldx, R, row_pos, nullptr, chans);
+            a.Rp = Rp; a.relu_pre = 1; a.ln_g = ps[g]->lng[0]; a.ln_b = ps[g]->lnb[0]; a.ln_eps = 1e-12f;
+            a.Xp = Xp; a.xp_scratch = xps; a.Yp = vp; a.yp_chunks = v.c0.N / 32; a.yp_col_off = g * chans; a.scratch = vs;
+            if ((rc = launch_gemm(h, s, g ? "pitch.conv0" : "energy.conv0", a, prec))) return rc;
+        }
+    } else {
+        GemmArgs a = gemm_args(v.c0, X, ldx, R, row_pos, nullptr, v.c0.N);
+        a.Rp = Rp; a.relu_pre = 1; a.ln_g = v.ln0g; a.ln_b = v.ln0b; a.ln_eps = 1e-12f; a.ln_groups = 2;
+        a.Xp = Xp; a.xp_scratch = xps; a.Yp = vp; a.yp_chunks = v.c0.N / 32; a.scratch = vs;
+        if ((rc = launch_gemm(h, s, "var.conv0", a, prec))) return rc;
+    }
+    GemmArgs a = gemm_args(v.c1, nullptr, v.c0.N, R, row_pos, nullptr, v.c1.N);
+    a.Rp = Rp; a.relu_pre = 1; a.ln_g = v.ln1g; a.ln_b = v.ln1b; a.ln_eps = 1e-12f; a.ln_groups = 2; a.k_groups = 2;
+    a.Xp = vp; a.xp_row_chunks = v.c0.N / 32; a.scratch = vs;
+    a.dot_w = v.lin_w; a.dot_b = v.lin_b; a.dot_out = e_rows; a.dot_gstride = (int)(p_rows - e_rows);
+    return launch_gemm(h, s, "var.conv1", a, prec);
+}
+
 // ------------------------------------------------------------------ weight loading
 // src [rows, cols] -> dst with every block of dk rows (by_cols: columns) moved to a block of dkp (dst pre-zeroed)
 __global__ void pad_heads(const float* src, int rows, int cols, int dk, int dkp, int by_cols, float* dst) {
@@ -979,6 +1026,19 @@ struct Loader {
         for (int64_t v : shape) n *= (size_t)v;
         float* p = dalloc(n);
         if (p && hipMemcpyAsync(p, d->data, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess && !rc) rc = fail(h, FS2_ERR_HIP, "copy of %s failed", name.c_str());
+        return p;
+    }
+    // two reference tensors of n elements each, back to back (parameters of stacked layers)
+    float* copy2(const std::string& a_, const std::string& b_, std::initializer_list<int64_t> shape) {
+        const fs2_tensor_desc *da = get(a_, shape), *db = get(b_, shape);
+        if (!da || !db) return nullptr;
+        size_t n = 1;
+        for (int64_t v : shape) n *= (size_t)v;
+        float* p = dalloc(2 * n);
+        if (p) {
+            hipMemcpyAsync(p, da->data, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+            hipMemcpyAsync(p + n, db->data, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+        }
         return p;
     }
     // parts: weights stacked along N (q|k|v); each [n_i, C, k] (k omitted for Linear)
@@ -1197,6 +1257,7 @@ size_t carve_tokens(const fs2_config& c, const fs2_batch& b, const HostLayout& L
 
 struct FrameBufs {
     int* meta; float* hfr; float *t0, *t1, *e_rows, *p_rows; StackBufs sb; float *before, *after; int *qe, *qp, *lri;
+    float *vp = nullptr, *vs = nullptr;      // fused pitch + energy predictors: planes of the stacked hidden layer [R][2 chans], fp32 scratch [R, 2 chans]
     float* kp; size_t kp_cap;
     // reduction_factor r > 1: the Postnet runs on r rows per decoder row (its own row metadata and ping-pong buffers)
     int* meta2 = nullptr; float *pa2 = nullptr, *pb2 = nullptr, *xps2 = nullptr;
@@ -1212,6 +1273,8 @@ size_t carve_frames(const fs2_config& c, const HostLayout& L, void* ws, size_t c
     f.t1 = bp.take<float>(R * c.var_chans);
     f.e_rows = bp.take<float>(R);
     f.p_rows = bp.take<float>(R);
+    f.vp = bp.take<float>(R * 2 * (size_t)c.var_chans);
+    f.vs = bp.take<float>(R * 2 * (size_t)c.var_chans);
     f.sb.x0 = bp.take<float>(R * c.ddim);
     f.sb.x1 = bp.take<float>(R * c.ddim);
     const size_t dDp = att_width(c.ddim, c.aheads);
@@ -1352,6 +1415,20 @@ int fs2_load_weights(fs2_handle* h, const fs2_tensor_desc* t, int32_t n, void* s
     load_predictor(L, h->dur, "duration_predictor", c.dur_layers, c.adim, c.dur_chans, c.dur_kernel);
     load_predictor(L, h->energy, "energy_predictor.predictor", c.var_layers, c.adim, c.var_chans, c.var_kernel);
     load_predictor(L, h->pitch, "pitch_predictor.predictor", c.var_layers, c.adim, c.var_chans, c.var_kernel);
+    h->var2 = FusedPredictors();
+    if (c.var_layers == 2 && c.var_chans % 128 == 0 && c.adim % 32 == 0) {
+        const std::string e = "energy_predictor.predictor", q = "pitch_predictor.predictor";
+        FusedPredictors& v = h->var2;
+        v.c0 = L.gemm({e + ".conv.0.0.weight", q + ".conv.0.0.weight"}, {e + ".conv.0.0.bias", q + ".conv.0.0.bias"}, c.var_chans, c.adim, c.var_kernel, false);
+        v.c1 = L.gemm({e + ".conv.1.0.weight", q + ".conv.1.0.weight"}, {e + ".conv.1.0.bias", q + ".conv.1.0.bias"}, c.var_chans, c.var_chans, c.var_kernel, false);
+        v.ln0g = L.copy2(e + ".conv.0.2.layer_norm.weight", q + ".conv.0.2.layer_norm.weight", {c.var_chans});
+        v.ln0b = L.copy2(e + ".conv.0.2.layer_norm.bias", q + ".conv.0.2.layer_norm.bias", {c.var_chans});
+        v.ln1g = L.copy2(e + ".conv.1.2.layer_norm.weight", q + ".conv.1.2.layer_norm.weight", {c.var_chans});
+        v.ln1b = L.copy2(e + ".conv.1.2.layer_norm.bias", q + ".conv.1.2.layer_norm.bias", {c.var_chans});
+        v.lin_w = L.copy2(e + ".linear.weight", q + ".linear.weight", {1, c.var_chans});
+        v.lin_b = L.copy2(e + ".linear.bias", q + ".linear.bias", {1});
+        v.ok = !L.rc;
+    }
     h->ebins = L.copy("energy_predictor.energy_bins", {c.n_bins - 1});
     h->pbins = L.copy("pitch_predictor.pitch_bins", {c.n_bins - 1});
     h->Te = L.dalloc((size_t)c.n_bins * c.adim);
@@ -1562,8 +1639,12 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         HIP_TRY(h, hipGetLastError());
     }
     const bool need_e = (io->es == nullptr) || io->e_out, need_p = (io->ps == nullptr) || io->p_out;
-    if (need_e && (rc = run_predictor(h, s, "energy", h->energy, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.e_rows, prec, hfr_planes, f.sb.xps, dl.dims))) return rc;
-    if (need_p && (rc = run_predictor(h, s, "pitch", h->pitch, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.p_rows, prec, hfr_planes, f.sb.xps, dl.dims))) return rc;
+    if (need_e && need_p && prec != FS2_PREC_FP32 && h->var2.ok && hfr_planes && opts().fuse_var) {
+        if ((rc = run_predictors_fused(h, s, h->var2, f.hfr, c.adim, R, dl.row_pos, dl.dims, hfr_planes, f.sb.xps, f.vp, f.vs, f.e_rows, f.p_rows, prec))) return rc;
+    } else {
+        if (need_e && (rc = run_predictor(h, s, "energy", h->energy, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.e_rows, prec, hfr_planes, f.sb.xps, dl.dims))) return rc;
+        if (need_p && (rc = run_predictor(h, s, "pitch", h->pitch, f.hfr, c.adim, R, dl.row_pos, f.t0, f.t1, f.p_rows, prec, hfr_planes, f.sb.xps, dl.dims))) return rc;
+    }
     {
         Scope sc(h, s, "var.embed", 0, 4.0 * R * c.adim * 4);
         hipLaunchKernelGGL(bucket_embed, dim3((R + 3) / 4), dim3(256), 0, s, f.hfr, c.adim, dl.row_pos, dl.row_seq, R, io->es, io->es_stride,
@@ -1887,6 +1968,7 @@ int fs2_set_option(const char* name, int32_t value) {
     else if (n == "FS2_NOSPLITK") o.nosplitk = value > 0;
     else if (n == "FS2_F32_ROWS") o.f32_rows = value > 0;
     else if (n == "FS2_MT8") o.mt8 = value;
+    else if (n == "FS2_FUSE_VAR") o.fuse_var = value != 0;
     else return fail(nullptr, FS2_ERR_ARG, "fs2_set_option: unknown option %s", name);
     return FS2_OK;
 }

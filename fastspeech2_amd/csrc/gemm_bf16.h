@@ -144,18 +144,26 @@ __device__ __forceinline__ int loadi_or_zero(const int* p, bool ok) {
 //   v = LN(y) (if ln_g) -> act_post -> v*x_scale + alpha*pe[pos] -> store; dot_out[row] = v . dot_w + dot_b
 // With Yp the result is also written as split-bf16 planes, the A operand of the next GEMM (gemm_planes.h).
 __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // ln_groups G > 1: every row holds G independent column groups (stacked layers over one input): one wavefront per (row, group)
+    const int G = a.ln_groups > 1 ? a.ln_groups : 1;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = G > 1 ? unit / G : unit, grp = G > 1 ? unit - row * G : 0;
     const int lane = threadIdx.x & 63;
     if (row >= a.R) return;
+    const int N = a.N / G, co = grp * N;             // this unit's columns [co, co + N)
     const int pos = a.row_pos ? a.row_pos[row] : 0;
-    float* y = a.Y + (size_t)row * a.ldy;
-    const float* ysrc = a.Ysrc ? a.Ysrc + (size_t)row * a.ldsrc : y;      // out-of-place form (pre-LN blocks keep the un-normalised stream)
-    const int pc = a.Yp ? a.yp_chunks * 32 : 0;      // channels of the output planes (>= N, zero padded)
+    float* y = a.Y + (size_t)row * a.ldy + co;
+    const float* ysrc = a.Ysrc ? a.Ysrc + (size_t)row * a.ldsrc + co : y;      // out-of-place form (pre-LN blocks keep the un-normalised stream)
+    const int pc = a.Yp ? (G > 1 ? N : a.yp_chunks * 32) : 0;      // channels of the output planes (>= N, zero padded)
+    const float* ln_g = a.ln_g ? a.ln_g + co : nullptr;
+    const float* ln_b = a.ln_b ? a.ln_b + co : nullptr;
+    const float* dot_w = a.dot_w ? a.dot_w + co : nullptr;
+    float* dot_out = a.dot_out ? a.dot_out + (size_t)grp * a.dot_gstride : nullptr;
     if (pos < 0) {
         if (a.Y)
-            for (int c = lane * 4; c < a.N; c += 256) *reinterpret_cast<float4*>(y + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c = lane * 4; c < pc; c += 256) store_planes4m(a.Yp, row, a.yp_chunks, c, f32x4{0.f, 0.f, 0.f, 0.f}, a.yp_f16, a.yp_scale);
-        if (a.dot_w && lane == 0) a.dot_out[row] = 0.f;
+            for (int c = lane * 4; c < N; c += 256) *reinterpret_cast<float4*>(y + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = lane * 4; c < pc; c += 256) store_planes4m(a.Yp, row, a.yp_chunks, co + c, f32x4{0.f, 0.f, 0.f, 0.f}, a.yp_f16, a.yp_scale);
+        if (dot_w && lane == 0) dot_out[row] = 0.f;
         return;
     }
     float4 v[4];
@@ -163,10 +171,10 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = lane * 4 + j * 256;
-        v[j] = (c < a.N) ? *reinterpret_cast<const float4*>(ysrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < a.N)
+        v[j] = (c < N) ? *reinterpret_cast<const float4*>(ysrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < N)
             for (int z = 1; z < a.ksplit; ++z) {      // split-K partials of the GEMM, added in a fixed order
-                const float4 q = *reinterpret_cast<const float4*>(a.kpart + (size_t)(z - 1) * a.kpart_stride + (size_t)row * a.ldy + c);
+                const float4 q = *reinterpret_cast<const float4*>(a.kpart + (size_t)(z - 1) * a.kpart_stride + (size_t)row * a.ldy + co + c);
                 v[j].x += q.x; v[j].y += q.y; v[j].z += q.z; v[j].w += q.w;
             }
         if (a.relu_pre) {      // ReLU in front of the LayerNorm (predictors); idempotent when the GEMM epilogue already applied it
@@ -174,26 +182,26 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
         }
         s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
     }
-    if (a.ln_g) {
+    if (ln_g) {
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const float mean = s / (float)a.N;
+        const float mean = s / (float)N;
         float q = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = lane * 4 + j * 256;
-            if (c < a.N) {
+            if (c < N) {
                 const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
                 q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
             }
         }
         for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-        const float rstd = 1.f / sqrtf(q / (float)a.N + a.ln_eps);
+        const float rstd = 1.f / sqrtf(q / (float)N + a.ln_eps);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = lane * 4 + j * 256;
-            if (c < a.N) {
-                const float4 g = *reinterpret_cast<const float4*>(a.ln_g + c);
-                const float4 b = *reinterpret_cast<const float4*>(a.ln_b + c);
+            if (c < N) {
+                const float4 g = *reinterpret_cast<const float4*>(ln_g + c);
+                const float4 b = *reinterpret_cast<const float4*>(ln_b + c);
                 v[j].x = (v[j].x - mean) * rstd * g.x + b.x;
                 v[j].y = (v[j].y - mean) * rstd * g.y + b.y;
                 v[j].z = (v[j].z - mean) * rstd * g.z + b.z;
@@ -206,28 +214,28 @@ __global__ __launch_bounds__(256) void ln_rows(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = lane * 4 + j * 256;
-        if (c < a.N) {
+        if (c < N) {
             float4 t = v[j];
             t.x = apply_act(t.x, a.act_post); t.y = apply_act(t.y, a.act_post);
             t.z = apply_act(t.z, a.act_post); t.w = apply_act(t.w, a.act_post);
             if (a.pe) {
-                const float4 p = *reinterpret_cast<const float4*>(a.pe + (size_t)pos * a.pe_ld + c);
+                const float4 p = *reinterpret_cast<const float4*>(a.pe + (size_t)pos * a.pe_ld + co + c);
                 t.x = t.x * a.x_scale + alpha * p.x; t.y = t.y * a.x_scale + alpha * p.y;
                 t.z = t.z * a.x_scale + alpha * p.z; t.w = t.w * a.x_scale + alpha * p.w;
             }
-            if (a.dot_w) {
-                const float4 w = *reinterpret_cast<const float4*>(a.dot_w + c);
+            if (dot_w) {
+                const float4 w = *reinterpret_cast<const float4*>(dot_w + c);
                 d += (t.x * w.x + t.y * w.y) + (t.z * w.z + t.w * w.w);
             }
             if (a.Y) *reinterpret_cast<float4*>(y + c) = t;
-            if (a.Yp) store_planes4m(a.Yp, row, a.yp_chunks, c, f32x4{t.x, t.y, t.z, t.w}, a.yp_f16, a.yp_scale);
+            if (a.Yp) store_planes4m(a.Yp, row, a.yp_chunks, co + c, f32x4{t.x, t.y, t.z, t.w}, a.yp_f16, a.yp_scale);
         } else if (c < pc) {
-            store_planes4m(a.Yp, row, a.yp_chunks, c, f32x4{0.f, 0.f, 0.f, 0.f}, a.yp_f16, a.yp_scale);
+            store_planes4m(a.Yp, row, a.yp_chunks, co + c, f32x4{0.f, 0.f, 0.f, 0.f}, a.yp_f16, a.yp_scale);
         }
     }
-    if (a.dot_w) {
+    if (dot_w) {
         for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
-        if (lane == 0) a.dot_out[row] = d + (a.dot_b ? a.dot_b[0] : 0.f);
+        if (lane == 0) dot_out[row] = d + (a.dot_b ? a.dot_b[grp] : 0.f);
     }
 }
 

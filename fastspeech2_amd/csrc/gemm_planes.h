@@ -126,8 +126,10 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     const int a_instr = K1 ? BM / 8 : (BM + 2 * P + 7) >> 3;
     const int sA = jslot ^ (jrow >> 1) ^ ((wave & 1) << 2);
     const int arow0 = m0 - P + wave * 8 + jrow;
-    const __bf16* a_src0 = Xp + (ptrdiff_t)arow0 * nchunks * 64 + sA * 8;      // dereferenced only when the row is in [0, R)
-    const size_t a_qstride = (size_t)32 * nchunks * 64;
+    const int xrc = a.xp_row_chunks ? a.xp_row_chunks : nchunks;      // chunks per plane row; grouped conv: this N tile's group starts at chunk cg
+    const int cg = a.k_groups > 1 ? (n0 / (a.N / a.k_groups)) * nchunks : 0;
+    const __bf16* a_src0 = Xp + (ptrdiff_t)arow0 * xrc * 64 + sA * 8 + cg * 64;      // dereferenced only when the row is in [0, R)
+    const size_t a_qstride = (size_t)32 * xrc * 64;
     // LDS destinations of the DMA instructions as SCALARS (M0 = SGPR arithmetic; otherwise hipcc keeps the LDS pointer in a VGPR
     // and pays a v_readfirstlane + M0 hazard per instruction: the issue of the 4-6 instructions of a step took 13-30 % of it)
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t*)smem_p);
@@ -591,9 +593,14 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
 //     end of a chunk, exactly as in gemm_pl_bf16's conv form); B: one 128 NB x 128 B tile per (chunk, tap), double-buffered.
 template <int NB, int MT = 2> constexpr size_t row8c_lds_bytes() { return (size_t)(64 * MT + kMaxHalo) * 128 + 2 * (size_t)(128 * NB) * 128; }
 
-template <int NSPLIT, int NB, int MT = 2>
+// GROUPS = 2 (NB = 4: N = 512 = two stacked 256-channel layers over ONE input, the first layer of the pitch and the energy predictor): every
+// N-wave holds one group's 256 columns, so ReLU / LayerNorm statistics stay inside the wave.  grid.y = a.k_groups > 1 (the second layer of
+// the two predictors as one launch): workgroup (x, g) computes group g's N outputs from chunks [g Cpad/32, ..) of the plane rows, with the
+// weights, bias, LayerNorm parameters and scalar head of group g (all stacked along N).
+template <int NSPLIT, int NB, int MT = 2, int GROUPS = 1>
 __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
     constexpr int NT = 4 * NB, BM = 64 * MT, BN = 128 * NB, RW = 16 * MT;
+    static_assert(GROUPS == 1 || (GROUPS == 2 && NB == 4), "two groups = two N-waves of 256 columns");
     constexpr int AROWS = BM + kMaxHalo;
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     char* As = smem_c;
@@ -606,17 +613,21 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
     const int ktaps = a.ktaps, P = (ktaps - 1) >> 1;
     const int lr = lane & 15, lg = lane >> 4;
     const int lp = rperm(lr);
-    const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
-    const __bf16* Xp = reinterpret_cast<const __bf16*>(a.Xp);
     const int nchunks = a.Cpad / 32;
     const int niter = nchunks * ktaps;
+    const int kg = a.k_groups > 1 ? (int)blockIdx.y : 0;             // input / parameter group of this workgroup
+    const int xrc = a.xp_row_chunks ? a.xp_row_chunks : nchunks;
+    const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W) + (size_t)kg * BN * niter * 64;
+    const __bf16* Xp = reinterpret_cast<const __bf16*>(a.Xp) + (size_t)kg * nchunks * 64;
+    if (kg) { a.bias = a.bias ? a.bias + kg * BN : nullptr; a.ln_g = a.ln_g ? a.ln_g + kg * BN : nullptr; a.ln_b = a.ln_b ? a.ln_b + kg * BN : nullptr;
+              a.dot_w = a.dot_w ? a.dot_w + kg * BN : nullptr; a.dot_b = a.dot_b ? a.dot_b + kg : nullptr; a.dot_out = a.dot_out ? a.dot_out + (size_t)kg * a.dot_gstride : nullptr; }
     const int jrow = lane >> 3, jslot = lane & 7;
     // A: instruction q = w, w + 8, w + 16 fills tile rows 8q + jrow (q & 1 == w & 1, so the swizzle term is a per-lane constant)
     const int a_instr = (BM + 2 * P + 7) >> 3;
     const int sA = jslot ^ (jrow >> 1) ^ ((wave & 1) << 2);
     const int arow0 = m0 - P + wave * 8 + jrow;
-    const __bf16* a_src0 = Xp + (ptrdiff_t)arow0 * nchunks * 64 + sA * 8;
-    const size_t a_qstride = (size_t)64 * nchunks * 64;
+    const __bf16* a_src0 = Xp + (ptrdiff_t)arow0 * xrc * 64 + sA * 8;
+    const size_t a_qstride = (size_t)64 * xrc * 64;
     auto dma_A = [&](int ch) {
         char* dst = As + wave * 1024;
         const __bf16* src = a_src0 + (size_t)ch * 64;
@@ -709,7 +720,20 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
     float* red = reinterpret_cast<float*>(smem_c);      // [3 passes][8 waves][RW rows]
     float mean[MT][4], rstd[MT][4];
     __syncthreads();                                    // operand buffers are dead
+    const int n_ln = GROUPS == 2 ? a.N / 2 : a.N;      // columns one LayerNorm runs over
     if (a.ln_g) {
+        if constexpr (GROUPS == 2) {      // the wave holds the whole group: no exchange
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    mean[mt][r] = rsum[mt][r] / (float)n_ln;
+                    float q = 0.f;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) { const float d = acc[mt][n][r] - mean[mt][r]; q += d * d; }
+                    rstd[mt][r] = 1.f / sqrtf(wave16_sum(q) / (float)n_ln + a.ln_eps);
+                }
+        } else {
         if (lr == 0)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -737,6 +761,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 rstd[mt][r] = 1.f / sqrtf((rsum[mt][r] + red[8 * RW + (wave ^ 1) * RW + mt * 16 + lg * 4 + r]) / (float)a.N + a.ln_eps);
+        }
     }
     float dsum[MT][4];
 #pragma unroll
@@ -766,7 +791,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
                 }
                 if (row < a.R) {
                     if (Y) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
-                    if (Yp) store_planes4m(Yp, row, a.yp_chunks, col, v, a.yp_f16, a.yp_scale);
+                    if (Yp) store_planes4m(Yp, row, a.yp_chunks, col + a.yp_col_off, v, a.yp_f16, a.yp_scale);
                 }
             }
     }

@@ -204,6 +204,33 @@ def test_c2_row_complete_tile_heights_are_bit_identical(env, fs2_option):
         model.precision = "fp32"
 
 
+@pytest.mark.parametrize("row8", [0, 1])
+def test_c2_fused_pitch_and_energy_predictors(env, row8, fs2_option):
+    """The two variance predictors read the same input (reference fastspeech.py:194-196,214-217): in the bf16 modes they run as one launch per
+    layer -- layer 0 stacked along N over one A tile, layer 1 a grouped convolution with both scalar heads.  Both kernel families (64-row
+    tiles + row pass / 8-wave row-complete) against the oracle, and against the separate launches: predictor outputs within 1e-5 (LayerNorm sums associate differently), bucket
+    indices identical."""
+    model, sd, cfg, O = env
+    from fastspeech2_amd.synthetic import make_batch
+    b = make_batch("c2")
+    fs2_option("FS2_ROW8", row8)
+    model.precision = "bf16x3"
+    try:
+        outs = []
+        for fuse in (1, 0):
+            fs2_option("FS2_FUSE_VAR", fuse)
+            with torch.no_grad():
+                outs.append(model._run(b["xs"].cuda(), b["ilens"], is_inference=True, d_override=b["ds"].cuda(), want=("after", "e_outs", "p_outs", "qe", "qp")))
+        fs2_option("FS2_FUSE_VAR", 1)
+        _c2_body(model, sd, cfg, O, b, "bf16x3")
+    finally:
+        model.precision = "fp32"
+    f, u = outs
+    assert _maxabs(f["e_outs"], u["e_outs"].cpu()) <= 1e-5 and _maxabs(f["p_outs"], u["p_outs"].cpu()) <= 1e-5
+    assert torch.equal(f["qe"], u["qe"]) and torch.equal(f["qp"], u["qp"])
+    assert _maxabs(f["after"], u["after"].cpu()) <= 1e-5
+
+
 @pytest.mark.parametrize("qkv8", ["0", "1"])
 def test_c2_qkv_kernel_choice(env, qkv8, fs2_option):
     """The fused QKV projection has two bf16 implementations (64 x 128 tiles / three 128 x D passes of an 8-wave workgroup,

@@ -1,13 +1,10 @@
 #!/bin/bash
-mkdir -p gpurun_out/r3g
-python -m pytest tests/test_gpu_ops.py -x -q -k "attention" 2>&1 | tail -3 > gpurun_out/r3g/pytest_attn.txt
-python -m pytest tests/test_gpu_parity.py -x -q -k "c2_batch or c1_single or g9 or c4" 2>&1 | tail -3 > gpurun_out/r3g/pytest_par.txt
-python bench.py --no-cpu-baseline --profile-kernels > /dev/null 2> gpurun_out/r3g/sites_c3.txt
-python bench.py --no-cpu-baseline --workload c4 --profile-kernels > /dev/null 2> gpurun_out/r3g/sites_c4.txt
-python bench.py --no-cpu-baseline --workload c4 > gpurun_out/r3g/bench_c4.json 2>/dev/null
-python bench.py --no-cpu-baseline --workload c1 > gpurun_out/r3g/bench_c1.json 2>/dev/null
-python bench.py --no-cpu-baseline > gpurun_out/r3g/bench_c3.json 2>/dev/null
-tail -n 2 gpurun_out/r3g/pytest_attn.txt gpurun_out/r3g/pytest_par.txt
-for f in gpurun_out/r3g/bench_*.json; do cut -c1-170 $f; done
-grep -v amdgpu gpurun_out/r3g/sites_c3.txt | head -6
-grep -v amdgpu gpurun_out/r3g/sites_c4.txt | head -6
+mkdir -p gpurun_out/r3h
+python -m pytest tests/test_gpu_parity.py -x -q -k "c2 or c3_free or g1 or device_driven or c1_single" 2>&1 | tail -4 > gpurun_out/r3h/pytest_par.txt
+tail -n 4 gpurun_out/r3h/pytest_par.txt
+for fv in 1 0 1 0; do
+FS2_FUSE_VAR=$fv python bench.py --no-cpu-baseline > gpurun_out/r3h/bench_c3_fuse$fv.json 2>/dev/null
+FS2_FUSE_VAR=$fv python bench.py --no-cpu-baseline --workload c1 > gpurun_out/r3h/bench_c1_fuse$fv.json 2>/dev/null
+echo "fuse=$fv c3 $(python -c "import json;d=json.load(open('gpurun_out/r3h/bench_c3_fuse$fv.json'));print(d['value'], d['ms_per_step'])") c1 $(python -c "import json;d=json.load(open('gpurun_out/r3h/bench_c1_fuse$fv.json'));print(d['value'], d['ms_per_step'])")"
+done
+python bench.py --no-cpu-baseline --profile-kernels 2>&1 >/dev/null | grep "var\.\|energy\|pitch"
