@@ -51,7 +51,8 @@ def csrc_sha16():
     hsh = hashlib.sha256()
     d = os.path.join(ROOT, "fastspeech2_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        hsh.update(open(os.path.join(d, f), "rb").read())
+        if f.endswith((".h", ".hip", ".cpp")):
+            hsh.update(open(os.path.join(d, f), "rb").read())
     return hsh.hexdigest()[:16]
 
 

@@ -284,6 +284,9 @@ hipError_t launch_pl_t(hipStream_t s, const GemmArgs& a) {
 // Same-box A/B: a 192-row tile costs 1.55-1.9 x a 128-row one (its epilogue spills), so it pays exactly when it turns two rounds into one
 // (c3: dec.ffn2_ln 0.174 -> 0.134 ms, step 5.68 -> 5.34 ms; c4, 15 rounds against 10: 68.0 -> 70.8 ms, so not there).  Results do not depend on MT.
 constexpr int kCus = 256;
+// Rows a launch will really touch: in the device-driven layout a.R is a capacity (15-25 % above the rows in use, the surplus tiles exit at once);
+// the regime estimate (8 frames per phoneme + alignment rows, the same number in both layout modes) is the better basis for balancing rounds.
+inline long rows_in_use(const GemmArgs& a, long rows) { return a.regime_rows > 0 ? std::min<long>(rows, a.regime_rows) : rows; }
 inline int row8_mt(long rows) {
     const long t128 = (rows + 127) / 128, t192 = (rows + 191) / 192;
     return (t128 > kCus && t192 <= kCus) ? 3 : 2;
@@ -299,7 +302,7 @@ hipError_t launch_row8_t(hipStream_t s, const GemmArgs& a) {
 }
 template <int NSPLIT, int NB>
 hipError_t launch_row8(hipStream_t s, const GemmArgs& a) {
-    const int mt = opts().mt8 > 0 ? opts().mt8 : row8_mt(a.R);
+    const int mt = opts().mt8 > 0 ? opts().mt8 : row8_mt(rows_in_use(a, a.R));
     if (mt >= 3) return launch_row8_t<NSPLIT, NB, 3>(s, a);
     return launch_row8_t<NSPLIT, NB, 2>(s, a);
 }
@@ -314,7 +317,7 @@ hipError_t launch_row8c_t(hipStream_t s, const GemmArgs& a) {
 }
 template <int NSPLIT, int NB>
 hipError_t launch_row8c(hipStream_t s, const GemmArgs& a) {
-    const int mt = opts().mt8 > 0 ? opts().mt8 : row8_mt(a.R);
+    const int mt = opts().mt8 > 0 ? opts().mt8 : row8_mt(rows_in_use(a, a.R));
     if (mt >= 3) return launch_row8c_t<NSPLIT, NB, 3>(s, a);
     return launch_row8c_t<NSPLIT, NB, 2>(s, a);
 }
@@ -329,7 +332,7 @@ hipError_t launch_qkv8_t(hipStream_t s, const GemmArgs& a) {
 }
 template <int NSPLIT, int NB>
 hipError_t launch_qkv8(hipStream_t s, const GemmArgs& a) {
-    const int mt = opts().mt8 > 0 ? opts().mt8 : row8_mt(a.Rvt);
+    const int mt = opts().mt8 > 0 ? opts().mt8 : row8_mt(rows_in_use(a, a.Rvt));
     if (mt >= 3) return launch_qkv8_t<NSPLIT, NB, 3>(s, a);
     return launch_qkv8_t<NSPLIT, NB, 2>(s, a);
 }
@@ -385,7 +388,7 @@ hipError_t launch_pl(hipStream_t s, const GemmArgs& a) {
     }
     bm = force ? force : (nN * ((rows + 255) / 256) >= 512 ? 256 : (nN * ((rows + 127) / 128) >= 400 ? 128 : 64));
     if (bm > 128) {
-        if (!force && a.ksplit <= 1) bm = conv_bm_balanced(rows, nN);
+        if (!force && a.ksplit <= 1) bm = conv_bm_balanced(rows_in_use(a, rows), nN);
         if constexpr (NSPLIT == 3) return launch_pl_tall<3, 0>(s, a, bm);
         else return launch_pl_t<NSPLIT, 256, false>(s, a);
     }
@@ -397,7 +400,7 @@ hipError_t launch_mx(hipStream_t s, const GemmArgs& a) {
     const int force = opts().bm > 0 ? opts().bm : 0;
     const long nN = (a.N + kB16BN - 1) / kB16BN;
     int bm = force ? force : (nN * ((a.R + 255) / 256) >= 512 ? 256 : (nN * ((a.R + 127) / 128) >= 400 ? 128 : 64));
-    if (bm > 128) return launch_pl_tall<1, 2>(s, a, force ? bm : conv_bm_balanced(a.R, nN));
+    if (bm > 128) return launch_pl_tall<1, 2>(s, a, force ? bm : conv_bm_balanced(rows_in_use(a, a.R), nN));
     return bm == 128 ? launch_pl_t<1, 128, false, 2>(s, a) : launch_pl_t<1, 64, false, 2>(s, a);
 }
 

@@ -1,13 +1,13 @@
 """End-to-end latency of one-utterance calls (host work + GPU + synchronisation) and a cProfile of the host side.
    python tools/latency_c1.py      (on an MI355X)"""
 import time, torch, sys
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
-from fastspeech2_amd.synthetic import portable_state_dict, bias_durations, make_batch
+from fastspeech2_amd.synthetic import portable_state_dict, ljspeech_durations, make_batch
 hp = default_hparams()
 model = FeedForwardTransformer(N_PHONEME_SYMBOLS, hp.audio.num_mels, hp).eval()
-model.load_state_dict(bias_durations(portable_state_dict(model.state_dict(), seed=0)))
-model = model.cuda(); model.precision = "bf16x3"
+model.load_state_dict(ljspeech_durations(portable_state_dict(model.state_dict(), seed=0)))
+model = model.cuda(); model.precision = "mix_mx"
 b = make_batch("c1")
 x = b["xs"][0, : int(b["ilens"][0])].cuda()
 with torch.no_grad():

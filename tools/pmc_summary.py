@@ -7,9 +7,9 @@ HBM traffic = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes): on gfx950 FETCH_SIZE ta
 coalesced reads at 64 B (MI355X_MICROARCH.md, HBM/rocprofv3 section); WRITE_SIZE is used as is."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 workload = os.environ.get("FS2_PROF_WORKLOAD", "c3")
-precision = os.environ.get("FS2_PROF_PRECISION", "bf16x3")
+precision = os.environ.get("FS2_PROF_PRECISION", "mix_mx")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
@@ -22,7 +22,7 @@ stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursi
 if stats:
     shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for sub in ("fetch", "write", "sq"):
+for sub in ("fetch", "write", "sq", "sq2"):
     for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = (short(r["Kernel_Name"]), int(r["Grid_Size"]))
@@ -50,6 +50,9 @@ info = {"_comment": "HBM-side traffic of the dominant kernel per launch: rocprof
         "workload": workload, "precision": precision, "kernel": kern, "grid_size": grid, "launches_averaged": len(v["FETCH_SIZE"]),
         "fetch_size_kb_raw": round(fetch, 1), "write_size_kb": round(write, 1), "traffic_bytes": int((2 * fetch + write) * 1024),
         "avg_duration_us_pmc_run": round(sum(v["dur_us"]) / len(v["dur_us"]), 1)}
+sys.path.insert(0, root)
+import bench      # noqa: E402  (csrc_sha16: the fingerprint of the kernel sources this record was measured on)
+info["csrc_sha16"] = bench.csrc_sha16()
 if len(sys.argv) > 2:
     info["kernel_site"] = sys.argv[2]
 if len(sys.argv) > 3:

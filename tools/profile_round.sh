@@ -4,9 +4,9 @@
 # tools/pmc_summary.py on the build host and commit the summaries under profiles/.
 #   tools/profile_round.sh <tag> [workload] [precision] [pmc: 0|1]
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 WL=${2:-c3}
-PREC=${3:-bf16x3}
+PREC=${3:-mix_mx}
 PMC=${4:-1}
 OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -18,5 +18,6 @@ if [ "$PMC" = "1" ]; then
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o p -- $CMD > "$OUT/fetch.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o p -- $CMD > "$OUT/write.log" 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/sq" -o p -- $CMD > "$OUT/sq.log" 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d "$OUT/sq2" -o p -- $CMD > "$OUT/sq2.log" 2>&1
 fi
 find "$OUT" -name "*.csv" | head -20
