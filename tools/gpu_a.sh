@@ -1,11 +1,12 @@
 #!/bin/bash
-# round 3, GPU call A: full -m gpu suite + c3 in bf16x3 / mix_mx (per-site tables)
-mkdir -p gpurun_out/r3a
-python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > gpurun_out/r3a/pytest.txt
-for p in bf16x3 mix_mx; do
-  python bench.py --precision $p --no-cpu-baseline > gpurun_out/r3a/bench_c3_$p.json 2> gpurun_out/r3a/bench_c3_$p.err
-  python bench.py --precision $p --no-cpu-baseline --profile-kernels > gpurun_out/r3a/sites_c3_$p.json 2> gpurun_out/r3a/sites_c3_$p.txt
+mkdir -p gpurun_out/r3p
+P=tools/probes/mx_conv_probe.bin; T=tools/probes/mx_conv_probe_t.bin
+{
+echo "--- baseline 4-wave BM 256"; $P 36352 384 1536 9 256 2 | tail -2; $P 36352 384 1536 9 256 0 | tail -2
+for bm in 1192 1160 1128; do
+echo "--- ping-pong $bm, fragments fetched in the DMA phase"; timeout 120 $P 36352 384 1536 9 $bm 2 | tail -3; timeout 120 $P 36352 384 1536 9 $bm 0 | tail -3
 done
-python bench.py --precision mix_mx > gpurun_out/r3a/bench_c3_mix_mx_full.json 2> gpurun_out/r3a/bench_c3_mix_mx_full.err
-tail -5 gpurun_out/r3a/pytest.txt
-cat gpurun_out/r3a/bench_c3_bf16x3.json gpurun_out/r3a/bench_c3_mix_mx.json | cut -c1-400
+echo "--- phases (timing build)"; timeout 120 $T 36352 384 1536 9 1160 2 | tail -5; timeout 120 $T 36352 384 1536 9 1192 0 | tail -5; timeout 120 $T 36352 384 1536 9 1128 2 | tail -5
+echo "--- c4-sized"; $P 460000 384 1536 9 256 2 | tail -2; timeout 120 $P 460000 384 1536 9 1160 2 | tail -3; $P 460000 384 1536 9 256 0 | tail -2; timeout 120 $P 460000 384 1536 9 1192 0 | tail -3
+} > gpurun_out/r3p/pp_probe4.txt 2>&1
+cat gpurun_out/r3p/pp_probe4.txt | cut -c1-250

@@ -2,7 +2,7 @@
 // operands: ticks wave 0 of workgroup (0,0) spends per k-step in barrier wait | DMA issue | fragment reads + MFMAs | A refill, the
 // kernel time and the effective shader clock.  Random bit patterns (finite in every format they are read as).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DFS2_GEMM_TIMING] [-DFS2_MX_SKIP=1|2] [-DFS2_PROBE_DMA=1|2|3] -I fastspeech2_amd/csrc -I tools/probes tools/probes/mx_conv_probe.hip -o tools/probes/mx_conv_probe.bin
-//   mx_conv_probe.bin R C N ktaps BM(64|128|256; 512 = the rejected 8-wave kernel) arith(0|2) data(0 low entropy | 1 model-like)
+//   mx_conv_probe.bin R C N ktaps BM(64|128|256; 512 = the rejected 8-wave kernel; 1128|1160|1192 = ping-pong kernel with 2 x 128|160|192 rows, checked bit-for-bit against BM 256) arith(0|2) data(0 low entropy | 1 model-like)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -10,6 +10,7 @@
 #include <vector>
 #include "gemm_mx.h"
 #include "rejected/gemm_planes8.h"      // the 8-wave ring-buffered variant (measured slower: DESIGN.md section 4)
+#include "rejected/gemm_pp.h"          // the ping-pong kernel (bit-identical, measured slower: DESIGN.md section 3)
 using namespace fs2;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 template <int NS, int BM, int AR>
@@ -50,6 +51,44 @@ int run8(GemmArgs a, int steps) {
         printf("pl8 arith=%d k=%d R=%d C=%d N=%d: %.1f us, %u workgroups x %d steps\n", AR, a.ktaps, a.R, a.C, a.N, ms * 1e3, grid.x * grid.y, steps);
     }
     return 0;
+}
+template <int NS, int BM, int AR>
+int run_pp(GemmArgs a, int steps) {
+    constexpr size_t lds = pp_lds_bytes<BM>(), lds_ref = pl_lds_bytes<256, false>();
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_conv<NS, BM, AR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pl_bf16<NS, 256, false, AR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ref));
+    dim3 grid((a.N + 127) / 128, (a.R + 2 * BM - 1) / (2 * BM));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+#ifdef FS2_PP_TIMING
+        long long zero[8] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_pp_phase), zero, sizeof zero));
+#endif
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((gemm_pp_conv<NS, BM, AR>), grid, dim3(512), lds, 0, a);
+        hipEventRecord(e1); CK(hipDeviceSynchronize());
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("pp arith=%d BM=2x%d k=%d R=%d C=%d N=%d: %.1f us, %u workgroups x %d steps\n", AR, BM, a.ktaps, a.R, a.C, a.N, ms * 1e3, grid.x * grid.y, steps);
+#ifdef FS2_PP_TIMING
+        long long ph[8]; CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_pp_phase), sizeof ph));
+        printf("   per step, group 0: mfma phase %lld + wait %lld | dma phase %lld + wait %lld;  group 1: mfma %lld + wait %lld | dma %lld + wait %lld cycles\n",
+               ph[0] / steps, ph[1] / steps, ph[2] / steps, ph[3] / steps, ph[4] / steps, ph[5] / steps, ph[6] / steps, ph[7] / steps);
+#endif
+    }
+    // bit-for-bit against the 4-wave kernel (same arithmetic order per accumulator)
+    std::vector<float> y1((size_t)a.R * a.N), y0((size_t)a.R * a.N);
+    CK(hipMemcpy(y1.data(), a.Y, y1.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemset(a.Y, 0xff, y1.size() * 4));
+    hipLaunchKernelGGL((gemm_pl_bf16<NS, 256, false, AR>), dim3((a.N + 127) / 128, (a.R + 255) / 256), dim3(256), lds_ref, 0, a);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(y0.data(), a.Y, y0.size() * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0, first = 0; double amax = 0;
+    for (size_t i = 0; i < y0.size(); ++i) {
+        if (memcmp(&y0[i], &y1[i], 4) != 0) { if (!bad) first = i; ++bad; }
+        if (std::isfinite(y0[i]) && fabs(y0[i]) > amax) amax = fabs(y0[i]);
+    }
+    printf("   vs gemm_pl_bf16<BM 256>: %zu of %zu outputs differ (first at row %zu col %zu: %g vs %g); max |y| %g\n", bad, y0.size(), first / a.N, first % a.N,
+           bad ? y1[first] : 0.f, bad ? y0[first] : 0.f, amax);
+    return bad ? 2 : 0;
 }
 int main(int argc, char** argv) {
     const int R = argc > 1 ? atoi(argv[1]) : 30208, C = argc > 2 ? atoi(argv[2]) : 384, N = argc > 3 ? atoi(argv[3]) : 1024;
@@ -116,6 +155,9 @@ int main(int argc, char** argv) {
     if (a_scale_real) { a.mx_scale = (127 - 4 - 11) * 0x01010101; a.mx_scale_b = (127 - 14) * 0x01010101; }
     const int steps = nchunks * k;
     if (BM == 512) return AR == 2 ? run8<1, 2>(a, steps) : run8<3, 0>(a, steps);
+    if (BM == 1192) return AR == 2 ? run_pp<1, 192, 2>(a, steps) : run_pp<3, 192, 0>(a, steps);
+    if (BM == 1160) return AR == 2 ? run_pp<1, 160, 2>(a, steps) : run_pp<3, 160, 0>(a, steps);
+    if (BM == 1128) return AR == 2 ? run_pp<1, 128, 2>(a, steps) : run_pp<3, 128, 0>(a, steps);
     if (AR == 2) return BM == 256 ? run<1, 256, 2>(a, steps) : (BM == 128 ? run<1, 128, 2>(a, steps) : run<1, 64, 2>(a, steps));
     return BM == 256 ? run<3, 256, 0>(a, steps) : (BM == 128 ? run<3, 128, 0>(a, steps) : run<3, 64, 0>(a, steps));
 }
