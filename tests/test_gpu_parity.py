@@ -492,12 +492,15 @@ def test_errors(env):
                        torch.ones(1, 4, dtype=torch.int64), torch.ones(1, 4), torch.ones(1, 4))
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+_C4_ORACLE = {}      # utterance index -> oracle mel (the same 16 utterances serve every arithmetic mode)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "mix_mx"])
 def test_full_size_c4_length_regulator_stress(env, precision):
     """BASELINE config c4 (B=256, 32..512 phonemes, ~0.5 M frames, Lmax > 4000, with Postnet): frame counts,
     zero pads, exact length-regulator indices for every utterance, and a seeded sample of 16 utterances -- the two
     shortest, the two longest (beyond the 5000-row positional table when the batch has such) and 12 random ones -- against
-    the oracle, in both parity modes."""
+    the oracle, in fp32, bf16x3 and the bench default mix_mx."""
     model, sd, cfg, O = env
     from fastspeech2_amd.synthetic import make_batch
     from tests.conftest import record_measurement
@@ -525,8 +528,9 @@ def test_full_size_c4_length_regulator_stress(env, precision):
     worst = 0.0
     for i in pick:
         T, L = int(b["ilens"][i]), int(b["olens"][i])
-        o = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], is_inference=True, d_override=b["ds"][i:i + 1, :T])
-        d = _maxabs(after[i, :L], o["after"][0])
+        if i not in _C4_ORACLE:
+            _C4_ORACLE[i] = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], is_inference=True, d_override=b["ds"][i:i + 1, :T])["after"][0]
+        d = _maxabs(after[i, :L], _C4_ORACLE[i])
         assert d <= MEL_TOL, (i, L, d)
         worst = max(worst, d)
     print("c4 [%s]: %d frames, Lmax %d; %d sampled utterances (L %d..%d): worst mel max-abs vs oracle %.2e"
@@ -536,7 +540,7 @@ def test_full_size_c4_length_regulator_stress(env, precision):
 
 def test_c5_shard_of_the_8_gpu_partition(env):
     """BASELINE config c5 (batch = 1024 sharded over 8 MI355X): the shard rank 0 of 8 gets from the LPT partition
-    (`shard_indices`, 128 +- a few utterances), bf16x3, through the batched entry point in its packed form (what the
+    (`shard_indices`, 128 +- a few utterances), mix_mx, through the batched entry point in its packed form (what the
     all-gather ships): properties on every utterance, a seeded sample of 16 (plus the longest and the shortest) against the
     oracle.  The 8-rank collective itself is covered on CPU (tests/test_parallel_gloo.py) and at world size 1 below."""
     model, sd, cfg, O = env
@@ -550,7 +554,7 @@ def test_c5_shard_of_the_8_gpu_partition(env):
     il = b["ilens"][sel]
     Tm = int(il.max())
     xs, ds = b["xs"][sel][:, :Tm], b["ds"][sel][:, :Tm]
-    model.precision = "bf16x3"
+    model.precision = "mix_mx"          # what bench.py runs on this shard
     try:
         with torch.no_grad():
             packed, ol = model.inference_batch(xs.cuda(), il, d_override=ds.cuda(), packed=True)
@@ -568,7 +572,7 @@ def test_c5_shard_of_the_8_gpu_partition(env):
         assert d <= MEL_TOL, (j, L, d)
         worst = max(worst, d)
     print("c5 shard 0/8: %d utterances, %d frames; %d sampled utterances: worst mel max-abs vs oracle %.2e" % (len(sel), int(ol.sum()), len(pick), worst))
-    record_measurement("c5_shard_sample_mel_maxabs_bf16x3", worst)
+    record_measurement("c5_shard_sample_mel_maxabs_mix_mx", worst)
 
 
 def test_sharded_synthesizer_over_nccl_world_size_1(env):
