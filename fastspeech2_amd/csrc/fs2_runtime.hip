@@ -79,6 +79,7 @@ constexpr int kXcds = 8;      // MI355X: 8 accelerator dies, workgroups of a lau
 // changed afterwards only through fs2_set_option(): the launch path never touches the environment.  -1 = automatic choice.
 struct Options {
     int bm = -1;         // FS2_BM       tile height of gemm_pl_bf16 (64 | 128 | 256)
+    int bal = 1;         // FS2_BAL      tall conv tiles: 0 = always 256 rows, 1 = height balanced over whole rounds of the rows in use, 2 = of the row capacity
     int row8 = -1;       // FS2_ROW8     force (1) / forbid (0) the row-complete LayerNorm-fused k = 1 GEMM
     int qkv8 = -1;       // FS2_QKV8     force / forbid the 8-wave fused QKV projection
     int nosplitk = 0;    // FS2_NOSPLITK no split-K of the token-level k = 1 GEMMs
@@ -94,7 +95,7 @@ Options& opts() {
     static Options o = [] {
         Options x;
         x.bm = env_int("FS2_BM", -1); x.row8 = env_int("FS2_ROW8", -1); x.qkv8 = env_int("FS2_QKV8", -1);
-        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.fuse_var = env_int("FS2_FUSE_VAR", 1);
+        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 1);
         return x;
     }();
     return o;
@@ -388,7 +389,7 @@ hipError_t launch_pl(hipStream_t s, const GemmArgs& a) {
     }
     bm = force ? force : (nN * ((rows + 255) / 256) >= 512 ? 256 : (nN * ((rows + 127) / 128) >= 400 ? 128 : 64));
     if (bm > 128) {
-        if (!force && a.ksplit <= 1) bm = conv_bm_balanced(rows_in_use(a, rows), nN);
+        if (!force && a.ksplit <= 1 && opts().bal) bm = conv_bm_balanced(opts().bal == 2 ? rows : rows_in_use(a, rows), nN);
         if constexpr (NSPLIT == 3) return launch_pl_tall<3, 0>(s, a, bm);
         else return launch_pl_t<NSPLIT, 256, false>(s, a);
     }
@@ -400,7 +401,7 @@ hipError_t launch_mx(hipStream_t s, const GemmArgs& a) {
     const int force = opts().bm > 0 ? opts().bm : 0;
     const long nN = (a.N + kB16BN - 1) / kB16BN;
     int bm = force ? force : (nN * ((a.R + 255) / 256) >= 512 ? 256 : (nN * ((a.R + 127) / 128) >= 400 ? 128 : 64));
-    if (bm > 128) return launch_pl_tall<1, 2>(s, a, force ? bm : conv_bm_balanced(rows_in_use(a, a.R), nN));
+    if (bm > 128) return launch_pl_tall<1, 2>(s, a, (force || !opts().bal) ? bm : conv_bm_balanced(opts().bal == 2 ? a.R : rows_in_use(a, a.R), nN));
     return bm == 128 ? launch_pl_t<1, 128, false, 2>(s, a) : launch_pl_t<1, 64, false, 2>(s, a);
 }
 
@@ -1972,6 +1973,7 @@ int fs2_set_option(const char* name, int32_t value) {
     else if (n == "FS2_F32_ROWS") o.f32_rows = value > 0;
     else if (n == "FS2_MT8") o.mt8 = value;
     else if (n == "FS2_FUSE_VAR") o.fuse_var = value != 0;
+    else if (n == "FS2_BAL") o.bal = value < 0 ? 1 : value;
     else return fail(nullptr, FS2_ERR_ARG, "fs2_set_option: unknown option %s", name);
     return FS2_OK;
 }

@@ -458,12 +458,14 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
     // accumulators start at bias + residual (loaded under the first DMA round trip): acc[mt][4g + j][r] is channel
     // col0 + 64 g + j of tile row (mt, r)
     const int col0 = wn * (64 * NB) + 4 * lr;
-    int rowi[MT][4];
+    // this lane's rows: row(mt, r) = rowb + 16 mt + rp[r].  (Arrays of row indices, positions, means and reciprocal deviations used to live
+    // through the epilogue: 20 MT registers beside 16 MT NB accumulators -- the 192-row form spilled 158 of them and lost to the 128-row form
+    // whenever it did not save a whole round of workgroups.)
+    const int rowb = m0 + wm * RW;
+    int rp[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rp[r] = rperm(lg * 4 + r);
     f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rowi[mt][r] = m0 + wm * RW + mt * 16 + rperm(lg * 4 + r);
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
         const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + col0 + 64 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -471,8 +473,9 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                const int row = rowb + mt * 16 + rp[r];
                 f32x4 v = bv;
-                v += load4_or_zero(a.resid + (size_t)rowi[mt][r] * a.ldr + col0 + 64 * g, a.resid != nullptr && rowi[mt][r] < a.R);
+                v += load4_or_zero(a.resid + (size_t)row * a.ldr + col0 + 64 * g, a.resid != nullptr && row < a.R);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[mt][4 * g + j][r] = v[j];
             }
@@ -493,30 +496,33 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
         if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(0);
     }
 
-    // ---- epilogue: rows stay in registers
+    // ---- epilogue: rows stay in registers.  LayerNorm statistics in two passes (mean, then centred sum of squares) over the 64 NB values a wave
+    // holds per row, completed across the two N-waves through LDS; the accumulators are then normalised IN PLACE, so neither the means nor the
+    // reciprocal deviations outlive that loop.
     const int* __restrict__ rpos = a.row_pos;
     float* __restrict__ Y = a.Y;
     void* __restrict__ Yp = a.Yp;
     const bool relu_first = a.relu_pre != 0;
-    int pos[MT][4];
-    float rsum[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int pv = loadi_or_zero(rpos + rowi[mt][r], rpos != nullptr && rowi[mt][r] < a.R);
-            pos[mt][r] = rowi[mt][r] < a.R ? pv : -1;
-            float s = 0.f;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                if (relu_first) acc[mt][n][r] = fmaxf(acc[mt][n][r], 0.f);
-                s += acc[mt][n][r];
-            }
-            rsum[mt][r] = wave16_sum(s);
-        }
     float* red = reinterpret_cast<float*>(smem_r);      // [2 passes][8 waves][RW rows]
-    float mean[MT][4], rstd[MT][4];
+    if (relu_first) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][n][r] = fmaxf(acc[mt][n][r], 0.f);
+    }
     if (a.ln_g) {
+        float rsum[MT][4], mean[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) s += acc[mt][n][r];
+                rsum[mt][r] = wave16_sum(s);
+            }
         __syncthreads();                                // operand buffers are dead
         if (lr == 0)
 #pragma unroll
@@ -543,32 +549,46 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                rstd[mt][r] = 1.f / sqrtf((rsum[mt][r] + red[8 * RW + (wave ^ 1) * RW + mt * 16 + lg * 4 + r]) / (float)a.N + a.ln_eps);
+            for (int r = 0; r < 4; ++r) {
+                const float rstd = 1.f / sqrtf((rsum[mt][r] + red[8 * RW + (wave ^ 1) * RW + mt * 16 + lg * 4 + r]) / (float)a.N + a.ln_eps);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[mt][n][r] = (acc[mt][n][r] - mean[mt][r]) * rstd;
+            }
     }
     const float alpha = (a.pe && a.pe_alpha) ? a.pe_alpha[0] : 1.f;
     // the two forms (with / without the positional-encoding add) are separate straight-line bodies: no load sits behind a
     // per-lane branch (see load4_or_zero), and the common form carries no positional-encoding loads at all
     auto emit = [&](auto pe_tag) {
         constexpr bool PE = decltype(pe_tag)::value;
+        f32x4 gam[NB], bet[NB];
 #pragma unroll
         for (int g = 0; g < NB; ++g) {
-            const int col = col0 + 64 * g;
-            f32x4 gam = f32x4{1.f, 1.f, 1.f, 1.f}, bet = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (a.ln_g) { gam = *reinterpret_cast<const f32x4*>(a.ln_g + col); bet = *reinterpret_cast<const f32x4*>(a.ln_b + col); }
+            gam[g] = f32x4{1.f, 1.f, 1.f, 1.f}; bet[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.ln_g) { gam[g] = *reinterpret_cast<const f32x4*>(a.ln_g + col0 + 64 * g); bet[g] = *reinterpret_cast<const f32x4*>(a.ln_b + col0 + 64 * g); }
+        }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
+            int pos[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = rowi[mt][r];
-                    const bool live = pos[mt][r] >= 0;
+            for (int r = 0; r < 4; ++r) {           // (the four loads go out together, as address selects: see load4_or_zero)
+                const int row = rowb + mt * 16 + rp[r];
+                const int pv = loadi_or_zero(rpos + row, rpos != nullptr && row < a.R);
+                pos[r] = row < a.R ? pv : -1;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rowb + mt * 16 + rp[r];
+                const bool live = pos[r] >= 0;
+#pragma unroll
+                for (int g = 0; g < NB; ++g) {
+                    const int col = col0 + 64 * g;
                     f32x4 pe4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (PE) pe4 = load4_or_zero(a.pe + (size_t)(live ? pos[mt][r] : 0) * a.pe_ld + col, live);
+                    if (PE) pe4 = load4_or_zero(a.pe + (size_t)(live ? pos[r] : 0) * a.pe_ld + col, live);
                     f32x4 v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float t = acc[mt][4 * g + j][r];
-                        if (a.ln_g) t = (t - mean[mt][r]) * rstd[mt][r] * gam[j] + bet[j];
+                        if (a.ln_g) t = t * gam[g][j] + bet[g][j];
                         t = apply_act(t, a.act_post);
                         if (PE) t = t * a.x_scale + alpha * pe4[j];
                         v[j] = live ? t : 0.f;
@@ -578,6 +598,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8_bf16(GemmArgs a) {
                         if (Yp) store_planes4m(Yp, row, a.yp_chunks, col, v, a.yp_f16, a.yp_scale);
                     }
                 }
+            }
         }
     };
     if (a.pe) emit(std::true_type{}); else emit(std::false_type{});
@@ -655,12 +676,11 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
     dma_A(0);
     dma_B(0, 0);
     const int col0 = wn * (64 * NB) + 4 * lr;
-    int rowi[MT][4];
+    const int rowb = m0 + wm * RW;        // this lane's rows: row(mt, r) = rowb + 16 mt + rp[r] (no arrays of row state: see gemm_row8_bf16)
+    int rp[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rp[r] = rperm(lg * 4 + r);
     f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rowi[mt][r] = m0 + wm * RW + mt * 16 + rperm(lg * 4 + r);
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
         const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + col0 + 64 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -668,8 +688,9 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                const int row = rowb + mt * 16 + rp[r];
                 f32x4 v = bv;
-                v += load4_or_zero(a.resid + (size_t)rowi[mt][r] * a.ldr + col0 + 64 * g, a.resid != nullptr && rowi[mt][r] < a.R);
+                v += load4_or_zero(a.resid + (size_t)row * a.ldr + col0 + 64 * g, a.resid != nullptr && row < a.R);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[mt][4 * g + j][r] = v[j];
             }
@@ -696,32 +717,33 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
         }
     }
 
-    // ---- epilogue: rows stay in registers (as gemm_row8_bf16) + the scalar head
+    // ---- epilogue: rows stay in registers, normalised in place (as gemm_row8_bf16) + the scalar head
     const int* __restrict__ rpos = a.row_pos;
     float* __restrict__ Y = a.Y;
     void* __restrict__ Yp = a.Yp;
     const bool relu_first = a.relu_pre != 0;
-    int pos[MT][4];
-    float rsum[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int pv = loadi_or_zero(rpos + rowi[mt][r], rpos != nullptr && rowi[mt][r] < a.R);
-            pos[mt][r] = rowi[mt][r] < a.R ? pv : -1;
-            float s = 0.f;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                if (relu_first) acc[mt][n][r] = fmaxf(acc[mt][n][r], 0.f);
-                s += acc[mt][n][r];
-            }
-            rsum[mt][r] = wave16_sum(s);
-        }
     float* red = reinterpret_cast<float*>(smem_c);      // [3 passes][8 waves][RW rows]
-    float mean[MT][4], rstd[MT][4];
+    if (relu_first) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][n][r] = fmaxf(acc[mt][n][r], 0.f);
+    }
     __syncthreads();                                    // operand buffers are dead
     const int n_ln = GROUPS == 2 ? a.N / 2 : a.N;      // columns one LayerNorm runs over
     if (a.ln_g) {
+        float rsum[MT][4], mean[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) s += acc[mt][n][r];
+                rsum[mt][r] = wave16_sum(s);
+            }
         if constexpr (GROUPS == 2) {      // the wave holds the whole group: no exchange
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -731,36 +753,41 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
                     float q = 0.f;
 #pragma unroll
                     for (int n = 0; n < NT; ++n) { const float d = acc[mt][n][r] - mean[mt][r]; q += d * d; }
-                    rstd[mt][r] = 1.f / sqrtf(wave16_sum(q) / (float)n_ln + a.ln_eps);
+                    const float rstd = 1.f / sqrtf(wave16_sum(q) / (float)n_ln + a.ln_eps);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[mt][n][r] = (acc[mt][n][r] - mean[mt][r]) * rstd;
                 }
         } else {
-        if (lr == 0)
+            if (lr == 0)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[wave * RW + mt * 16 + lg * 4 + r] = rsum[mt][r];
+            __syncthreads();
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[wave * RW + mt * 16 + lg * 4 + r] = rsum[mt][r];
-        __syncthreads();
+                for (int r = 0; r < 4; ++r) {
+                    mean[mt][r] = (rsum[mt][r] + red[(wave ^ 1) * RW + mt * 16 + lg * 4 + r]) / (float)a.N;
+                    float q = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+                    for (int n = 0; n < NT; ++n) { const float d = acc[mt][n][r] - mean[mt][r]; q += d * d; }
+                    rsum[mt][r] = wave16_sum(q);
+                }
+            if (lr == 0)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                mean[mt][r] = (rsum[mt][r] + red[(wave ^ 1) * RW + mt * 16 + lg * 4 + r]) / (float)a.N;
-                float q = 0.f;
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) { const float d = acc[mt][n][r] - mean[mt][r]; q += d * d; }
-                rsum[mt][r] = wave16_sum(q);
-            }
-        if (lr == 0)
+                    for (int r = 0; r < 4; ++r) red[8 * RW + wave * RW + mt * 16 + lg * 4 + r] = rsum[mt][r];
+            __syncthreads();
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[8 * RW + wave * RW + mt * 16 + lg * 4 + r] = rsum[mt][r];
-        __syncthreads();
+                for (int r = 0; r < 4; ++r) {
+                    const float rstd = 1.f / sqrtf((rsum[mt][r] + red[8 * RW + (wave ^ 1) * RW + mt * 16 + lg * 4 + r]) / (float)a.N + a.ln_eps);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                rstd[mt][r] = 1.f / sqrtf((rsum[mt][r] + red[8 * RW + (wave ^ 1) * RW + mt * 16 + lg * 4 + r]) / (float)a.N + a.ln_eps);
+                    for (int n = 0; n < NT; ++n) acc[mt][n][r] = (acc[mt][n][r] - mean[mt][r]) * rstd;
+                }
         }
     }
     float dsum[MT][4];
@@ -775,16 +802,23 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
         if (a.ln_g) { gam = *reinterpret_cast<const f32x4*>(a.ln_g + col); bet = *reinterpret_cast<const f32x4*>(a.ln_b + col); }
         if (a.dot_w) dw = *reinterpret_cast<const f32x4*>(a.dot_w + col);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
+            int pos[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {           // (re-read per 64-column group: four L1-resident loads instead of 4 MT registers held throughout)
+                const int row = rowb + mt * 16 + rp[r];
+                const int pv = loadi_or_zero(rpos + row, rpos != nullptr && row < a.R);
+                pos[r] = row < a.R ? pv : -1;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = rowi[mt][r];
-                const bool live = pos[mt][r] >= 0;      // (selects, not branches: see gemm_row8_bf16)
+                const int row = rowb + mt * 16 + rp[r];
+                const bool live = pos[r] >= 0;      // (selects, not branches: see gemm_row8_bf16)
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float t = acc[mt][4 * g + j][r];
-                    if (a.ln_g) t = (t - mean[mt][r]) * rstd[mt][r] * gam[j] + bet[j];
+                    if (a.ln_g) t = t * gam[j] + bet[j];
                     t = apply_act(t, a.act_post);
                     v[j] = live ? t : 0.f;
                     dsum[mt][r] += live ? t * dw[j] : 0.f;
@@ -794,6 +828,7 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
                     if (Yp) store_planes4m(Yp, row, a.yp_chunks, col + a.yp_col_off, v, a.yp_f16, a.yp_scale);
                 }
             }
+        }
     }
     if (a.dot_w) {      // scalar head: dot_out[row] = v . dot_w + dot_b, summed over the 16 lanes of a row group and the two N-waves
 #pragma unroll
@@ -812,8 +847,9 @@ __global__ __launch_bounds__(512, 1) void gemm_row8c_bf16(GemmArgs a) {
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = rowi[mt][r];
-                    if (row < a.R) a.dot_out[row] = pos[mt][r] >= 0 ? dsum[mt][r] + red[16 * RW + (wave ^ 1) * RW + mt * 16 + lg * 4 + r] + db : 0.f;
+                    const int row = rowb + mt * 16 + rp[r];
+                    const bool live = row < a.R && loadi_or_zero(rpos + row, rpos != nullptr && row < a.R) >= 0;
+                    if (row < a.R) a.dot_out[row] = live ? dsum[mt][r] + red[16 * RW + (wave ^ 1) * RW + mt * 16 + lg * 4 + r] + db : 0.f;
                 }
         }
     }
@@ -875,14 +911,20 @@ __global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
     };
 
     const int col0 = wn * (64 * NB) + 4 * lr;
-    int rowi[MT][4];
-    bool rvalid[MT][4];
+    // this lane's rows: row(mt, r) = rowb + 16 mt + rp[r]; their validity as ONE bit mask (bit 4 mt + r) -- kept as arrays of row indices and
+    // flags they cost 8 MT registers through all three k-loops (the 192-row form spilled 63 registers)
+    const int rowb = m0 + wm * RW;
+    int rp[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rp[r] = rperm(lg * 4 + r);
+    unsigned vmask = 0;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            rowi[mt][r] = m0 + wm * RW + mt * 16 + rperm(lg * 4 + r);
-            rvalid[mt][r] = rowi[mt][r] < a.R && (a.row_pos == nullptr || a.row_pos[rowi[mt][r]] >= 0);
+            const int row = rowb + mt * 16 + rp[r];
+            const bool ok = row < a.R && loadi_or_zero(a.row_pos + row, a.row_pos != nullptr && row < a.R) >= 0;
+            vmask |= ok ? (1u << (mt * 4 + r)) : 0u;
         }
     __bf16* qkh = reinterpret_cast<__bf16*>(a.qk_hi);
     __bf16* qkl = reinterpret_cast<__bf16*>(a.qk_lo);
@@ -926,11 +968,12 @@ __global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (rowi[mt][r] >= a.Rvt) continue;
-                        const float f = rvalid[mt][r] ? sc : 0.f;
+                        const int row = rowb + mt * 16 + rp[r];
+                        if (row >= a.Rvt) continue;
+                        const float f = ((vmask >> (mt * 4 + r)) & 1u) ? sc : 0.f;
                         uint2 hi, lo;
                         split4(f32x4{acc[mt][4 * g][r], acc[mt][4 * g + 1][r], acc[mt][4 * g + 2][r], acc[mt][4 * g + 3][r]} * f, hi, lo);
-                        const size_t off = (size_t)rowi[mt][r] * 2 * BN + nb * BN + col0 + 64 * g;
+                        const size_t off = (size_t)row * 2 * BN + nb * BN + col0 + 64 * g;
                         *reinterpret_cast<uint2*>(qkh + off) = hi;
                         *reinterpret_cast<uint2*>(qkl + off) = lo;
                     }
@@ -949,8 +992,8 @@ __global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const f32x4 v = f32x4{acc[mt][4 * g][r], acc[mt][4 * g + 1][r], acc[mt][4 * g + 2][r], acc[mt][4 * g + 3][r]};
-                            *reinterpret_cast<f32x4*>(tile + (wm * RW + mt * 16 + rperm(lg * 4 + r)) * kQkvLd + (G & 1) * 64 + 4 * lr) =
-                                rvalid[mt][r] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                            *reinterpret_cast<f32x4*>(tile + (wm * RW + mt * 16 + rp[r]) * kQkvLd + (G & 1) * 64 + 4 * lr) =
+                                ((vmask >> (mt * 4 + r)) & 1u) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
                         }
                 }
                 __syncthreads();
