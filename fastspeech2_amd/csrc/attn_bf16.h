@@ -260,6 +260,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
     if (ntiles > 0) {
         k_fast = 32 <= klen;
         if (k_fast) { FS2_LOAD_K_FAST(0) FS2_STORE_K_FAST() } else { FS2_LOAD_K(0) FS2_STORE_K() }
+        v_fast = k_fast;
+        if (v_fast) { FS2_LOAD_V_FAST(0) } else { FS2_LOAD_V(0) }
     }
 #ifdef FS2_ATT_TIMING
     long long tprev = __builtin_readcyclecounter();
@@ -269,8 +271,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
         FS2_T(5)
         __syncthreads();          // (A) K(kt) visible; every wave is done with P.V(kt-1), so the V^T buffer is free
         FS2_T(0)
-        v_fast = key0 + 32 <= klen;
-        if (v_fast) { FS2_LOAD_V_FAST(key0) } else { FS2_LOAD_V(key0) }          // in flight during Q.K^T and the softmax
+        // (V^T(kt) was requested before this barrier -- at the end of the previous tile, or ahead of the loop -- and stays in flight during
+        //  Q.K^T and the softmax)
         bf16x8_t ph, pl;
         if (wave_live) {          // (a wave whose 16 queries all lie beyond the utterance only helps with the staging)
         f32x4 st[2];
@@ -279,45 +281,47 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
         {
             const char* krow0 = Ks + (8 * (lr >> 2) + (lr & 3)) * KROW;     // sub-tile 0 row; sub-tile 1 is 4 keys further
             const char* krow1 = krow0 + 4 * KROW;
-            // two k-steps of K fragments per batch: 8 ds_read_b128 issued together (the sched_barrier keeps hipcc from folding them
-            // back into a read -> wait -> MFMA chain on two registers: that paid the LDS latency 24 times per tile), then 12 MFMAs on
-            // four accumulators (even / odd k-step), summed at the end: no MFMA waits for the one just before it
-            f32x4 su[2];
-            su[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            su[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c2 = 0; c2 < NC; c2 += 2) {
-                bf16x8_t kh0[2], kh1[2], kl0[2], kl1[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int c = c2 + u;
-                    const int sh = ((c * 4 + lg) ^ lr) << 4, sl = ((KSL + c * 4 + lg) ^ lr) << 4;
-                    kh0[u] = *reinterpret_cast<const bf16x8_t*>(krow0 + sh);
-                    kh1[u] = *reinterpret_cast<const bf16x8_t*>(krow1 + sh);
-                    if (NSPLIT == 3) {
-                        kl0[u] = *reinterpret_cast<const bf16x8_t*>(krow0 + sl);
-                        kl1[u] = *reinterpret_cast<const bf16x8_t*>(krow1 + sl);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            // One k-step (32 channels) = 4 ds_read_b128 (hi / lo piece of the two sub-tiles' rows) + 6 MFMAs.  The fragments of step c + 1 are
+            // requested BEFORE the MFMAs of step c (register double buffer, order pinned with sched_group_barrier): the ISA of the previous form
+            // (8 reads -> s_waitcnt -> 12 MFMAs, three times) paid the LDS round trip three times per tile with nothing to cover it.  The cross
+            // terms (lo.hi + hi.lo) and the main term (hi.hi) of a sub-tile go to separate accumulators, so no MFMA depends on either of the
+            // two issued just before it.
+            f32x4 sc[2], sm[2];
+            sc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; sc[1] = sc[0]; sm[0] = sc[0]; sm[1] = sc[0];
+            bf16x8_t kh0[2], kh1[2], kl0[2], kl1[2];
+            auto kfetch = [&](int c, int b) {
+                const int sh = ((c * 4 + lg) ^ lr) << 4, sl = ((KSL + c * 4 + lg) ^ lr) << 4;
+                kh0[b] = *reinterpret_cast<const bf16x8_t*>(krow0 + sh);
+                kh1[b] = *reinterpret_cast<const bf16x8_t*>(krow1 + sh);
                 if (NSPLIT == 3) {
-                    st[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl0[0], qh[c2], st[0], 0, 0, 0);
-                    st[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl1[0], qh[c2], st[1], 0, 0, 0);
-                    su[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl0[1], qh[c2 + 1], su[0], 0, 0, 0);
-                    su[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl1[1], qh[c2 + 1], su[1], 0, 0, 0);
-                    st[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0[0], ql[c2], st[0], 0, 0, 0);
-                    st[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1[0], ql[c2], st[1], 0, 0, 0);
-                    su[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0[1], ql[c2 + 1], su[0], 0, 0, 0);
-                    su[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1[1], ql[c2 + 1], su[1], 0, 0, 0);
+                    kl0[b] = *reinterpret_cast<const bf16x8_t*>(krow0 + sl);
+                    kl1[b] = *reinterpret_cast<const bf16x8_t*>(krow1 + sl);
                 }
-                st[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0[0], qh[c2], st[0], 0, 0, 0);
-                st[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1[0], qh[c2], st[1], 0, 0, 0);
-                su[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0[1], qh[c2 + 1], su[0], 0, 0, 0);
-                su[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1[1], qh[c2 + 1], su[1], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+            };
+            constexpr int kKR = NSPLIT == 3 ? 4 : 2, kKM = NSPLIT == 3 ? 6 : 2;
+            kfetch(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, kKR, 0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int b = c & 1;
+                if (c + 1 < NC) {
+                    kfetch(c + 1, b ^ 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, kKR, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, kKM, 0);
+                if (NSPLIT == 3) {
+                    sc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl0[b], qh[c], sc[0], 0, 0, 0);
+                    sc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl1[b], qh[c], sc[1], 0, 0, 0);
+                }
+                sm[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0[b], qh[c], sm[0], 0, 0, 0);
+                sm[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1[b], qh[c], sm[1], 0, 0, 0);
+                if (NSPLIT == 3) {
+                    sc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0[b], ql[c], sc[0], 0, 0, 0);
+                    sc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1[b], ql[c], sc[1], 0, 0, 0);
+                }
             }
-            st[0] += su[0];
-            st[1] += su[1];
+            st[0] = sm[0] + sc[0];
+            st[1] = sm[1] + sc[1];
         }
         // st[t][r] = log2(e) * score of key key0 + 8g + 4t + r for query lr (Q was pre-scaled by log2(e)/sqrt(d_k)),
         // so the softmax runs on v_exp_f32 (2^x) directly.
@@ -365,32 +369,52 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
         }
         FS2_T(2)
         if (v_fast) { FS2_STORE_V_FAST() } else { FS2_STORE_V() }
+        // K(kt + 1) is requested as soon as the staging registers are free, i.e. BEFORE the barrier (the loads touch no LDS): it has the barrier
+        // wait and P.V(kt) to arrive
+        k_fast = key0 + 64 <= klen;
+        if (kt + 1 < ntiles) { if (k_fast) { FS2_LOAD_K_FAST(key0 + 32) } else { FS2_LOAD_K(key0 + 32) } }
         __syncthreads();          // (B) V^T(kt) visible; every wave is done with Q.K^T(kt), so the K buffer is free
         FS2_T(3)
-        k_fast = key0 + 64 <= klen;
-        if (kt + 1 < ntiles) { if (k_fast) { FS2_LOAD_K_FAST(key0 + 32) } else { FS2_LOAD_K(key0 + 32) } }     // in flight during P.V
-        constexpr int PG = (DK > 128) ? 2 : 4;     // n-tiles in flight: independent accumulators between dependent MFMAs
-        if (wave_live)
+        constexpr int PG = (DK > 128) ? 2 : 4;     // n-tiles per group: independent accumulators between dependent MFMAs
+        if (wave_live) {
+            // V^T fragments of group i + 1 are requested before the MFMAs of group i (register double buffer; the previous form -- 2 PG reads ->
+            // s_waitcnt -> 3 PG MFMAs, NT / PG times -- exposed the LDS round trip six times per tile at d_k = 192)
+            bf16x8_t vh[2][PG], vl[2][PG];
+            auto vfetch = [&](int n4, int b) {
 #pragma unroll
-        for (int n4 = 0; n4 < NT; n4 += PG) {
-            bf16x8_t vh[PG], vl[PG];
+                for (int u = 0; u < PG; ++u) {
+                    const int row = (n4 + u) * 16 + lr;
+                    vh[b][u] = *reinterpret_cast<const bf16x8_t*>(Vs + swz(row, lg));
+                    if (NSPLIT == 3) vl[b][u] = *reinterpret_cast<const bf16x8_t*>(Vs + swz(row, 4 + lg));
+                }
+            };
+            constexpr int kVR = (NSPLIT == 3 ? 2 : 1) * PG, kVM = (NSPLIT == 3 ? 3 : 1) * PG;
+            vfetch(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, kVR, 0);
 #pragma unroll
-            for (int u = 0; u < PG; ++u) {
-                const int row = (n4 + u) * 16 + lr;
-                vh[u] = *reinterpret_cast<const bf16x8_t*>(Vs + swz(row, lg));
-                if (NSPLIT == 3) vl[u] = *reinterpret_cast<const bf16x8_t*>(Vs + swz(row, 4 + lg));
+            for (int n4 = 0; n4 < NT; n4 += PG) {
+                const int b = (n4 / PG) & 1;
+                if (n4 + PG < NT) {
+                    vfetch(n4 + PG, b ^ 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, kVR, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, kVM, 0);
+                if (NSPLIT == 3) {
+#pragma unroll
+                    for (int u = 0; u < PG; ++u) o[n4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh[b][u], o[n4 + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < PG; ++u) o[n4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl[b][u], o[n4 + u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < PG; ++u) o[n4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[b][u], o[n4 + u], 0, 0, 0);
             }
-            if (NSPLIT == 3) {
-#pragma unroll
-                for (int u = 0; u < PG; ++u) o[n4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh[u], o[n4 + u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < PG; ++u) o[n4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl[u], o[n4 + u], 0, 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < PG; ++u) o[n4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh[u], o[n4 + u], 0, 0, 0);
         }
         FS2_T(4)
-        if (kt + 1 < ntiles) { if (k_fast) { FS2_STORE_K_FAST() } else { FS2_STORE_K() } }
+        if (kt + 1 < ntiles) {
+            if (k_fast) { FS2_STORE_K_FAST() } else { FS2_STORE_K() }
+            v_fast = key0 + 64 <= klen;          // V^T(kt + 1): likewise ahead of barrier (A)
+            if (v_fast) { FS2_LOAD_V_FAST(key0 + 32) } else { FS2_LOAD_V(key0 + 32) }
+        }
     }
 #undef FS2_LOAD_K_FAST
 #undef FS2_STORE_K_FAST
