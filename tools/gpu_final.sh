@@ -1,7 +1,9 @@
 #!/bin/bash
 # round 3 final GPU session: full -m gpu suite, smoke, benches of every config, rocprofv3 kernel trace + PMC passes (c3 default, c4), c1 trace
 mkdir -p gpurun_out/r3z
+rm -f gpurun_out/measured_errors.jsonl
 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r3z/pytest.txt
+cp gpurun_out/measured_errors.jsonl gpurun_out/r3z/r03_measured_errors.jsonl 2>/dev/null
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r3z/smoke.txt 2>&1
 python bench.py > gpurun_out/r3z/bench_r03_c3_mix_mx.json 2> gpurun_out/r3z/bench_c3.err
 for spec in "c3 bf16x3" "c3 fp32" "c2 mix_mx" "c2 fp32" "c1 mix_mx" "c4 mix_mx" "c4 bf16x3" "c5 mix_mx"; do set -- $spec

@@ -29,6 +29,9 @@ for sub in ("fetch", "write", "sq", "sq2"):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             if sub == "sq" and r["Counter_Name"] == "SQ_WAVES":
                 agg[k]["dur_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+if not agg:
+    print("no PMC passes under", src, "(kernel stats copied)")
+    sys.exit(0)
 names = sorted({c for v in agg.values() for c in v})
 rows = []
 for (kern, grid), v in agg.items():
