@@ -79,7 +79,8 @@ constexpr int kXcds = 8;      // MI355X: 8 accelerator dies, workgroups of a lau
 // changed afterwards only through fs2_set_option(): the launch path never touches the environment.  -1 = automatic choice.
 struct Options {
     int bm = -1;         // FS2_BM       tile height of gemm_pl_bf16 (64 | 128 | 256)
-    int bal = 1;         // FS2_BAL      tall conv tiles: 0 = always 256 rows, 1 = height balanced over whole rounds of the rows in use, 2 = of the row capacity
+    int bal = 0;         // FS2_BAL      tall conv tiles: 0 = always 256 rows (default: interleaved A/B, profiles/r03_ab_conv_tile_balance.txt), 1 = height balanced over
+                         //              whole rounds of the rows in use, 2 = of the row capacity
     int row8 = -1;       // FS2_ROW8     force (1) / forbid (0) the row-complete LayerNorm-fused k = 1 GEMM
     int qkv8 = -1;       // FS2_QKV8     force / forbid the 8-wave fused QKV projection
     int nosplitk = 0;    // FS2_NOSPLITK no split-K of the token-level k = 1 GEMMs
@@ -95,7 +96,7 @@ Options& opts() {
     static Options o = [] {
         Options x;
         x.bm = env_int("FS2_BM", -1); x.row8 = env_int("FS2_ROW8", -1); x.qkv8 = env_int("FS2_QKV8", -1);
-        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 1);
+        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 0);
         return x;
     }();
     return o;
@@ -1973,7 +1974,7 @@ int fs2_set_option(const char* name, int32_t value) {
     else if (n == "FS2_F32_ROWS") o.f32_rows = value > 0;
     else if (n == "FS2_MT8") o.mt8 = value;
     else if (n == "FS2_FUSE_VAR") o.fuse_var = value != 0;
-    else if (n == "FS2_BAL") o.bal = value < 0 ? 1 : value;
+    else if (n == "FS2_BAL") o.bal = value < 0 ? 0 : value;
     else return fail(nullptr, FS2_ERR_ARG, "fs2_set_option: unknown option %s", name);
     return FS2_OK;
 }
