@@ -133,7 +133,9 @@ def _worker(rank, world, port, q):
         for _ in range(2):
             m1, o1 = form(xs[:1], il[:1])
             assert torch.equal(o1, want_ol[:1]) and torch.equal(m1[:, : int(want_ol[0])], want_mel[:1, : int(want_ol[0])])
-    q.put((rank, mel4[:, :L].clone(), ol4.clone()))
+    # (numpy, not torch tensors: a tensor on an mp.Queue travels as a file descriptor the RECEIVER fetches from the sender's resource
+    #  sharer -- if this process has exited by then the parent's q.get() fails with FileNotFoundError, which it did once in ~30 runs)
+    q.put((rank, mel4[:, :L].numpy().copy(), ol4.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -154,7 +156,7 @@ def _run_world(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, mel, ol in got:
-        assert torch.equal(ol, want_ol) and torch.equal(mel, want_mel)
+        assert torch.equal(torch.from_numpy(ol), want_ol) and torch.equal(torch.from_numpy(mel), want_mel)
 
 
 def test_sharded_equals_unsharded_gloo():
