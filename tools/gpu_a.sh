@@ -1,12 +1,14 @@
 #!/bin/bash
+# timing probe: cross-term units of the mx conv as block-scaled fp6 (e2m3) instead of e4m3
 mkdir -p gpurun_out/r3p
-P=tools/probes/mx_conv_probe.bin; T=tools/probes/mx_conv_probe_t.bin
+P=tools/probes/mx_conv_probe.bin
 {
-echo "--- baseline 4-wave BM 256"; $P 36352 384 1536 9 256 2 | tail -2; $P 36352 384 1536 9 256 0 | tail -2
-for bm in 1192 1160 1128; do
-echo "--- ping-pong $bm, fragments fetched in the DMA phase"; timeout 120 $P 36352 384 1536 9 $bm 2 | tail -3; timeout 120 $P 36352 384 1536 9 $bm 0 | tail -3
+for rep in 1 2; do
+echo "--- mx (e4m3 cross terms), c3-sized"; $P 36352 384 1536 9 256 2 | tail -2
+echo "--- fp6 probe, c3-sized"; timeout 120 $P 36352 384 1536 9 2256 2 | tail -2
 done
-echo "--- phases (timing build)"; timeout 120 $T 36352 384 1536 9 1160 2 | tail -5; timeout 120 $T 36352 384 1536 9 1192 0 | tail -5; timeout 120 $T 36352 384 1536 9 1128 2 | tail -5
-echo "--- c4-sized"; $P 460000 384 1536 9 256 2 | tail -2; timeout 120 $P 460000 384 1536 9 1160 2 | tail -3; $P 460000 384 1536 9 256 0 | tail -2; timeout 120 $P 460000 384 1536 9 1192 0 | tail -3
-} > gpurun_out/r3p/pp_probe4.txt 2>&1
-cat gpurun_out/r3p/pp_probe4.txt | cut -c1-250
+echo "--- split-bf16 x3, c3-sized"; $P 36352 384 1536 9 256 0 | tail -1
+echo "--- mx, c4-sized"; $P 460000 384 1536 9 256 2 | tail -2
+echo "--- fp6 probe, c4-sized"; timeout 120 $P 460000 384 1536 9 2256 2 | tail -2
+} > gpurun_out/r3p/fp6_probe.txt 2>&1
+cat gpurun_out/r3p/fp6_probe.txt | cut -c1-200
