@@ -1,11 +1,15 @@
 #!/bin/bash
-# EXPERIMENT: row-complete k = 1 GEMM with the weight stage through registers (FS2_BV=1, 128-row tiles) against LDS-DMA for both operands
-mkdir -p gpurun_out/r3v
+# row-complete k = 1 GEMM: A tiles requested two steps ahead (ring of three, FS2_A_RING=3) against one step (2)
+mkdir -p gpurun_out/r3w
 python -m pytest tests/test_gpu_ops.py -x -q -k "row_complete" 2>&1 | tail -2
-FS2_BV=1 python -m pytest tests/test_gpu_ops.py -x -q -k "row_complete" 2>&1 | tail -2
-for wl in c3 c4; do for bv in 0 1; do
-  FS2_MT8=2 FS2_BV=$bv python bench.py --no-cpu-baseline --workload $wl --profile-kernels > /dev/null 2> gpurun_out/r3v/sites_${wl}_bv${bv}.txt
-  FS2_MT8=2 FS2_BV=$bv python bench.py --no-cpu-baseline --workload $wl > gpurun_out/r3v/bench_${wl}_bv${bv}.json 2>/dev/null
+python -m pytest tests/test_gpu_parity.py -x -q -k "c2_batch or c2_row_complete" 2>&1 | tail -2
+for wl in c3 c4; do for ar in 2 3 2 3; do
+  n=$(ls gpurun_out/r3w | grep -c "bench_${wl}_ar${ar}")
+  FS2_MT8=2 FS2_A_RING=$ar python bench.py --no-cpu-baseline --workload $wl > gpurun_out/r3w/bench_${wl}_ar${ar}_$n.json 2>/dev/null
 done; done
-for f in gpurun_out/r3v/bench_*.json; do echo "$f $(python -c "import json,sys;d=json.load(open('$f'));print(d['value'], d['ms_per_step'], d.get('mel_max_abs_diff'))")"; done
-for f in gpurun_out/r3v/sites_*.txt; do echo $f; grep -E "dec.ffn2_ln|dec.out_ln|dec.in |enc.ffn2_ln|enc.out_ln" $f | cut -c1-90; done
+for wl in c3 c4; do for ar in 2 3; do
+  FS2_MT8=2 FS2_A_RING=$ar python bench.py --no-cpu-baseline --workload $wl --profile-kernels > /dev/null 2> gpurun_out/r3w/sites_${wl}_ar${ar}.txt
+done; done
+python bench.py --no-cpu-baseline --workload c3 > gpurun_out/r3w/bench_c3_auto.json 2>/dev/null
+for f in gpurun_out/r3w/bench_*.json; do echo "$f $(python -c "import json,sys;d=json.load(open('$f'));print(d['value'], d['ms_per_step'])")"; done
+for f in gpurun_out/r3w/sites_*.txt; do echo $f; grep -E "dec.ffn2_ln|dec.out_ln|dec.in " $f | cut -c1-90; done
