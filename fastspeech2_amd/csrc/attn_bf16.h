@@ -86,9 +86,11 @@ struct AttnB16Args {
     float* ctx; int ldc;                       // fp32 context [R][ldc] (or nullptr) ...
     void* ctxp; int ctxp_chunks;               // ... and / or split-bf16 planes, the A operand of the output projection (gemm_planes.h)
     const int* start; const int* len; const int* klen;
-    const int2* work;
-    const int* nwork;                          // device-driven layout: number of valid work items (grid.x is a capacity), or nullptr
+    const int2* work;                          // (utterance, 128-query block) items, attn_f32.h: kAttBlk
+    const int* nwork;                          // device-driven layout: number of valid work items (the grid is a capacity), or nullptr
+    int nitems;                                // host-driven layout: number of work items
     int D; int mask_q;
+    unsigned qk_lo_bytes, vt_lo_bytes;         // attn_w32.h: byte distance of the lo planes behind the hi planes (both < 2^31)
 };
 
 // max / sum over the four lanes {l, l^16, l^32, l^48} (the four 8-key groups of one query column) with the gfx950 row swaps:
@@ -130,12 +132,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16(AttnB16Args a) {
     char* Vs = smem_a + 32 * KROW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
-    if (a.nwork != nullptr && (int)blockIdx.x >= *a.nwork) return;
-    const int2 wk = a.work[blockIdx.x];
-    if (wk.x < 0) return;                      // padding entry of the XCD-interleaved work list
-    const int b = wk.x, h = blockIdx.y;
-    const int s0 = a.start[b], len = a.len[b], klen = a.klen[b];
-    const int q0 = wk.y * 64 + wave * 16;
+    int b, qb;
+    if (!att_item64(a.work, a.nwork, a.nitems, b, qb)) return;
+    const int h = blockIdx.y;
+    const int s0 = __builtin_amdgcn_readfirstlane(a.start[b]), len = __builtin_amdgcn_readfirstlane(a.len[b]), klen = __builtin_amdgcn_readfirstlane(a.klen[b]);
+    if (qb >= len) return;                     // second half of an utterance's last 128-query item
+    const int q0 = qb + wave * 16;
     const bool wave_live = __builtin_amdgcn_readfirstlane(q0) < len;      // wave-uniform: any of this wave's 16 queries inside the utterance
 
     // Q fragments (B operand of S^T): row q0 + lr, d = 32c + 8g .. +7

@@ -19,14 +19,14 @@
 namespace fs2 {
 
 constexpr int kAttKT = 32;   // keys per LDS tile
-constexpr int kAttBQ = 64;   // queries per workgroup (4 waves x 16)
 
 struct AttnArgs {
     const float* qkv; int ld;        // [R, 3D]: q at col h*dk, k at D + h*dk, v at 2D + h*dk
     float* ctx; int ldc;             // [R, D]
     const int* start; const int* len; const int* klen;   // per utterance
     const int2* work;                // (utterance, query tile)
-    const int* nwork;                // device-driven layout: number of valid work items (grid.x is a capacity), or nullptr
+    const int* nwork;                // device-driven layout: number of valid work items (the grid is a capacity), or nullptr
+    int nitems;                      // host-driven layout: number of work items
     int D; int mask_q;               // mask_q: query rows >= klen yield zeros (reference masked_fill(0))
     float scale;                     // 1/sqrt(dk)
 };
@@ -43,12 +43,12 @@ __global__ __launch_bounds__(256) void attn_f32(AttnArgs a) {
     float* Vs = smem + kAttKT * LDK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
-    if (a.nwork != nullptr && (int)blockIdx.x >= *a.nwork) return;
-    const int2 wk = a.work[blockIdx.x];
-    if (wk.x < 0) return;                      // padding entry of the XCD-interleaved work list
-    const int b = wk.x, h = blockIdx.y;
-    const int s0 = a.start[b], len = a.len[b], klen = a.klen[b];
-    const int q0 = wk.y * kAttBQ + wave * 16;
+    int b, qb;
+    if (!att_item64(a.work, a.nwork, a.nitems, b, qb)) return;
+    const int h = blockIdx.y;
+    const int s0 = __builtin_amdgcn_readfirstlane(a.start[b]), len = __builtin_amdgcn_readfirstlane(a.len[b]), klen = __builtin_amdgcn_readfirstlane(a.klen[b]);
+    if (qb >= len) return;                     // second half of an utterance's last 128-query item
+    const int q0 = qb + wave * 16;
     const float* qbase = a.qkv + (size_t)h * DK;
     const float* kbase = a.qkv + a.D + (size_t)h * DK;
     const float* vbase = a.qkv + 2 * a.D + (size_t)h * DK;

@@ -18,6 +18,26 @@ constexpr int kMaxHalo = 16;   // LDS rows reserved for conv halos (ktaps <= 17)
 constexpr int kBK = 32;        // K-chunk (channels per LDS stage) of the fp32 GEMMs
 constexpr int kLd = kBK + 4;   // LDS row stride in floats (16-B aligned, breaks the 128-B bank period)
 
+constexpr int kAttBQ = 64;   // queries per workgroup (4 waves x 16) of attn_f32 / attn_bf16
+constexpr int kAttBlk = 128; // queries per work-list item: one workgroup of attn_w32 (4 waves x 32), two of the 64-query kernels
+
+// The 64-query kernels (attn_f32, attn_bf16) over the 128-query work list: grid.x = 2 x (items rounded up to a multiple of 8);
+// workgroup x serves half (x >> 3) & 1 of item 8 (x >> 4) + (x & 7), so x % 8 -- the XCD the workgroup runs on -- is the item's
+// position in the eight interleaved queues (fs2_runtime.hip: build_work_list) and the halves of an item are dispatched 8 apart.
+// Returns false when there is nothing to do; q0 = first query of the workgroup.
+inline unsigned att_grid64(int nitems) { return 2u * (unsigned)((nitems + 7) & ~7); }
+__device__ __forceinline__ bool att_item64(const int2* work, const int* nwork, int nitems, int& b, int& q0) {
+    const int x = (int)blockIdx.x;
+    const int item = ((x >> 4) << 3) | (x & 7);
+    if (item >= (nwork != nullptr ? *nwork : nitems)) return false;
+    const int2 wk = work[item];
+    // (explicit scalars: the values are wave-uniform, but loaded through the vector cache they would occupy vector registers -- and
+    //  attn_bf16<192,3> has none to spare)
+    b = __builtin_amdgcn_readfirstlane(wk.x);
+    q0 = __builtin_amdgcn_readfirstlane(wk.y) * kAttBlk + ((x >> 3) & 1) * kAttBQ;
+    return b >= 0;                             // (-1: padding entry of the XCD-interleaved work list)
+}
+
 // Activation layout ("gapped packed rows"): utterance b owns rows [start[b], start[b]+len[b]) of every
 // [R, width] activation buffer; at least kGap zero rows separate utterances and precede the first one,
 // so a k-tap convolution along the row axis needs no boundary logic: it simply reads the zero rows.

@@ -27,7 +27,7 @@ __global__ void build_row_meta(const int* start, const int* len, int B, int rpad
 // kGap zero rows between utterances, attention work list = (utterance, 64-query block) items in eight interleaved per-XCD queues,
 // utterances dealt longest-key-range first to the shortest queue, padding entries (-1, 0).
 // One workgroup.  dims = {rows used, work list length, overflow flags, longest utterance, valid frames}; pcum[b] = valid frames of the
-// utterances before b (row offset of utterance b in the packed output); 8 = kGap = kAttAlign, 64 = kAttBQ.
+// utterances before b (row offset of utterance b in the packed output); 8 = kGap = kAttAlign, 128 = kAttBlk.
 __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B, int compat, int masked, int row_cap, int work_cap,
                                                          int lmax_cap, int pe_rows, int* start, int* len, int* klen, int* vlen,
                                                          int* rank_tmp, int* woff_tmp, int* pcum, int2* work, int* dims, int* status = nullptr, int gap = 8) {
@@ -84,10 +84,10 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
         s_row = row + 8; s_frames = frames;      // + kTailRows, as build_layout on the host
     }
     __syncthreads();
-    // blocks of 64 queries per utterance IN DEALING ORDER, so that the serial loop below walks two arrays front to back instead of
+    // blocks of 128 queries (kAttBlk) per utterance IN DEALING ORDER, so that the serial loop below walks two arrays front to back instead of
     // chasing s_order[r] -> s_len[b] through LDS (two dependent round trips per utterance on one thread)
     if (staged)
-        for (int r = tid; r < B; r += 1024) s_vlen[r] = (s_len[s_order[r]] + 63) >> 6;
+        for (int r = tid; r < B; r += 1024) s_vlen[r] = (s_len[s_order[r]] + 127) >> 7;
     __syncthreads();
     if (tid == 0) {
         const int row = s_row, frames = s_frames;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
             for (int t = 1; t < 8; ++t)
                 if (qlen[t] < best) { best = qlen[t]; j = t; }
             woff_tmp[b] = best * 8 + j;           // list position of the utterance's first block; the next ones follow 8 apart
-            const int add = staged ? s_vlen[r] : ((len[b] + 63) >> 6);
+            const int add = staged ? s_vlen[r] : ((len[b] + 127) >> 7);
 #pragma unroll
             for (int t = 0; t < 8; ++t) qlen[t] += (t == j) ? add : 0;
             depth = max(depth, best + add);
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
         return;
     }
     for (int b = tid; b < B; b += 1024) {
-        const int nq = (len[b] + 63) >> 6, o = woff_tmp[b];
+        const int nq = (len[b] + 127) >> 7, o = woff_tmp[b];
         for (int q = 0; q < nq; ++q) work[o + 8 * q] = make_int2(b, q);
     }
 }

@@ -17,6 +17,7 @@
 
 #include "../../include/fs2.h"
 #include "attn_bf16.h"
+#include "attn_w32.h"
 #include "attn_f32.h"
 #include "common.h"
 #include "elementwise.h"
@@ -87,6 +88,7 @@ struct Options {
     int f32_rows = 0;    // FS2_F32_ROWS row-complete fp32 GEMM for LayerNorm-terminated ops
     int fuse_var = 1;    // FS2_FUSE_VAR the pitch and the energy predictor as one launch per layer (0: separate launches)
     int mt8 = -1;        // FS2_MT8      m-tiles per wave of the 8-wave row-complete kernels (2 | 3: 128 / 192-row workgroups)
+    int w32 = -1;        // FS2_ATTN_W32 split-bf16 attention with 32 queries per wave (attn_w32.h): 0 never, 1 whenever the head dim allows, -1 by regime
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -96,7 +98,7 @@ Options& opts() {
     static Options o = [] {
         Options x;
         x.bm = env_int("FS2_BM", -1); x.row8 = env_int("FS2_ROW8", -1); x.qkv8 = env_int("FS2_QKV8", -1);
-        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 0);
+        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 0); x.w32 = env_int("FS2_ATTN_W32", -1);
         return x;
     }();
     return o;
@@ -557,10 +559,10 @@ int launch_attention(fs2_handle* h, hipStream_t s, const char* name, const float
     if (!dk_true) dk_true = dk;
     AttnArgs a;
     a.qkv = qkv; a.ld = 3 * D; a.ctx = ctx; a.ldc = D; a.start = dl.start; a.len = dl.len; a.klen = dl.klen;
-    a.work = dl.work; a.nwork = dl.dims ? dl.dims + 1 : nullptr; a.D = D; a.mask_q = mask_q; a.scale = 1.0f / sqrtf((float)dk_true);
+    a.work = dl.work; a.nwork = dl.dims ? dl.dims + 1 : nullptr; a.nitems = nwork; a.D = D; a.mask_q = mask_q; a.scale = 1.0f / sqrtf((float)dk_true);
     if (nwork == 0) return FS2_OK;
     Scope sc(h, s, name, flops, 0.0);
-    dim3 grid(nwork, heads);
+    dim3 grid(att_grid64(nwork), heads);      // two 64-query workgroups per 128-query work item
     if (dk == 128) {
         static LdsAttr attr;
         allow_lds(reinterpret_cast<const void*>(&attn_f32<128>), attn_lds_bytes<128>(), attr);
@@ -583,6 +585,26 @@ int launch_attention(fs2_handle* h, hipStream_t s, const char* name, const float
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, FS2_ERR_HIP, "%s launch: %s", name, hipGetErrorString(e));
     return FS2_OK;
+}
+
+template <int DK>
+hipError_t launch_attn_w32_t(hipStream_t s, dim3 grid, const AttnB16Args& a) {
+    static LdsAttr attr;
+    allow_lds(reinterpret_cast<const void*>(&attn_w32<DK>), attn_w32_lds_bytes<DK>(), attr);
+    hipLaunchKernelGGL((attn_w32<DK>), grid, dim3(256), attn_w32_lds_bytes<DK>(), s, a);
+    return hipGetLastError();
+}
+
+// attn_w32 (32 queries per wave, one wave per SIMD, 128-query workgroups) serves the split-bf16 launches whose grid fills the chip:
+// below kW32MinBlocks 128-query blocks per head a 128-query workgroup per CU leaves CUs idle and doubles the serial chain of an
+// utterance's key tiles per wave; the 64-query kernel keeps those (token-level launches, single utterances).  The choice is a
+// function of the regime row count (fs2_decode: derived from the phoneme count), like every other kernel-variant choice.
+constexpr int kW32MinBlocks = 64;
+bool use_attn_w32(int precision, int dk, long rows, unsigned long long qk_lo_bytes, unsigned long long vt_lo_bytes) {
+    if (precision != FS2_PREC_BF16X3 || (dk != 128 && dk != 192)) return false;
+    if (qk_lo_bytes >= (1ull << 31) || vt_lo_bytes >= (1ull << 31)) return false;      // the lo planes must sit within 2 GB behind the hi planes (32-bit DMA offsets)
+    if (opts().w32 >= 0) return opts().w32 != 0;
+    return (rows + kAttBlk - 1) / kAttBlk >= kW32MinBlocks;
 }
 
 template <int DK, int NSPLIT>
@@ -617,10 +639,19 @@ int launch_attention_b16(fs2_handle* h, hipStream_t s, const char* name, const f
     AttnB16Args a;
     a.qk_hi = qkh; a.qk_lo = qkl; a.ldqk = 2 * D; a.vt_hi = vth; a.vt_lo = vtl; a.Rvt = Rvt; a.ctx = ctx; a.ldc = D;
     a.ctxp = ctxp; a.ctxp_chunks = D / 32;
-    a.start = dl.start; a.len = dl.len; a.klen = dl.klen; a.work = dl.work; a.nwork = dl.dims ? dl.dims + 1 : nullptr; a.D = D; a.mask_q = mask_q;
+    a.start = dl.start; a.len = dl.len; a.klen = dl.klen; a.work = dl.work; a.nwork = dl.dims ? dl.dims + 1 : nullptr; a.nitems = nwork; a.D = D; a.mask_q = mask_q;
+    const ptrdiff_t qk_d = reinterpret_cast<const char*>(qkl) - reinterpret_cast<const char*>(qkh), vt_d = reinterpret_cast<const char*>(vtl) - reinterpret_cast<const char*>(vth);
+    a.qk_lo_bytes = (unsigned)qk_d; a.vt_lo_bytes = (unsigned)vt_d;
     Scope sc(h, s, name, flops, 0.0);
-    dim3 grid(nwork, heads);
     hipError_t e;
+    const long regime = (h && h->cur_regime > 0) ? std::min<long>(h->cur_regime, R) : R;
+    if (qk_d > 0 && vt_d > 0 && use_attn_w32(precision, dk, regime, (unsigned long long)qk_d, (unsigned long long)vt_d)) {
+        dim3 grid(nwork, heads);
+        e = dk == 128 ? launch_attn_w32_t<128>(s, grid, a) : launch_attn_w32_t<192>(s, grid, a);
+        if (e != hipSuccess) return fail(h, FS2_ERR_HIP, "%s launch: %s", name, hipGetErrorString(e));
+        return FS2_OK;
+    }
+    dim3 grid(att_grid64(nwork), heads);      // two 64-query workgroups per 128-query work item
     const bool x3 = precision == FS2_PREC_BF16X3;
     if (dk == 128) e = x3 ? launch_attn_b16_t<128, 3>(s, grid, a) : launch_attn_b16_t<128, 1>(s, grid, a);
     else if (dk == 192) e = x3 ? launch_attn_b16_t<192, 3>(s, grid, a) : launch_attn_b16_t<192, 1>(s, grid, a);
@@ -632,7 +663,8 @@ int launch_attention_b16(fs2_handle* h, hipStream_t s, const char* name, const f
 }
 
 // ------------------------------------------------------------------ layouts
-// Attention work list = (utterance, 64-query block) items, dispatched in list order.  Two goals:
+// Attention work list = (utterance, 128-query block) items (kAttBlk: one workgroup of attn_w32, two of the 64-query kernels),
+// dispatched in list order.  Two goals:
 //  * XCD locality: workgroup i of a launch runs on XCD i % 8 (round-robin dispatch) and every XCD has its own L2.  All query
 //    blocks of one utterance stream the same K / V rows, so they are given to ONE XCD: the list is eight interleaved queues
 //    (entry 8 i + j = i-th item of queue j).  With the blocks of an utterance spread over all XCDs the K / V planes were
@@ -648,7 +680,7 @@ void build_work_list(const std::vector<int>& len, const std::vector<int>& klen, 
     for (int b : order) {
         int j = 0;
         for (int t = 1; t < kXcds; ++t) if (q[t].size() < q[j].size()) j = t;
-        for (int i = 0; i * kAttBQ < len[b]; ++i) q[j].push_back(make_int2(b, i));
+        for (int i = 0; i * kAttBlk < len[b]; ++i) q[j].push_back(make_int2(b, i));
     }
     size_t depth = 0;
     for (int j = 0; j < kXcds; ++j) depth = std::max(depth, q[j].size());
@@ -1576,7 +1608,7 @@ int64_t fs2_row_capacity(const fs2_batch* b, int64_t total_frames_bound) {
 void capacity_layout(const fs2_batch& b, int64_t row_capacity, int lmax_cap, HostLayout& L) {
     L.B = b.B; L.R = (int)row_capacity; L.Rpad = round_up((int)row_capacity, 128);
     // eight LPT queues: none is longer than the mean plus one utterance's items
-    L.work_cap = kXcds * (((int)(row_capacity / kAttBQ) + b.B + kXcds - 1) / kXcds + lmax_cap / kAttBQ + 2);
+    L.work_cap = kXcds * (((int)(row_capacity / kAttBlk) + b.B + kXcds - 1) / kXcds + lmax_cap / kAttBlk + 2);
     L.start.clear(); L.len.clear(); L.klen.clear(); L.vlen.clear(); L.work.clear();
 }
 
@@ -1860,7 +1892,7 @@ int fs2_op_attention(void* stream, const float* qkv, float* ctx, int32_t D, int3
     std::vector<int2> work;
     int R = 0;
     for (int b = 0; b < B; ++b) {
-        for (int q = 0; q * kAttBQ < seq_len[b]; ++q) work.push_back(make_int2(b, q));
+        for (int q = 0; q * kAttBlk < seq_len[b]; ++q) work.push_back(make_int2(b, q));
         R = std::max(R, seq_start[b] + seq_len[b]);
         if (precision != FS2_PREC_FP32 && seq_start[b] % kAttAlign) return fail(nullptr, FS2_ERR_ARG, "bf16 attention needs sequence starts aligned to %d rows", kAttAlign);
     }
@@ -1975,6 +2007,7 @@ int fs2_set_option(const char* name, int32_t value) {
     else if (n == "FS2_MT8") o.mt8 = value;
     else if (n == "FS2_FUSE_VAR") o.fuse_var = value != 0;
     else if (n == "FS2_BAL") o.bal = value < 0 ? 0 : value;
+    else if (n == "FS2_ATTN_W32") o.w32 = value;
     else return fail(nullptr, FS2_ERR_ARG, "fs2_set_option: unknown option %s", name);
     return FS2_OK;
 }

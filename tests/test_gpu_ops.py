@@ -190,15 +190,21 @@ def test_conv_gemm_transpose_detecting():
 ATT_TOL = {"fp32": 5e-6, "bf16x3": 7e-5, "bf16": 3.5e-2}
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
+# "bf16x3/w32": the same arithmetic through attn_w32 (32 queries per wave; forced with FS2_ATTN_W32 = 1: the automatic choice takes it
+# only for grids that fill the chip); "bf16x3" pins the 64-query kernel (FS2_ATTN_W32 = 0)
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x3/w32", "bf16"])
 @pytest.mark.parametrize("D,heads", [(256, 2), (384, 2)])
 @pytest.mark.parametrize("mask_q", [0, 1])
-def test_attention(D, heads, mask_q, precision):
+def test_attention(D, heads, mask_q, precision, fs2_option):
     from tests import ops_binding as ops
     dev = _dev()
+    if precision.startswith("bf16x3"):
+        fs2_option("FS2_ATTN_W32", 1 if precision.endswith("/w32") else 0)
+        precision = "bf16x3"
     rs = np.random.RandomState(D + mask_q)
-    lens = [70, 1, 33, 200, 64]
-    klens = [70, 1, 20, 150, 64] if mask_q else lens
+    # (lengths around the tile sizes of both kernels: 32-key tiles, 64- and 128-query blocks; a 1-frame utterance; klen % 8 != 0)
+    lens = [70, 1, 33, 200, 64, 129, 261]
+    klens = [70, 1, 20, 150, 64, 128, 255] if mask_q else lens
     starts, row = [], 32
     for l in lens:
         starts.append(row)
@@ -229,15 +235,21 @@ def test_attention(D, heads, mask_q, precision):
     assert worst < ATT_TOL[precision], "max-abs %g" % worst
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-def test_attention_spiked_key_forces_rescale(precision):
-    """One key far above the others late in the sequence: exercises the online-softmax rescale branch."""
+@pytest.mark.parametrize("spike", [40.0, 400.0])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x3/w32"])
+def test_attention_spiked_key_forces_rescale(precision, spike, fs2_option):
+    """One key far above the others late in the sequence: exercises the online-softmax rescale branch of the 64-query kernels and, in
+    attn_w32 (which never rescales: attn_w32.h), the deferred reference maximum (spike 40: the row's scores jump by ~2^40 over its first
+    tile's maximum) and the wave's exit to the plain fp32 row loop (spike 400: beyond 2^64)."""
     from tests import ops_binding as ops
     dev = _dev()
+    if precision.startswith("bf16x3"):
+        fs2_option("FS2_ATTN_W32", 1 if precision.endswith("/w32") else 0)
+        precision = "bf16x3"
     rs = np.random.RandomState(5)
     D, heads, l = 256, 2, 130
     qkv = _rand(rs, 32 + l + 16, 3 * D, scale=0.5)
-    qkv[32 + 97, D:2 * D] = qkv[32 + 3, 0:D] * 40.0      # key 97 aligned with query 3
+    qkv[32 + 97, D:2 * D] = qkv[32 + 3, 0:D] * spike      # key 97 aligned with query 3
     ctx = ops.attention(qkv.to(dev), D, heads, [32], [l], [l], 0, precision=precision).cpu()
     dk = D // heads
     q, k, v = (qkv[32:32 + l, i * D:(i + 1) * D].double().view(l, heads, dk).transpose(0, 1) for i in range(3))

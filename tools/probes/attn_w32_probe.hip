@@ -1,0 +1,197 @@
+// attn_w32<DK> against attn_bf16<DK,3> on the same split-bf16 operands: max |difference| of the context (both are the same
+// arithmetic up to the summation order and the deferred rescale), then the time of each kernel.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I fastspeech2_amd/csrc tools/probes/attn_w32_probe.hip -o tools/probes/attn_w32_probe.bin
+//   attn_w32_probe.bin <B> <Lmin> <Lmax> [dk = 192] [reps = 5] [klen_slack = 0] [spike = 0]
+// spike > 0: one key per utterance (in its third tile) gets K scaled by `spike`, so that rows meet a score far above their first
+// tile's maximum -- above 2^64 the wave leaves the fast path (attn_w32_rows_slow).  Small cases (<= 2e8 score pairs) are also checked
+// against a double-precision host reference of the same split operands.
+// Utterance b has a length in [Lmin, Lmax] (deterministic spread); with klen_slack > 0 the last `slack` rows of every utterance are
+// masked keys holding NaN (the padded_compat form).  Rows between utterances hold NaN in K and V^T as well.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <algorithm>
+#include "gemm_bf16.h"
+#include "attn_bf16.h"
+#include "attn_w32.h"
+using namespace fs2;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+static unsigned short f2bf(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffff) > 0x7f800000) return 0x7fc0;
+    u += 0x7fff + ((u >> 16) & 1);
+    return (unsigned short)(u >> 16);
+}
+static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+template <int DK>
+int run(int B, int Lmin, int Lmax, int reps, int slack, float spike) {
+    const int heads = 2, D = heads * DK;
+    std::vector<int> start(B), len(B), klen(B);
+    int row = 8;
+    long long pairs = 0;
+    for (int b = 0; b < B; ++b) {
+        len[b] = Lmin + (int)(((long long)(Lmax - Lmin) * ((b * 37) % 101)) / 100);
+        klen[b] = std::max(1, len[b] - slack);
+        row = (row + 7) & ~7; start[b] = row; row += len[b] + 8;
+        pairs += (long long)len[b] * klen[b];
+    }
+    row += 8;
+    const int Rvt = (row + 127) & ~127;
+    std::vector<int2> work;
+    {   // eight interleaved queues, longest first (as build_work_list)
+        std::vector<int> order(B);
+        for (int b = 0; b < B; ++b) order[b] = b;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return klen[x] > klen[y]; });
+        std::vector<int2> q[8];
+        for (int b : order) {
+            int j = 0;
+            for (int t = 1; t < 8; ++t) if (q[t].size() < q[j].size()) j = t;
+            for (int i = 0; i * kAttBlk < len[b]; ++i) q[j].push_back(make_int2(b, i));
+        }
+        size_t depth = 0;
+        for (int j = 0; j < 8; ++j) depth = std::max(depth, q[j].size());
+        work.assign(depth * 8, make_int2(-1, 0));
+        for (int j = 0; j < 8; ++j) for (size_t i = 0; i < q[j].size(); ++i) work[i * 8 + j] = q[j][i];
+    }
+    // operands: fp32 values -> hi / lo bf16 planes; NaN wherever a key must never be read
+    std::vector<unsigned short> qkh((size_t)Rvt * 2 * D, 0x7fc0), qkl((size_t)Rvt * 2 * D, 0x7fc0), vth((size_t)D * Rvt, 0x7fc0), vtl((size_t)D * Rvt, 0x7fc0);
+    srand(1234);
+    auto rnd = [] { return (float)((rand() & 0xffff) - 32768) / 32768.f; };
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < len[b]; ++t) {
+            const size_t r = (size_t)start[b] + t;
+            for (int c = 0; c < 2 * D; ++c) {
+                const bool is_k = c >= D;
+                if (is_k && t >= klen[b]) continue;                  // masked key rows stay NaN
+                float x = rnd() * (is_k ? 1.5f : 0.6f);
+                if (is_k && spike > 0.f && t == 70 && t < klen[b]) x *= spike;
+                const unsigned short hh = f2bf(x);
+                qkh[r * 2 * D + c] = hh; qkl[r * 2 * D + c] = f2bf(x - bf2f(hh));
+            }
+            if (t < klen[b])
+                for (int n = 0; n < D; ++n) {
+                    const float x = rnd() * 2.f;
+                    const unsigned short hh = f2bf(x);
+                    vth[(size_t)n * Rvt + r] = hh; vtl[(size_t)n * Rvt + r] = f2bf(x - bf2f(hh));
+                }
+        }
+    __bf16 *dq, *dv; float *ctx0, *ctx1; int* dmeta; int2* dwork;
+    const size_t qbytes = qkh.size() * 2, vbytes = vth.size() * 2;
+    CK(hipMalloc(&dq, 2 * qbytes)); CK(hipMalloc(&dv, 2 * vbytes));
+    CK(hipMemcpy(dq, qkh.data(), qbytes, hipMemcpyHostToDevice)); CK(hipMemcpy((char*)dq + qbytes, qkl.data(), qbytes, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dv, vth.data(), vbytes, hipMemcpyHostToDevice)); CK(hipMemcpy((char*)dv + vbytes, vtl.data(), vbytes, hipMemcpyHostToDevice));
+    CK(hipMalloc(&ctx0, (size_t)Rvt * D * 4)); CK(hipMalloc(&ctx1, (size_t)Rvt * D * 4));
+    CK(hipMemset(ctx0, 0, (size_t)Rvt * D * 4)); CK(hipMemset(ctx1, 0, (size_t)Rvt * D * 4));
+    CK(hipMalloc(&dmeta, 3 * B * 4)); CK(hipMalloc(&dwork, work.size() * 8));
+    CK(hipMemcpy(dmeta, start.data(), B * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dmeta + B, len.data(), B * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dmeta + 2 * B, klen.data(), B * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dwork, work.data(), work.size() * 8, hipMemcpyHostToDevice));
+    AttnB16Args a;
+    memset(&a, 0, sizeof a);
+    a.qk_hi = dq; a.qk_lo = (const __bf16*)((const char*)dq + qbytes); a.ldqk = 2 * D;
+    a.vt_hi = dv; a.vt_lo = (const __bf16*)((const char*)dv + vbytes); a.Rvt = Rvt; a.ldc = D; a.ctxp = nullptr; a.ctxp_chunks = D / 32;
+    a.start = dmeta; a.len = dmeta + B; a.klen = dmeta + 2 * B; a.work = dwork; a.nwork = nullptr; a.nitems = (int)work.size(); a.D = D; a.mask_q = slack > 0;
+    a.qk_lo_bytes = (unsigned)qbytes; a.vt_lo_bytes = (unsigned)vbytes;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16<DK, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_b16_lds_bytes<DK>()));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_w32<DK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_w32_lds_bytes<DK>()));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const double flops = 4.0 * DK * heads * (double)pairs;
+    float best0 = 1e9f, best1 = 1e9f;
+    for (int rep = 0; rep < reps; ++rep) {
+        float ms;
+        a.ctx = ctx0;
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((attn_bf16<DK, 3>), dim3(att_grid64((int)work.size()), heads), dim3(256), attn_b16_lds_bytes<DK>(), 0, a);
+        hipEventRecord(e1); CK(hipDeviceSynchronize());
+        hipEventElapsedTime(&ms, e0, e1); best0 = std::min(best0, ms);
+        a.ctx = ctx1;
+#ifdef FS2_W32_TIMING
+        { long long zero[8] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_w32_phase), zero, sizeof zero)); }
+#endif
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((attn_w32<DK>), dim3((unsigned)work.size(), heads), dim3(256), attn_w32_lds_bytes<DK>(), 0, a);
+        hipEventRecord(e1); CK(hipDeviceSynchronize());
+        hipEventElapsedTime(&ms, e0, e1); best1 = std::min(best1, ms);
+#ifdef FS2_W32_TIMING
+        if (rep == reps - 1) {
+            long long ph[8]; CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_w32_phase), sizeof ph));
+            const double n = (double)std::max(1LL, ph[4]);
+            printf("  wave 0 of workgroup 0, cycles per tile over %lld tiles: phase A (Q.K^T + exponentials + DMA issue) %.0f | phase B (P.V + next head) %.0f | DMA wait %.0f | barrier %.0f\n",
+                   ph[4], ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n);
+        }
+#endif
+    }
+    std::vector<float> c0((size_t)Rvt * D), c1((size_t)Rvt * D);
+    CK(hipMemcpy(c0.data(), ctx0, c0.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(c1.data(), ctx1, c1.size() * 4, hipMemcpyDeviceToHost));
+    double maxd = 0, maxv = 0; long long bad = 0, nan0 = 0, nan1 = 0;
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < len[b]; ++t)
+            for (int c = 0; c < D; ++c) {
+                const size_t i = ((size_t)start[b] + t) * D + c;
+                if (std::isnan(c0[i])) ++nan0;
+                if (std::isnan(c1[i])) ++nan1;
+                const double d = fabs((double)c0[i] - c1[i]);
+                if (!(d <= 2e-5)) ++bad;
+                if (d > maxd) maxd = d;
+                maxv = std::max(maxv, (double)fabs(c0[i]));
+            }
+    // host reference (double) of the same operands for small cases
+    double maxr0 = -1, maxr1 = -1;
+    if ((double)pairs * heads <= 2e8 / DK * 16) {
+        maxr0 = maxr1 = 0;
+        std::vector<double> sc, ov(DK);
+        for (int b = 0; b < B; ++b)
+            for (int hh = 0; hh < heads; ++hh)
+                for (int t = 0; t < len[b]; ++t) {
+                    const size_t rq = (size_t)start[b] + t;
+                    sc.assign(klen[b], 0.0);
+                    double m = -1e300;
+                    for (int k = 0; k < klen[b]; ++k) {
+                        const size_t rk = (size_t)start[b] + k;
+                        double d = 0;
+                        for (int c = 0; c < DK; ++c) {
+                            const size_t iq = rq * 2 * D + hh * DK + c, ik = rk * 2 * D + D + hh * DK + c;
+                            d += ((double)bf2f(qkh[iq]) + bf2f(qkl[iq])) * ((double)bf2f(qkh[ik]) + bf2f(qkl[ik]));
+                        }
+                        sc[k] = d; m = std::max(m, d);
+                    }
+                    double l = 0;
+                    std::fill(ov.begin(), ov.end(), 0.0);
+                    for (int k = 0; k < klen[b]; ++k) {
+                        const double pk = exp2(sc[k] - m);
+                        l += pk;
+                        const size_t rk = (size_t)start[b] + k;
+                        for (int c = 0; c < DK; ++c) {
+                            const size_t iv = (size_t)(hh * DK + c) * Rvt + rk;
+                            ov[c] += pk * ((double)bf2f(vth[iv]) + bf2f(vtl[iv]));
+                        }
+                    }
+                    const bool dead = slack > 0 && t >= klen[b];
+                    for (int c = 0; c < DK; ++c) {
+                        const double ref = dead ? 0.0 : ov[c] / l;
+                        const size_t i = rq * D + hh * DK + c;
+                        maxr0 = std::max(maxr0, fabs(ref - c0[i]));
+                        const double d1 = fabs(ref - c1[i]);
+                        if (!(d1 <= 1e-4) && bad < 8) { printf("  w32 wrong at utt %d row %d head %d ch %d: %g, reference %g, attn_bf16 %g\n", b, t, hh, c, c1[i], ref, c0[i]); }
+                        maxr1 = std::max(maxr1, std::isnan(c1[i]) ? 1e30 : d1);
+                    }
+                }
+    }
+    printf("dk=%d B=%d L=[%d,%d] slack=%d spike=%g items=%zu: attn_bf16 %.1f us (%.1f TF/s)  attn_w32 %.1f us (%.1f TF/s)  speedup %.3f | max|diff| %.3e (max|ctx| %.2f) bad %lld nan %lld/%lld | vs host reference: attn_bf16 %.3e attn_w32 %.3e\n",
+           DK, B, Lmin, Lmax, slack, (double)spike, work.size(), best0 * 1e3, flops / best0 * 1e-9, best1 * 1e3, flops / best1 * 1e-9, best0 / best1, maxd, maxv, bad, nan0, nan1, maxr0, maxr1);
+    hipFree(dq); hipFree(dv); hipFree(ctx0); hipFree(ctx1); hipFree(dmeta); hipFree(dwork);
+    return (bad || nan1) ? 2 : 0;
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 64, Lmin = argc > 2 ? atoi(argv[2]) : 300, Lmax = argc > 3 ? atoi(argv[3]) : 800;
+    const int dk = argc > 4 ? atoi(argv[4]) : 192, reps = argc > 5 ? atoi(argv[5]) : 5, slack = argc > 6 ? atoi(argv[6]) : 0;
+    const float spike = argc > 7 ? (float)atof(argv[7]) : 0.f;
+    if (dk == 192) return run<192>(B, Lmin, Lmax, reps, slack, spike);
+    if (dk == 128) return run<128>(B, Lmin, Lmax, reps, slack, spike);
+    printf("dk must be 128 or 192\n");
+    return 1;
+}
