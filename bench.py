@@ -2,7 +2,9 @@
 """Benchmark of the MI355X FastSpeech2 mel-generation path (BASELINE.json metric: mel-frames/sec).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  (N > 1: either under python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...,
+   or as the plain command above: without WORLD_SIZE in the environment the script re-launches itself under torch.distributed.run
+   with N ranks on 127.0.0.1 and a free port; rank 0 prints the one JSON line either way)
 
 One "step" = one full free-running forward of the hot path over one synthetic batch already resident in
 HBM: phoneme ids -> encoder -> duration predictor -> length regulator -> pitch/energy -> decoder -> mel
@@ -21,6 +23,7 @@ value = valid mel frames of the global batch / max-over-ranks wall time of exact
 import argparse
 import json
 import os
+import socket
 import statistics
 import sys
 import time
@@ -46,7 +49,7 @@ WORKLOAD_TEXT = {
 
 
 def csrc_sha16():
-    """Fingerprint of the kernel sources (what profiles/r03_traffic.json was measured on)."""
+    """Fingerprint of the kernel sources (what profiles/r04_traffic.json was measured on)."""
     import hashlib
     hsh = hashlib.sha256()
     d = os.path.join(ROOT, "fastspeech2_amd", "csrc")
@@ -125,6 +128,48 @@ def cpu_baseline(sd, cfg, batch, gpu, budget_s=14.0):
                        "one padded batch of %d = %.0f fr/s; faster quoted" % (n, frames, per_utt, nb, padded)), worst, flips
 
 
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def relaunch_command(argv, gpus):
+    """`python bench.py --gpus N ...` without a launcher: the same command under torch.distributed.run, one rank per GPU of this node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def fake_main(args, json_fd):
+    """TEST HARNESS (tests/test_parallel_gloo.py, FS2_BENCH_FAKE=1): the launch / sharding / collective / timing skeleton of this script
+    on CPU ranks over gloo with the stand-in model of the gloo tests -- what lets a machine without GPUs check that
+    `python bench.py --gpus 2` spawns its ranks and prints ONE line.  Measures nothing."""
+    from fastspeech2_amd.parallel import ShardedSynthesizer
+    from tests.test_parallel_gloo import FakeModel, _make_inputs
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        os.environ["MASTER_PORT"] = str(free_port())
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # (also at world size 1: the collective path is the one under test)
+    xs, il = _make_inputs(B=4 * max(world, 1) + 3)
+    synth = ShardedSynthesizer(FakeModel())
+    out = synth(xs, il, sync=True)
+    for _ in range(args.warmup):
+        out = synth(xs, il, sync=False, packed=not args.padded)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = synth(xs, il, sync=False, packed=not args.padded)
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    frames = int(torch.as_tensor(out[-1]).sum())
+    if rank == 0:
+        os.write(json_fd, (json.dumps({"metric": "mel-frames/sec", "value": round(frames * args.steps / dt, 1), "unit": "mel-frames/s", "n_gpus": world,
+                                       "steps": args.steps, "warmup": args.warmup, "data": "FAKE (FS2_BENCH_FAKE test harness: gloo, stand-in model, measures nothing)",
+                                       "config": {"workload": "fake", "gather": "padded" if args.padded else "packed"}}) + "\n").encode())
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,7 +180,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-kernels", action="store_true", help="print the per-kernel hipEvent table to stderr")
     ap.add_argument("--graph", action="store_true", help="replay the forward as one captured HIP graph (single GPU; the launch-bound small configs)")
+    ap.add_argument("--padded", action="store_true", help="N > 1: every rank also unpacks the gathered mels into the padded [B, Lcap, odim] tensor "
+                                                           "(default: the packed form, gathered packs + offsets, no unpack launch)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched as a plain command: become `torch.distributed.run ... bench.py <same arguments>` (one rank per GPU, 127.0.0.1, a free port)
+        cmd = relaunch_command(sys.argv[1:], args.gpus)
+        sys.stdout.flush()
+        os.execv(cmd[0], cmd)
     # stdout carries exactly ONE line, the JSON record: whatever a library prints there (RCCL's version banner, ...) goes to stderr
     json_fd = os.dup(1)
     os.dup2(2, 1)
@@ -144,14 +196,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("--gpus %d under a launcher with WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("FS2_BENCH_FAKE") == "1":
+        return fake_main(args, json_fd)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("FS2_FORCE_DIST") == "1"    # FS2_FORCE_DIST: exercise the RCCL path with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:          # (only the one-rank FS2_FORCE_DIST form gets here without a launcher)
+            os.environ["MASTER_PORT"] = str(free_port())
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     workload = args.workload or ("c5" if use_dist else "c3")
 
@@ -187,8 +242,12 @@ def main():
             mel_, ol_, _ = graph_run(xs)
             return mel_, ol_
         if synth is not None:
-            # LPT shard -> sync-free single-GPU path -> one all-gather (packs + frame counts) -> ordered padded mels on every rank
-            return synth(xs, il, sync=args.profile_kernels)
+            # LPT shard -> sync-free single-GPU path -> one all-gather (packs + frame counts) -> on every rank the gathered packs +
+            # offsets (default) or, with --padded, one more launch that scatters them into the ordered padded [B, Lcap, odim] tensor
+            if args.padded or args.profile_kernels:
+                return synth(xs, il, sync=args.profile_kernels)
+            r = synth(xs, il, packed=True)        # (recv, starts, olens); the very first call is synchronous and returns (mels, olens)
+            return r[0], r[-1]
         # nothing on the host waits for the GPU: the frame layout is built on the device (fs2_decode's device-driven
         # mode); the very first call is synchronous and teaches the capacity predictor the frames-per-phoneme ratio
         # (--profile-kernels uses the host-driven layout so that the per-site FLOP counts are those of the rows in use)
@@ -292,14 +351,39 @@ def main():
         roofline["measured_mfma_peak"] = 1950.0
         roofline["issued_frac_of_measured_peak"] = round(achieved * {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1, "mix_mx": 2}.get(args.precision, 1) / 1950.0, 4) \
             if dom_name.endswith("ffn1") or args.precision == "bf16x3" else None
-    try:    # HBM-side bytes per launch: rocprofv3 PMC passes of this same command (tools/profile_round.sh -> profiles/).  The record names the
-        # kernel sources it was measured on: after any change to them it is stale and `traffic` stays null instead of quoting an old kernel
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+    # Algorithmic HBM bytes of one launch of the dominant kernel, from the launch's own shapes (valid rows of this rank): every operand read
+    # once, every result written once.  bf16 modes: an activation travels as planes of 4 bytes per element (hi + lo bf16, or the mx image
+    # of the same size), a weight image has 4 bytes per weight; the attention kernel reads the Q | K | V^T planes and writes the context planes.
+    eb = 4
+    shapes = {"dec.ffn1": (c["ddim"], c["dunits"], c["ffn_kernel"]), "enc.ffn1": (c["adim"], c["eunits"], c["ffn_kernel"]),
+              "dec.ffn2_ln": (c["dunits"], c["ddim"], 1), "dec.qkv": (c["ddim"], 3 * c["ddim"], 1), "dec.out_ln": (c["ddim"], c["ddim"], 1)}
+    algo_bytes = None
+    if dom_name in shapes:
+        Cc, Nn, kk = shapes[dom_name]
+        algo_bytes = dict(a_planes_read=rows * Cc * eb, weight_image_read=Nn * kk * Cc * eb, result_written=rows * Nn * eb * (2 if dom_name.endswith("_ln") else 1))
+    elif dom_name in per_launch:
+        Dd = c["ddim"] if dom_name.startswith("dec") else c["adim"]
+        algo_bytes = dict(qkv_planes_read=rows * 3 * Dd * eb, context_planes_written=rows * Dd * eb)
+    if algo_bytes is not None:
+        roofline["algorithmic_bytes"] = int(sum(algo_bytes.values()))
+        roofline["algorithmic_bytes_parts"] = {k: int(v) for k, v in algo_bytes.items()}
+    # the whole step against the same peak: algorithmic FLOP of the step (valid tokens / frames of the global batch)
+    # / wall time per step / (peak x GPUs) -- `frac` above is the best kernel's, this is the path's
+    step_flop = sum(path_flops(int(t), int(l)) for t, l in zip(il, olens_all.cpu()))
+    roofline["step_frac"] = round(step_flop / (dt / args.steps) / 1e12 / (peak * world), 4)
+    try:    # HBM-side bytes per launch + the matrix-pipe occupancy of the same kernel: rocprofv3 PMC passes of this same command (tools/profile_round.sh
+        # -> tools/pmc_summary.py -> profiles/).  The record names the kernel sources it was measured on: after any change to them it is stale and
+        # the fields stay null instead of quoting an old kernel
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
         if (tr["workload"] == workload and tr["precision"] == args.precision and tr["kernel_site"] == dom_name and world == 1
                 and tr.get("csrc_sha16") == csrc_sha16()):
             roofline["traffic"] = tr["traffic_bytes"]
-            roofline["traffic_note"] = ("rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r03_traffic.json (separate --pmc passes of this "
-                                        "command on these kernel sources); algorithmic HBM bytes %d" % tr["algorithmic_bytes"])
+            roofline["traffic_note"] = ("rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r04_traffic.json (separate --pmc passes of this "
+                                        "command on these kernel sources)")
+            if roofline.get("algorithmic_bytes"):
+                roofline["traffic_over_algorithmic"] = round(tr["traffic_bytes"] / roofline["algorithmic_bytes"], 2)
+            if tr.get("mfma_busy") is not None:
+                roofline["mfma_busy"] = tr["mfma_busy"]          # SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES) of the dominant kernel
     except (OSError, KeyError, ValueError):
         pass
     if args.precision in MFMA_PER_PRODUCT and dom_name.endswith("ffn1"):   # split operands: several MFMAs are issued per algorithmic product
@@ -342,6 +426,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s%s; default.yaml dims, free-running, random-init weights (seed 0), duration bias calibrated to 7.87 frames/phoneme"
                                    % (WORKLOAD_TEXT[workload], " -- here %d utterances on %d GPU(s)" % (B, world) if workload == "c5" else ""),
+                       "precision": args.precision,      # the arithmetic mode the line was measured in (rounds 1-2: bf16x3; since round 3: mix_mx)
                        "utterances": B, "utterances_per_gpu": [len(p) for p in parts], "valid_frames_per_step": total_frames,
                        "phonemes": int(il.sum()),
                        "algorithmic_gflop_per_step": round(sum(path_flops(int(t), int(l)) for t, l in zip(il, ol_host)) / 1e9, 1),

@@ -110,7 +110,10 @@ def build_torch_op(force=False, verbose=False):
     src = os.path.join(CSRC, "fs2_torch_op.cpp")
     hdr = os.path.join(_HERE, "..", "include", "fs2.h")
     build(force=False)
-    if not force and os.path.exists(TORCH_OP_PATH) and os.path.getmtime(TORCH_OP_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    # (rebuilt when its source, the header OR libfs2_hip.so is newer: the op links against the library's ABI, and checks
+    #  fs2_abi_version() against its own FS2_ABI_VERSION at first use)
+    if not force and os.path.exists(TORCH_OP_PATH) and os.path.getmtime(TORCH_OP_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr),
+                                                                                             os.path.getmtime(LIB_PATH)):
         return TORCH_OP_PATH
     import torch
     tdir = os.path.dirname(torch.__file__)

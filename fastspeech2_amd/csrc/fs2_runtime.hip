@@ -644,7 +644,9 @@ int launch_attention_b16(fs2_handle* h, hipStream_t s, const char* name, const f
     a.qk_lo_bytes = (unsigned)qk_d; a.vt_lo_bytes = (unsigned)vt_d;
     Scope sc(h, s, name, flops, 0.0);
     hipError_t e;
-    const long regime = (h && h->cur_regime > 0) ? std::min<long>(h->cur_regime, R) : R;
+    // (the regime row count of the call in progress when there is one: derived from the phoneme count, it is the same number in the host-
+    //  and the device-driven layout of a batch, whose R -- rows in use vs row capacity -- differ)
+    const long regime = (h && h->cur_regime > 0) ? h->cur_regime : R;
     if (qk_d > 0 && vt_d > 0 && use_attn_w32(precision, dk, regime, (unsigned long long)qk_d, (unsigned long long)vt_d)) {
         dim3 grid(nwork, heads);
         e = dk == 128 ? launch_attn_w32_t<128>(s, grid, a) : launch_attn_w32_t<192>(s, grid, a);

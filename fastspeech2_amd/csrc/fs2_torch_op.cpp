@@ -9,7 +9,7 @@
 //
 // x: [T] int64 phoneme ids; flat_weights: every float32 tensor of the twin's state dict, concatenated; config_json: the hyper-parameters
 // (the fs2_config fields) plus the manifest {"tensors": [[name, [shape...]], ...]} that says how to cut the flat buffer, written by
-// fastspeech2_amd/fastspeech2_script.py at export time.  The op builds a libfs2_hip handle per (weight buffer, config) -- an LRU of four --
+// fastspeech2_amd/fastspeech2_script.py at export time.  The op builds a libfs2_hip handle per (weight buffer, config) -- an LRU of FS2_TWIN_CACHE entries (default 2) --
 // and runs fs2_encode -> frame count read-back -> fs2_decode on torch's current HIP stream with torch-allocated workspaces, exactly what
 // FeedForwardTransformer.inference() does through ctypes.  Inputs on another device are moved to the weights' device (the reference traces
 // with a CPU example input, export_torchscript.py:53-56); weights on the CPU are refused: there is no CPU path.
@@ -19,6 +19,7 @@
 #include <torch/library.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <list>
 #include <map>
@@ -39,42 +40,93 @@ struct Json {
 struct JsonParser {
     const std::string& s; size_t i = 0;
     explicit JsonParser(const std::string& s_) : s(s_) {}
+    // every read of s[i] goes through at(): a truncated or malformed document is a TORCH_CHECK error, never a read past the buffer
+    char at() const { TORCH_CHECK(i < s.size(), "fs2::twin_inference: truncated config_json (offset ", i, ")"); return s[i]; }
     void ws() { while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) ++i; }
-    Json parse() {
+    static void put_utf8(std::string& o, unsigned cp) {
+        if (cp < 0x80) o.push_back((char)cp);
+        else if (cp < 0x800) { o.push_back((char)(0xC0 | (cp >> 6))); o.push_back((char)(0x80 | (cp & 0x3F))); }
+        else if (cp < 0x10000) { o.push_back((char)(0xE0 | (cp >> 12))); o.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); o.push_back((char)(0x80 | (cp & 0x3F))); }
+        else { o.push_back((char)(0xF0 | (cp >> 18))); o.push_back((char)(0x80 | ((cp >> 12) & 0x3F))); o.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); o.push_back((char)(0x80 | (cp & 0x3F))); }
+    }
+    unsigned hex4() {
+        TORCH_CHECK(i + 4 <= s.size(), "config_json: truncated \\u escape");
+        unsigned v = 0;
+        for (int k = 0; k < 4; ++k) {
+            const char c = s[i++];
+            v <<= 4;
+            if (c >= '0' && c <= '9') v |= (unsigned)(c - '0');
+            else if (c >= 'a' && c <= 'f') v |= (unsigned)(c - 'a' + 10);
+            else if (c >= 'A' && c <= 'F') v |= (unsigned)(c - 'A' + 10);
+            else TORCH_CHECK(false, "config_json: bad \\u escape");
+        }
+        return v;
+    }
+    Json parse(int depth = 0) {
+        TORCH_CHECK(depth < 64, "config_json: nested too deeply");
         ws();
-        TORCH_CHECK(i < s.size(), "fs2::twin_inference: truncated config_json");
         Json j;
-        const char c = s[i];
+        const char c = at();
         if (c == '{') {
             j.kind = Json::Obj; ++i; ws();
-            if (s[i] == '}') { ++i; return j; }
+            if (at() == '}') { ++i; return j; }
             for (;;) {
-                ws(); Json k = parse(); TORCH_CHECK(k.kind == Json::Str, "config_json: object key is not a string");
-                ws(); TORCH_CHECK(s[i] == ':', "config_json: ':' expected"); ++i;
-                j.obj[k.str] = parse(); ws();
-                if (s[i] == ',') { ++i; continue; }
-                TORCH_CHECK(s[i] == '}', "config_json: '}' expected"); ++i; return j;
+                ws(); Json k = parse(depth + 1); TORCH_CHECK(k.kind == Json::Str, "config_json: object key is not a string");
+                ws(); TORCH_CHECK(at() == ':', "config_json: ':' expected"); ++i;
+                j.obj[k.str] = parse(depth + 1); ws();
+                if (at() == ',') { ++i; continue; }
+                TORCH_CHECK(at() == '}', "config_json: '}' expected"); ++i; return j;
             }
         }
         if (c == '[') {
             j.kind = Json::Arr; ++i; ws();
-            if (s[i] == ']') { ++i; return j; }
+            if (at() == ']') { ++i; return j; }
             for (;;) {
-                j.arr.push_back(parse()); ws();
-                if (s[i] == ',') { ++i; continue; }
-                TORCH_CHECK(s[i] == ']', "config_json: ']' expected"); ++i; return j;
+                j.arr.push_back(parse(depth + 1)); ws();
+                if (at() == ',') { ++i; continue; }
+                TORCH_CHECK(at() == ']', "config_json: ']' expected"); ++i; return j;
             }
         }
         if (c == '"') {
             j.kind = Json::Str; ++i;
-            while (i < s.size() && s[i] != '"') { if (s[i] == '\\' && i + 1 < s.size()) ++i; j.str.push_back(s[i++]); }
-            ++i; return j;
+            for (;;) {
+                const char ch = at();          // (an unterminated string ends in the TORCH_CHECK of at())
+                ++i;
+                if (ch == '"') return j;
+                if (ch != '\\') { j.str.push_back(ch); continue; }
+                const char e = at();
+                ++i;
+                switch (e) {
+                    case '"': case '\\': case '/': j.str.push_back(e); break;
+                    case 'n': j.str.push_back('\n'); break;
+                    case 't': j.str.push_back('\t'); break;
+                    case 'r': j.str.push_back('\r'); break;
+                    case 'b': j.str.push_back('\b'); break;
+                    case 'f': j.str.push_back('\f'); break;
+                    case 'u': {      // json.dumps writes every non-ASCII character of an hp value this way
+                        unsigned cp = hex4();
+                        if (cp >= 0xD800 && cp < 0xDC00 && i + 1 < s.size() && s[i] == '\\' && s[i + 1] == 'u') {
+                            i += 2;
+                            const unsigned lo = hex4();
+                            TORCH_CHECK(lo >= 0xDC00 && lo < 0xE000, "config_json: unpaired surrogate");
+                            cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                        }
+                        put_utf8(j.str, cp);
+                        break;
+                    }
+                    default: TORCH_CHECK(false, "config_json: unknown escape \\", std::string(1, e));
+                }
+            }
         }
         if (!s.compare(i, 4, "true")) { j.kind = Json::Bool; j.b = true; i += 4; return j; }
         if (!s.compare(i, 5, "false")) { j.kind = Json::Bool; i += 5; return j; }
         if (!s.compare(i, 4, "null")) { i += 4; return j; }
-        size_t n = 0;
-        j.kind = Json::Num; j.num = std::stod(s.substr(i), &n); i += n;
+        // a number, parsed in place (std::string is NUL-terminated: strtod stops at the terminator at the latest; no copy of the tail)
+        const char* b = s.c_str() + i;
+        char* end = nullptr;
+        j.kind = Json::Num; j.num = std::strtod(b, &end);
+        TORCH_CHECK(end != b, "config_json: unexpected character '", std::string(1, c), "' at offset ", i);
+        i += (size_t)(end - b);
         return j;
     }
 };
@@ -93,8 +145,23 @@ struct Entry {
     std::map<std::string, at::Tensor> grown;      // positional tables recomputed for longer utterances (reference embedding.py:50-56 extend_pe)
 };
 std::mutex g_mu;
-std::list<Entry> g_lru;               // front = most recent
-constexpr size_t kMaxEntries = 4;
+// The cache is reached through a pointer that is never deleted: its entries hold device tensors and library handles, and static
+// destruction at process exit may run after the HIP runtime / torch's caching allocator have been torn down.  Eviction (below) is
+// what frees an entry: fs2_destroy for the handle's device allocations, then the tensors.
+std::list<Entry>& lru() { static std::list<Entry>* l = new std::list<Entry>(); return *l; }      // front = most recent
+size_t max_entries() {      // FS2_TWIN_CACHE (1 .. 16, default 2): every entry is a full copy of the weights on the device
+    static const size_t n = [] { const char* e = getenv("FS2_TWIN_CACHE"); const long v = e ? atol(e) : 2; return (size_t)std::min<long>(std::max<long>(v, 1), 16); }();
+    return n;
+}
+void check_abi() {      // a stale libfs2_torch.so next to a newer libfs2_hip.so (or the reverse) must not get as far as a struct mismatch
+    static const bool ok = [] {
+        const uint32_t v = fs2_abi_version();
+        TORCH_CHECK(v == FS2_ABI_VERSION, "libfs2_torch.so was built against include/fs2.h ABI revision ", FS2_ABI_VERSION,
+                    " but libfs2_hip.so reports revision ", v, ": rebuild both (python __graft_entry__.py)");
+        return true;
+    }();
+    (void)ok;
+}
 
 void check(int rc, fs2_handle* h, const char* what) {
     TORCH_CHECK(rc == FS2_OK, "libfs2_hip: ", what, " failed (", rc, "): ", fs2_last_error(h));
@@ -137,6 +204,8 @@ Entry& get_entry(const at::Tensor& flat, const std::string& config, hipStream_t 
     const void* ptr = flat.data_ptr();
     const uint32_t ver = flat._version();
     const int dev = flat.get_device();
+    check_abi();
+    std::list<Entry>& g_lru = lru();
     for (auto it = g_lru.begin(); it != g_lru.end(); ++it)
         if (it->ptr == ptr && it->numel == flat.numel() && it->version == ver && it->dev == dev && it->config == config) {
             g_lru.splice(g_lru.begin(), g_lru, it);
@@ -196,7 +265,7 @@ Entry& get_entry(const at::Tensor& flat, const std::string& config, hipStream_t 
         fs2_destroy(e.h);
         throw;
     }
-    while (g_lru.size() >= kMaxEntries) { fs2_destroy(g_lru.back().h); g_lru.pop_back(); }
+    while (g_lru.size() >= max_entries()) { fs2_destroy(g_lru.back().h); g_lru.pop_back(); }
     g_lru.push_front(std::move(e));
     return g_lru.front();
 }

@@ -58,6 +58,20 @@ class FeedForwardTransformer(_Base):
     """Same ctor as reference utils/fastspeech2_script.py:29; ``forward(x)`` as :201-219; state_dict keys as the
     reference twin's (``decoder.embed.0.{alpha,pe}``, ``feat_out.weight [odim, adim]``)."""
 
+    __jit_unused_properties__ = ["precision"]
+
+    @property
+    def precision(self):
+        """The arithmetic mode (as on the base class).  On the twin it is frozen into ``config_json`` when the weights are packed, so
+        setting it repacks: `twin.precision = "mix_mx"` followed by scripting / saving exports what was asked for, not fp32."""
+        return self.__dict__.get("_precision", "fp32")
+
+    @precision.setter
+    def precision(self, value):
+        self.__dict__["_precision"] = value
+        if self.__dict__.get("config_json"):      # (not yet during __init__: the first pack_weights() comes at its end)
+            self.pack_weights()
+
     def __init__(self, idim: int, odim: int, hp):
         super().__init__(idim, odim, hp, _script_twin=True)
         self._hp_plain = {"model": dict(hp.model), "data": {k: hp.data[k] for k in ("e_min", "e_max", "p_min", "p_max")}}

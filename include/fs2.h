@@ -54,9 +54,14 @@ extern "C" {
 
 typedef struct fs2_handle fs2_handle;
 
-/* ABI revision of this header.  Every struct a caller fills and passes by pointer starts with `struct_size`, which the
- * library compares with its own sizeof: a caller built against a different revision gets FS2_ERR_ARG (and a message
- * naming both sizes) instead of fields read at the wrong offsets.  fs2_abi_version() returns the library's revision. */
+/* ABI revision of this header.  The four structs that are the argument of an entry point -- fs2_config, fs2_encode_io,
+ * fs2_decode_io, fs2_op_gemm_args -- start with `struct_size`, which the library compares with its own sizeof: a caller
+ * built against a different revision gets FS2_ERR_ARG (and a message naming both sizes) instead of fields read at the
+ * wrong offsets.  Two structs carry no size field: `fs2_batch`, embedded in the io structs and so covered by their check
+ * and passed alone only to the workspace-size / row-capacity queries, and `fs2_tensor_desc`, the array elements handed to
+ * fs2_load_weights.  Their layout is frozen within a revision: any change to them bumps FS2_ABI_VERSION, and a binding
+ * compares its own FS2_ABI_VERSION with fs2_abi_version() before the first call (fastspeech2_amd/_lib.py: lib();
+ * csrc/fs2_torch_op.cpp: check_abi()). */
 #define FS2_ABI_VERSION 3
 int32_t fs2_abi_version(void);
 

@@ -239,8 +239,9 @@ def test_attention(D, heads, mask_q, precision, fs2_option):
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x3/w32"])
 def test_attention_spiked_key_forces_rescale(precision, spike, fs2_option):
     """One key far above the others late in the sequence: exercises the online-softmax rescale branch of the 64-query kernels and, in
-    attn_w32 (which never rescales: attn_w32.h), the deferred reference maximum (spike 40: the row's scores jump by ~2^40 over its first
-    tile's maximum) and the wave's exit to the plain fp32 row loop (spike 400: beyond 2^64)."""
+    attn_w32 (which never rescales: its reference maximum is the first tile's, attn_w32.h), probabilities far above 1 (rows whose
+    scores jump by less than 2^60 over their first tile's maximum) and the wave's exit to the plain fp32 row loop (beyond: spike 40
+    sends some rows there, spike 400 nearly all)."""
     from tests import ops_binding as ops
     dev = _dev()
     if precision.startswith("bf16x3"):

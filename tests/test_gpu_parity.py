@@ -498,9 +498,8 @@ _C4_ORACLE = {}      # utterance index -> oracle mel (the same 16 utterances ser
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "mix_mx"])
 def test_full_size_c4_length_regulator_stress(env, precision):
     """BASELINE config c4 (B=256, 32..512 phonemes, ~0.5 M frames, Lmax > 4000, with Postnet): frame counts,
-    zero pads, exact length-regulator indices for every utterance, and a seeded sample of 16 utterances -- the two
-    shortest, the two longest (beyond the 5000-row positional table when the batch has such) and 12 random ones -- against
-    the oracle, in fp32, bf16x3 and the bench default mix_mx."""
+    zero pads, exact length-regulator indices and the mel of EVERY one of the 256 utterances against the oracle (the oracle's
+    results are computed once and shared by the three modes), in fp32, bf16x3 and the bench default mix_mx."""
     model, sd, cfg, O = env
     from fastspeech2_amd.synthetic import make_batch
     from tests.conftest import record_measurement
@@ -523,26 +522,27 @@ def test_full_size_c4_length_regulator_stress(env, precision):
         assert torch.equal(idx, torch.repeat_interleave(torch.arange(T), b["ds"][i, :T])), i   # bit-exact
         assert (lri[i, L:] == -1).all()
     order = torch.argsort(b["olens"]).tolist()
-    rest = [i for i in order[2:-2]]
-    pick = order[:2] + order[-2:] + [rest[j] for j in np.random.RandomState(44).permutation(len(rest))[:12]]
+    pick = list(range(after.shape[0]))
+    after_h = after.cpu()
     worst = 0.0
     for i in pick:
         T, L = int(b["ilens"][i]), int(b["olens"][i])
         if i not in _C4_ORACLE:
             _C4_ORACLE[i] = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], is_inference=True, d_override=b["ds"][i:i + 1, :T])["after"][0]
-        d = _maxabs(after[i, :L], _C4_ORACLE[i])
+        d = _maxabs(after_h[i, :L], _C4_ORACLE[i])
         assert d <= MEL_TOL, (i, L, d)
         worst = max(worst, d)
-    print("c4 [%s]: %d frames, Lmax %d; %d sampled utterances (L %d..%d): worst mel max-abs vs oracle %.2e"
-          % (precision, int(b["olens"].sum()), after.shape[1], len(pick), int(b["olens"][order[0]]), int(b["olens"][order[-1]]), worst))
-    record_measurement("c4_sample16_mel_maxabs_" + precision, worst)
+    print("c4 [%s]: %d frames, Lmax %d; %d / %d utterances (L %d..%d) vs the oracle: worst mel max-abs %.2e"
+          % (precision, int(b["olens"].sum()), after.shape[1], len(pick), after.shape[0], int(b["olens"][order[0]]), int(b["olens"][order[-1]]), worst))
+    record_measurement("c4_all256_mel_maxabs_" + precision, worst)
 
 
 def test_c5_shard_of_the_8_gpu_partition(env):
     """BASELINE config c5 (batch = 1024 sharded over 8 MI355X): the shard rank 0 of 8 gets from the LPT partition
     (`shard_indices`, 128 +- a few utterances), mix_mx, through the batched entry point in its packed form (what the
-    all-gather ships): properties on every utterance, a seeded sample of 16 (plus the longest and the shortest) against the
-    oracle.  The 8-rank collective itself is covered on CPU (tests/test_parallel_gloo.py) and at world size 1 below."""
+    all-gather ships): EVERY utterance of that shard against the oracle, plus the longest and the shortest utterance of each of
+    the other seven shards (run as one more batch: per-utterance semantics, so a result does not depend on its batch-mates).
+    The 8-rank collective itself is covered on CPU (tests/test_parallel_gloo.py) and at world size 1 below."""
     model, sd, cfg, O = env
     from fastspeech2_amd.synthetic import make_batch
     from fastspeech2_amd.parallel import shard_indices
@@ -562,17 +562,41 @@ def test_c5_shard_of_the_8_gpu_partition(env):
         model.precision = "fp32"
     assert torch.equal(ol, b["olens"][sel]) and packed.shape == (int(ol.sum()), 80) and torch.isfinite(packed).all()
     starts = (torch.cumsum(ol, 0) - ol).tolist()
-    order = torch.argsort(ol).tolist()
-    pick = sorted(set([order[0], order[-1]] + np.random.RandomState(55).permutation(len(sel))[:16].tolist()))
     packed_h, worst = packed.cpu(), 0.0
-    for j in pick:
+    for j in range(len(sel)):
         T, L = int(il[j]), int(ol[j])
         o = O.padded_forward(sd, cfg, xs[j:j + 1, :T], il[j:j + 1], is_inference=True, d_override=ds[j:j + 1, :T])
         d = float((packed_h[starts[j]:starts[j] + L] - o["after"][0]).abs().max())
         assert d <= MEL_TOL, (j, L, d)
         worst = max(worst, d)
-    print("c5 shard 0/8: %d utterances, %d frames; %d sampled utterances: worst mel max-abs vs oracle %.2e" % (len(sel), int(ol.sum()), len(pick), worst))
-    record_measurement("c5_shard_sample_mel_maxabs_mix_mx", worst)
+    # the extremes of the other shards
+    extra = []
+    for p_ in parts[1:]:
+        lens_ = b["olens"][torch.as_tensor(p_)]
+        extra += [p_[int(torch.argmax(lens_))], p_[int(torch.argmin(lens_))]]
+    esel = torch.as_tensor(sorted(set(extra)))
+    eil = b["ilens"][esel]
+    eTm = int(eil.max())
+    exs, eds = b["xs"][esel][:, :eTm], b["ds"][esel][:, :eTm]
+    model.precision = "mix_mx"
+    try:
+        with torch.no_grad():
+            epk, eol = model.inference_batch(exs.cuda(), eil, d_override=eds.cuda(), packed=True)
+    finally:
+        model.precision = "fp32"
+    assert torch.equal(eol, b["olens"][esel])
+    est, epk_h = (torch.cumsum(eol, 0) - eol).tolist(), epk.cpu()
+    for j in range(len(esel)):
+        T, L = int(eil[j]), int(eol[j])
+        o = O.padded_forward(sd, cfg, exs[j:j + 1, :T], eil[j:j + 1], is_inference=True, d_override=eds[j:j + 1, :T])
+        d = float((epk_h[est[j]:est[j] + L] - o["after"][0]).abs().max())
+        assert d <= MEL_TOL, (int(esel[j]), L, d)
+        worst = max(worst, d)
+    n_cmp = len(sel) + len(esel)
+    assert n_cmp >= 142 - 2, n_cmp          # (128 +- a few of shard 0, two per other shard)
+    print("c5 shard 0/8: %d utterances, %d frames, all vs the oracle + %d extremes of the other shards = %d utterances: worst mel max-abs %.2e"
+          % (len(sel), int(ol.sum()), len(esel), n_cmp, worst))
+    record_measurement("c5_shard_all_plus_extremes_mel_maxabs_mix_mx", worst)
 
 
 def test_sharded_synthesizer_over_nccl_world_size_1(env):
@@ -1017,3 +1041,65 @@ def test_c3_free_running_decisions_equal_the_oracles(env, precision):
     print("c3 free-running [%s]: %d phonemes -> %d frames (%.2f per phoneme), every decision equal, mel max-abs %.2e" % (precision, tok, frames, frames / tok, worst))
     assert 7.6 <= frames / tok <= 8.1               # LJSpeech-like (7.87)
     assert worst <= C3_TOL.get(precision, MEL_TOL)
+
+
+# ---- static-scale stress (VERDICT r03 "what's weak" 1): every parity number above comes from ONE weight distribution (uniform +-1/sqrt(fan_in),
+# LayerNorm affine 1 +- 0.1), while the bench default mix_mx keeps the cross terms of the FFN conv in e4m3 with STATIC per-tensor scales
+# (kw from max |w|, ka from sqrt(D) max|gamma| + max|beta|; gemm_mx.h): one outlier weight or a large gamma costs every other element of
+# that tensor exponent range.  Real checkpoints are unreachable here, so the heavy tails are synthesised.
+def _stressed_state_dict(sd, kind, seed=123):
+    rs = np.random.RandomState(seed)
+    out = {}
+    for k, v in sd.items():
+        v = v.clone()
+        is_mat = v.dim() >= 2 and v.is_floating_point() and "embed" not in k and not k.endswith("pe")
+        if kind == "student_t" and is_mat:
+            t = torch.from_numpy(rs.standard_t(3.0, size=tuple(v.shape))).float()
+            v = t * (v.pow(2).mean().sqrt() / t.pow(2).mean().sqrt())              # same rms, Student-t(3) tails (max / rms ~ 30 .. 100)
+        elif kind == "ffn_outliers" and k.endswith("w_1.weight"):
+            m = torch.from_numpy(rs.uniform(size=tuple(v.shape)) < 1e-3)
+            v = torch.where(m, v * 30.0, v)                                        # 0.1 % of the FFN conv weights x 30
+        elif kind == "ln_affine" and v.dim() == 1 and ("norm" in k) and k.endswith("weight"):
+            v = torch.from_numpy(rs.uniform(0.1, 8.0, size=tuple(v.shape))).float()
+        elif kind == "ln_affine" and v.dim() == 1 and ("norm" in k) and k.endswith("bias"):
+            v = torch.from_numpy(rs.uniform(-2.0, 2.0, size=tuple(v.shape))).float()
+        out[k] = v
+    return out
+
+
+@pytest.mark.parametrize("kind", ["student_t", "ffn_outliers", "ln_affine"])
+def test_static_scale_arithmetic_under_heavy_tailed_weights(env, kind):
+    """mix_mx (and bf16x3 as the control) against the oracle with heavy-tailed weights / outlier FFN weights / wide LayerNorm affines, on
+    the c2 batch and on the two longest utterances of c4.  The mel's own scale grows with these weights, so the bar is relative to it:
+    2.5e-4 x max(1, max|mel| / 4) (4 = the mel range of the plain synthetic model); the numbers are recorded."""
+    from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
+    from fastspeech2_amd.synthetic import make_batch
+    from tests.conftest import record_measurement
+    _, sd0, cfg, O = env
+    sd = _stressed_state_dict(sd0, kind)
+    hp = default_hparams()
+    model = FeedForwardTransformer(N_PHONEME_SYMBOLS, hp.audio.num_mels, hp).eval()
+    model.load_state_dict(sd)
+    model = model.to("cuda:0")
+    b2 = make_batch("c2")
+    b4 = make_batch("c4")
+    long2 = torch.argsort(b4["olens"])[-2:]
+    T4, L4 = int(b4["ilens"][long2].max()), int(b4["olens"][long2].max())
+    sub4 = dict(xs=b4["xs"][long2][:, :T4], ilens=b4["ilens"][long2], ds=b4["ds"][long2][:, :T4], olens=b4["olens"][long2],
+                es=b4["es"][long2][:, :L4], ps=b4["ps"][long2][:, :L4])
+    for name, b in (("c2", b2), ("c4_longest2", sub4)):
+        # teacher-forced (durations, energy, pitch given): the comparison measures arithmetic, not flipped bucket decisions
+        o = O.per_utterance_forward(sd, cfg, b["xs"], b["ilens"], b["ds"], b["es"], b["ps"])
+        scale = float(o["after"].abs().max())
+        errs = {}
+        for prec in ("bf16x3", "mix_mx"):
+            model.precision = prec
+            with torch.no_grad():
+                r = model._run(b["xs"].cuda(), b["ilens"], b["olens"], b["ds"].cuda(), b["es"].cuda(), b["ps"].cuda(), is_inference=False, want=("after",))
+            assert torch.isfinite(r["after"]).all(), (kind, name, prec)
+            errs[prec] = _maxabs(r["after"], o["after"])
+            record_measurement("stress_%s_%s_%s_mel_maxabs" % (kind, name, prec), errs[prec])
+        record_measurement("stress_%s_%s_mel_scale" % (kind, name), scale)
+        bar = 2.5e-4 * max(1.0, scale / 4.0)
+        print("static-scale stress [%s, %s]: max|mel| %.2f; mel max-abs vs oracle: bf16x3 %.2e, mix_mx %.2e (bar %.2e)" % (kind, name, scale, errs["bf16x3"], errs["mix_mx"], bar))
+        assert errs["mix_mx"] <= bar, (kind, name, errs, scale)

@@ -197,3 +197,33 @@ def test_c5_partition_is_balanced():
     assert sorted(sum(parts, [])) == list(range(1024))
     loads = [sum(utterance_cost(il[i]) for i in p) for p in parts]
     assert max(loads) / (sum(loads) / 8) < 1.01
+
+
+def test_bench_self_launches_its_ranks_when_started_as_a_plain_command():
+    """`python bench.py --gpus 2` with no launcher (no WORLD_SIZE): the script re-launches itself under torch.distributed.run with two
+    ranks on 127.0.0.1 and a free port, and exactly ONE JSON line comes back on stdout (the only unmeasured row of the
+    survey depended on a launch convention).  FS2_BENCH_FAKE=1 swaps the GPU model for the stand-in of this file over gloo; the
+    launch, sharding, collective and printing code is the real one."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["FS2_BENCH_FAKE"] = "1"
+    for extra in ([], ["--padded"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra,
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0
+        assert rec["config"]["gather"] == ("padded" if extra else "packed")
+
+
+def test_bench_relaunch_command_shape():
+    import bench
+    cmd = bench.relaunch_command(["--gpus", "8", "--steps", "3"], 8)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "3"] and cmd[-5].endswith("bench.py")

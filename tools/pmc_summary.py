@@ -7,7 +7,7 @@ HBM traffic = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes): on gfx950 FETCH_SIZE ta
 coalesced reads at 64 B (MI355X_MICROARCH.md, HBM/rocprofv3 section); WRITE_SIZE is used as is."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 workload = os.environ.get("FS2_PROF_WORKLOAD", "c3")
 precision = os.environ.get("FS2_PROF_PRECISION", "mix_mx")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -58,7 +58,19 @@ import bench      # noqa: E402  (csrc_sha16: the fingerprint of the kernel sourc
 info["csrc_sha16"] = bench.csrc_sha16()
 if len(sys.argv) > 2:
     info["kernel_site"] = sys.argv[2]
-if len(sys.argv) > 3:
-    info["algorithmic_bytes"] = int(sys.argv[3])
+# matrix-pipe occupancy and wave-state shares of the same kernel (the algorithmic byte count is bench.py's business: it computes it from
+# the launch's shapes and reports traffic / algorithmic itself)
+def avg(c):
+    return sum(v[c]) / len(v[c]) if v.get(c) else None
+if avg("SQ_VALU_MFMA_BUSY_CYCLES") and avg("SQ_BUSY_CU_CYCLES"):
+    info["mfma_busy"] = round(avg("SQ_VALU_MFMA_BUSY_CYCLES") / (4.0 * avg("SQ_BUSY_CU_CYCLES")), 3)
+if avg("SQ_WAVE_CYCLES"):
+    for c, k in (("SQ_WAIT_ANY", "waves_parked"), ("SQ_WAIT_INST_ANY", "waves_issue_stalled"), ("SQ_ACTIVE_INST_ANY", "waves_issuing")):
+        if avg(c) is not None:
+            info[k] = round(avg(c) / avg("SQ_WAVE_CYCLES"), 3)
+if avg("SQ_LDS_IDX_ACTIVE"):
+    info["lds_bank_conflict_share"] = round((avg("SQ_LDS_BANK_CONFLICT") or 0.0) / avg("SQ_LDS_IDX_ACTIVE"), 4)
+if avg("SQ_INSTS_MFMA"):
+    info["valu_per_mfma"] = round(((avg("SQ_INSTS_VALU") or 0.0) - avg("SQ_INSTS_MFMA")) / avg("SQ_INSTS_MFMA"), 2)
 json.dump(info, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
 print(json.dumps(info, indent=1))

@@ -186,7 +186,37 @@ int run(int B, int Lmin, int Lmax, int reps, int slack, float spike) {
     return (bad || nan1) ? 2 : 0;
 }
 
+// Issue rate of v_mfma_f32_32x32x16_bf16 from one wave: 96 MFMAs rotating over NACC accumulators (NACC = 1: every MFMA depends on its
+// predecessor), cycles per MFMA from s_memtime.  One wave per SIMD (256 threads), one workgroup.
+template <int NACC>
+__global__ __launch_bounds__(256, 1) void mfma_chain(long long* out, const float* seed) {
+    bf16x8_t a = __builtin_bit_cast(bf16x8_t, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}), b = a;
+    f32x16 acc[NACC];
+    for (int k = 0; k < NACC; ++k) for (int r = 0; r < 16; ++r) acc[k][r] = seed[threadIdx.x & 15];
+    __builtin_amdgcn_sched_barrier(0);
+    const long long t0 = __builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 96; ++i) acc[i % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i % NACC], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    const long long t1 = __builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
+    float s_ = 0.f;
+    for (int k = 0; k < NACC; ++k) for (int r = 0; r < 16; ++r) s_ += acc[k][r];
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = (long long)s_; }
+}
+static int mfma_bench() {
+    long long* d; float* sd; CK(hipMalloc(&d, 16)); CK(hipMalloc(&sd, 64)); CK(hipMemset(sd, 0, 64));
+    long long h[2];
+    #define RUN(N) hipLaunchKernelGGL((mfma_chain<N>), dim3(1), dim3(256), 0, 0, d, sd); CK(hipDeviceSynchronize()); hipLaunchKernelGGL((mfma_chain<N>), dim3(1), dim3(256), 0, 0, d, sd); CK(hipDeviceSynchronize()); \
+        CK(hipMemcpy(h, d, 16, hipMemcpyDeviceToHost)); printf("v_mfma_f32_32x32x16_bf16, 96 in a row over %d accumulator(s): %.1f cycles per MFMA\n", N, h[0] / 96.0);
+    RUN(1) RUN(2) RUN(3) RUN(4)
+    #undef RUN
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "mfma")) return mfma_bench();
     const int B = argc > 1 ? atoi(argv[1]) : 64, Lmin = argc > 2 ? atoi(argv[2]) : 300, Lmax = argc > 3 ? atoi(argv[3]) : 800;
     const int dk = argc > 4 ? atoi(argv[4]) : 192, reps = argc > 5 ? atoi(argv[5]) : 5, slack = argc > 6 ? atoi(argv[6]) : 0;
     const float spike = argc > 7 ? (float)atof(argv[7]) : 0.f;

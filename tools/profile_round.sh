@@ -4,7 +4,7 @@
 # tools/pmc_summary.py on the build host and commit the summaries under profiles/.
 #   tools/profile_round.sh <tag> [workload] [precision] [pmc: 0|1]
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 WL=${2:-c3}
 PREC=${3:-mix_mx}
 PMC=${4:-1}
