@@ -492,7 +492,7 @@ def test_errors(env):
                        torch.ones(1, 4, dtype=torch.int64), torch.ones(1, 4), torch.ones(1, 4))
 
 
-_C4_ORACLE = {}      # utterance index -> oracle mel (the same 16 utterances serve every arithmetic mode)
+_C4_ORACLE = {}      # utterance index -> oracle (mel, energy codes, pitch codes): computed once, shared by the three arithmetic modes
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "mix_mx"])
@@ -524,17 +524,41 @@ def test_full_size_c4_length_regulator_stress(env, precision):
     order = torch.argsort(b["olens"]).tolist()
     pick = list(range(after.shape[0]))
     after_h = after.cpu()
-    worst = 0.0
+    worst, flipped_utts, flipped_frames = 0.0, [], 0
     for i in pick:
         T, L = int(b["ilens"][i]), int(b["olens"][i])
         if i not in _C4_ORACLE:
-            _C4_ORACLE[i] = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], is_inference=True, d_override=b["ds"][i:i + 1, :T])["after"][0]
-        d = _maxabs(after_h[i, :L], _C4_ORACLE[i])
+            o = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], is_inference=True, d_override=b["ds"][i:i + 1, :T])
+            _C4_ORACLE[i] = (o["after"][0], o["qe"][0, :L].long(), o["qp"][0, :L].long())
+        o_after, o_qe, o_qp = _C4_ORACLE[i]
+        d = _maxabs(after_h[i, :L], o_after)
+        if d > MEL_TOL:
+            # The pass is free-running in pitch and energy: ~1 M bucket decisions per mode, each a predictor output within ~1e-5 of the
+            # CPU's, so a few land on the other side of a bin edge in the reduced-precision modes (SURVEY.md hard part 2; fp32 has none).
+            # Such an utterance must (a) differ from the oracle in a handful of bucket indices and nowhere else in kind, and (b) match the
+            # oracle within the tolerance once pitch and energy are teacher-forced (the arithmetic, without the decision).
+            flips = int((qe_h[i, :L] != o_qe).sum() + (qp_h[i, :L] != o_qp).sum())
+            assert precision != "fp32" and 0 < flips <= max(3, L // 500), (i, L, d, flips)
+            sub = {k: b[k][i:i + 1] for k in ("xs", "ilens", "ds", "olens", "es", "ps")}
+            sub["xs"], sub["ds"], sub["es"], sub["ps"] = sub["xs"][:, :T], sub["ds"][:, :T], sub["es"][:, :L], sub["ps"][:, :L]
+            model.precision = precision
+            try:
+                with torch.no_grad():
+                    rt = model._run(sub["xs"].cuda(), sub["ilens"], sub["olens"], sub["ds"].cuda(), sub["es"].cuda(), sub["ps"].cuda(), is_inference=False, want=("after",))
+            finally:
+                model.precision = "fp32"
+            ot = O.per_utterance_forward(sd, cfg, sub["xs"], sub["ilens"], sub["ds"], sub["es"], sub["ps"])
+            d = _maxabs(rt["after"], ot["after"])
+            flipped_utts.append(i)
+            flipped_frames += flips
         assert d <= MEL_TOL, (i, L, d)
         worst = max(worst, d)
-    print("c4 [%s]: %d frames, Lmax %d; %d / %d utterances (L %d..%d) vs the oracle: worst mel max-abs %.2e"
-          % (precision, int(b["olens"].sum()), after.shape[1], len(pick), after.shape[0], int(b["olens"][order[0]]), int(b["olens"][order[-1]]), worst))
+    print("c4 [%s]: %d frames, Lmax %d; %d / %d utterances (L %d..%d) vs the oracle: worst mel max-abs %.2e; %d bucket decision(s) in %d utterance(s) "
+          "fell on the other side of a bin edge (those utterances verified teacher-forced)"
+          % (precision, int(b["olens"].sum()), after.shape[1], len(pick), after.shape[0], int(b["olens"][order[0]]), int(b["olens"][order[-1]]), worst,
+             flipped_frames, len(flipped_utts)))
     record_measurement("c4_all256_mel_maxabs_" + precision, worst)
+    record_measurement("c4_all256_flipped_bucket_decisions_" + precision, flipped_frames)
 
 
 def test_c5_shard_of_the_8_gpu_partition(env):
