@@ -151,7 +151,7 @@ __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7"
 // Phase timing for tools/probes/attn_w32_probe.hip (compiled only with -DFS2_W32_TIMING): cycles of wave 0 of workgroup (0, 0) per
 // phase of the tile loop: [0] prep + phase A, [1] phase B (+ head), [2] DMA wait, [3] barrier, [4] tiles counted.
 #ifdef FS2_W32_TIMING
-__device__ long long g_w32_phase[8];
+__device__ long long g_w32_phase[16];
 #define FS2_WT(i) { const long long t_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_w32_phase[i] += t_ - tprev; tprev = t_; }
 #else
 #define FS2_WT(i)
@@ -218,6 +218,12 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef FS2_W32_TIMING
+    long long tpro = __builtin_readcyclecounter();
+#define FS2_WP(i) { const long long t_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_w32_phase[i] += t_ - tpro; tpro = t_; }
+#else
+#define FS2_WP(i)
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     {
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
     const bool wave_live = q0 < len;           // wave-uniform: a wave whose 32 queries lie beyond the utterance only feeds the DMA
     const int ntiles = (klen + 31) >> 5;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t*)smem_w);
+    FS2_WP(8)
 
     // ---- DMA source offsets (loop invariant): piece p = 4u + wave of a tile, this lane's 16 bytes = physical slot 64 p + lane.
     // (ln: the lane index, passed in so that the slow paths can hand over an opaque copy -- otherwise hipcc hoists their whole address
@@ -346,24 +353,39 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
         for (int e = 0; e < 4; ++e) vp[e] = smem_w + 3 * KB + l31 * 128 + ((((2 * e) ^ (g & 6)) | (g & 1)) << 4);
     }
 
+    FS2_WP(9)
     if (ntiles > 0) issue_K(0, 0);
-    // Q fragments (B operand of S^T): row q0 + l31, d = 16c + 8 hi .. + 7
+    // Q fragments (B operand of S^T): row q0 + l31, d = 16c + 8 hi .. + 7.  The wave's 32 Q rows come in as ONE more tile of the K layout
+    // (LDS-DMA, coalesced 384-byte plane rows; rows beyond the utterance repeat its last row: their results are never stored) into a
+    // private region -- K slots 1, 2 and V^T slots 0, 1, free until the first barrier -- and the fragments are read from there.  (Loaded
+    // straight from global memory, 24 x 16 bytes per lane at a 1.5-KB row stride, the Q loads were 10,500 of the 26,000 cycles a
+    // workgroup spends outside its tile loop.)
+    static_assert(KB == VB, "the Q staging region spans K and V^T ring slots of equal size");
     bf16x8_t qh[NKS], ql[NKS];
-    {
-        const int qrow = q0 + l31;
-        const bool ok = qrow < len;
-        // (address selects, no branches: a row beyond the utterance reads the zero vector; see load4_or_zero)
-        const size_t off = (size_t)(s0 + qrow) * a.ldqk + (size_t)h * DK + hi * 8;
-        const __bf16* zq = reinterpret_cast<const __bf16*>(g_zero16);
-        const __bf16* ph_ = ok ? a.qk_hi + off : zq;
-        const __bf16* pl_ = ok ? a.qk_lo + off : zq;
-        const int cs = ok ? 16 : 0;
+    {       // (every wave, also one whose rows all lie beyond the utterance: no second definition of the fragments for hipcc to merge)
+        gchar_t* qbase = (gchar_t*)reinterpret_cast<const char*>(a.qk_hi + (size_t)h * DK);
+#pragma unroll
+        for (int pc = 0; pc < KSL; ++pc) {
+            const int G = pc * 64 + lane;
+            const int rho = G / (2 * KSL), ps = G - rho * (2 * KSL);
+            const int sl = (ps & ~15) | ((ps & 15) ^ (rho & 15));
+            const int plane = sl >= KSL;
+            const int qr = min(q0 + rho, len - 1);
+            dma16((const void*)(qbase + (size_t)(s0 + qr) * a.ldqk * 2 + (sl - plane * KSL) * 16 + (size_t)plane * a.qk_lo_bytes), lds0 + (1 + wave) * KB + pc * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int qoff = (1 + wave) * KB;
 #pragma unroll
         for (int c = 0; c < NKS; ++c) {
-            qh[c] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(ph_ + c * cs));
-            ql[c] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(pl_ + c * cs));
+            const int sh = 2 * c, sl = KSL + 2 * c;
+            qh[c] = *reinterpret_cast<const bf16x8_t*>(kp[(sh & 15) >> 1] + qoff + (sh >> 4) * 256);
+            ql[c] = *reinterpret_cast<const bf16x8_t*>(kp[(sl & 15) >> 1] + qoff + (sl >> 4) * 256);
+            // from here on the fragments ARE accumulator-file values (every later use asks for one): without this hipcc keeps them in the
+            // architectural file and copies each into a[0:3] -- O^T's registers, free in its eyes between two P.V statements -- at every use
+            asm volatile("" : "+a"(qh[c]), "+a"(ql[c]));
         }
     }
+    FS2_WP(10)
     {      // O^T = 0 (a[0 : 16 NT))
         const bf16x8_t z = __builtin_bit_cast(bf16x8_t, u32x4{0, 0, 0, 0});
         for_seq([&](auto n_tag) __attribute__((always_inline)) { mfma_o0<decltype(n_tag)::value>(z); }, std::make_integer_sequence<int, NT>{});
@@ -621,6 +643,7 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
     if (ntiles > 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();              // K(0) landed
+        FS2_WP(5)
         issue_K(min(1, ntiles - 1), 1);
         issue_K(min(2, ntiles - 1), 2);
         issue_V(0, 0);
@@ -641,12 +664,18 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
         for (int c = 0; c < NKS; ++c) asm volatile("" : : "a"(qh[c]), "a"(ql[c]));
         if (ntiles == 1) fix_V(0, 0);
         __syncthreads();              // K(1), K(2), V^T(0), V^T(1) landed; every wave is done with K(0)
+        FS2_WP(6)
         for (int kt = 0; kt < ntiles; kt += 3) {
             tile(I0{}, kt);
             if (kt + 1 < ntiles) tile(I1{}, kt + 1);
             if (kt + 2 < ntiles) tile(std::integral_constant<int, 2>{}, kt + 2);
         }
     }
+#ifdef FS2_W32_TIMING
+    tpro = __builtin_readcyclecounter();
+#endif
+    const bool staged = a.ctxp != nullptr && a.ctx == nullptr;      // the model's form: the context leaves as planes only
+    if (staged) __syncthreads();               // every wave is done with the rings: their memory stages the output tiles
     if (!wave_live) return;
     if (bail) {
         attn_w32_rows_slow<DK>(a, s0, len, klen, q0, h, lane);
@@ -654,26 +683,63 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
     }
 
     // O^T: register r of n-tile nt = head channel 32 nt + 8 (r >> 2) + 4 hi + (r & 3) of query q0 + l31: four consecutive
-    // channels per register quad -> 16-byte stores (or 8 + 8 bytes of planes)
+    // channels per register quad.
     mfma_drain();
     const int qrow = q0 + l31;
-    if (qrow >= len) return;
     const float linv = (l_run > 0.f) ? 1.f / l_run : 0.f;
     const bool dead = a.mask_q && qrow >= klen;
-    const size_t row = (size_t)(s0 + qrow);
-    for_seq([&](auto n_tag) __attribute__((always_inline)) {
-        constexpr int nt = decltype(n_tag)::value;
-        float e[16];
-        read_o<nt>(e);
+    if (staged) {
+        // The wave's 32 context rows as planes: per row the head's NT chunks of 128 B [hi 32 | lo 32] are contiguous in global memory
+        // (common.h: plane_byte), so the tile is staged in LDS in exactly that image (rows 16 bytes apart from a multiple of 256: the
+        // 8-byte writes of a 16-lane group land on 16 banks) and leaves as whole rows, 1 KB per store instruction.  (Stored from the
+        // registers -- 8 + 8 bytes per lane and four channels, 32 rows apart per instruction -- the epilogue took 6,300 cycles.)
+        constexpr int RS = DK * 4 + 16;
+        char* stage = smem_w + wave * (32 * RS);
+        for_seq([&](auto n_tag) __attribute__((always_inline)) {
+            constexpr int nt = decltype(n_tag)::value;
+            float e[16];
+            read_o<nt>(e);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int col = h * DK + 32 * nt + 8 * g + 4 * hi;
-            f32x4 v = f32x4{e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]} * linv;
-            if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (a.ctx) *reinterpret_cast<f32x4*>(a.ctx + row * a.ldc + col) = v;
-            if (a.ctxp) store_planes4(a.ctxp, row, a.ctxp_chunks, col, v);
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = f32x4{e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]} * linv;
+                if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                uint2 vh, vl;
+                split4(v, vh, vl);
+                char* d = stage + l31 * RS + nt * 128 + 16 * (2 * (g & 1) + hi) + 8 * (g >> 1);      // plane_byte of channel 32 nt + 8 g + 4 hi inside its chunk
+                *reinterpret_cast<uint2*>(d) = vh;
+                *reinterpret_cast<uint2*>(d + 64) = vl;
+            }
+        }, std::make_integer_sequence<int, NT>{});
+        constexpr int UPR = DK * 4 / 16;            // 16-byte units per row
+        char* out = reinterpret_cast<char*>(a.ctxp) + ((size_t)(s0 + q0) * a.ctxp_chunks + (size_t)h * NT) * 128;
+        const size_t row_bytes = (size_t)a.ctxp_chunks * 128;
+#pragma unroll
+        for (int i = 0; i < 32 * UPR / 64; ++i) {
+            const int U = i * 64 + lane, r = U / UPR, ps = U - r * UPR;
+            const u32x4 w = *reinterpret_cast<const u32x4*>(stage + r * RS + ps * 16);
+            if (q0 + r < len) *reinterpret_cast<u32x4*>(out + (size_t)r * row_bytes + ps * 16) = w;
         }
-    }, std::make_integer_sequence<int, NT>{});
+    } else {
+        if (qrow >= len) return;
+        const size_t row = (size_t)(s0 + qrow);
+        for_seq([&](auto n_tag) __attribute__((always_inline)) {
+            constexpr int nt = decltype(n_tag)::value;
+            float e[16];
+            read_o<nt>(e);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = h * DK + 32 * nt + 8 * g + 4 * hi;
+                f32x4 v = f32x4{e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]} * linv;
+                if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.ctx) *reinterpret_cast<f32x4*>(a.ctx + row * a.ldc + col) = v;
+                if (a.ctxp) store_planes4(a.ctxp, row, a.ctxp_chunks, col, v);
+            }
+        }, std::make_integer_sequence<int, NT>{});
+    }
+#ifdef FS2_W32_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    { const long long t_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_w32_phase[7] = t_ - tpro; }
+#endif
 }
 
 }  // namespace fs2

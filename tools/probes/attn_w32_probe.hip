@@ -108,19 +108,24 @@ int run(int B, int Lmin, int Lmax, int reps, int slack, float spike) {
         hipEventRecord(e1); CK(hipDeviceSynchronize());
         hipEventElapsedTime(&ms, e0, e1); best0 = std::min(best0, ms);
         a.ctx = ctx1;
+        if (getenv("W32_PLANES")) { a.ctx = nullptr; a.ctxp = ctx1; }      // the model's output form (context as planes only: the LDS-staged epilogue); timing only, the comparison below is then meaningless
 #ifdef FS2_W32_TIMING
-        { long long zero[8] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_w32_phase), zero, sizeof zero)); }
+        { long long zero[16] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_w32_phase), zero, sizeof zero)); }
 #endif
         hipEventRecord(e0);
         hipLaunchKernelGGL((attn_w32<DK>), dim3((unsigned)work.size(), heads), dim3(256), attn_w32_lds_bytes<DK>(), 0, a);
         hipEventRecord(e1); CK(hipDeviceSynchronize());
         hipEventElapsedTime(&ms, e0, e1); best1 = std::min(best1, ms);
+        a.ctxp = nullptr;
 #ifdef FS2_W32_TIMING
         if (rep == reps - 1) {
-            long long ph[8]; CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_w32_phase), sizeof ph));
+            long long ph[16]; CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_w32_phase), sizeof ph));
             const double n = (double)std::max(1LL, ph[4]);
             printf("  wave 0 of workgroup 0, cycles per tile over %lld tiles: phase A (Q.K^T + exponentials + DMA issue) %.0f | phase B (P.V + next head) %.0f | DMA wait %.0f | barrier %.0f\n",
                    ph[4], ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n);
+            printf("  the same wave, cycles outside the tile loop: kernel entry -> K(0) landed + barrier %lld | -> Q.K^T(0), first maximum, K(1) K(2) V(0) V(1) landed + barrier %lld | epilogue (drain, stores issued and landed) %lld\n",
+                   ph[5], ph[6], ph[7]);
+            printf("  entry in detail: work item + start/len/klen loaded %lld | DMA offsets + fragment addresses computed %lld | K(0) DMA + Q loads issued %lld | (then O = 0, wait, barrier: the rest of the first figure)\n", ph[8], ph[9], ph[10]);
         }
 #endif
     }
