@@ -142,7 +142,7 @@ __device__ __forceinline__ void mfma_o(const bf16x8_t& a_v, const bf16x8_t& b_v)
 //  measured 2-5 % slower than one statement per MFMA with the other work spread between them: profiles/r04_attn_w32_blocked_mfma_statements.txt.)
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }      // 16 states: an 8-pass MFMA result is readable
 
-// Ablations for tools/probes/attn_w32_probe.hip (timing only, results wrong): FS2_W32_ABL bit 0: no DMA pieces in the tile loop; bit 1: no
+// Ablations for tools/probes/attn_w32_probe.hip (timing only, results wrong): FS2_W32_ABL bit 6 (64): no V^T pieces; bit 7 (128): no K pieces; bit 4 (16): no closing vmcnt wait; bit 5 (32): no closing barrier; bit 0: no DMA pieces in the tile loop; bit 1: no
 // softmax work in the blocks; bit 2: no closing wait / barrier; bit 3: no fragment reads inside the blocks (the first ones are reused).
 #ifndef FS2_W32_ABL
 #define FS2_W32_ABL 0
@@ -152,7 +152,9 @@ __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7"
 // phase of the tile loop: [0] prep + phase A, [1] phase B (+ head), [2] DMA wait, [3] barrier, [4] tiles counted.
 #ifdef FS2_W32_TIMING
 __device__ long long g_w32_phase[16];
-#define FS2_WT(i) { const long long t_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_w32_phase[i] += t_ - tprev; tprev = t_; }
+// (accumulated in scalar registers and written once at the end: a read-modify-write of global memory per stamp put a memory round trip
+//  into every interval it opened)
+#define FS2_WT(i) { const long long t_ = __builtin_readcyclecounter(); wstamp[i] += t_ - tprev; tprev = t_; }
 #else
 #define FS2_WT(i)
 #endif
@@ -219,8 +221,9 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
     using I1 = std::integral_constant<int, 1>;
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef FS2_W32_TIMING
+    long long wstamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tpro = __builtin_readcyclecounter();
-#define FS2_WP(i) { const long long t_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_w32_phase[i] += t_ - tpro; tpro = t_; }
+#define FS2_WP(i) { const long long t_ = __builtin_readcyclecounter(); wstamp[i] += t_ - tpro; tpro = t_; }
 #else
 #define FS2_WP(i)
 #endif
@@ -421,11 +424,13 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
                 psum += p[R];
                 psum += p[R + 1];
                 phw[J] = pack2(p[R], p[R + 1]);
+                asm volatile("" : "+v"(phw[J]));      // (the conversion stays in this slot: with any branch further down hipcc sinks it to its first use, in front of phase B's first MFMA)
             } else if constexpr (U == 2) {
                 p[R] -= __uint_as_float(phw[J] << 16);
                 p[R + 1] -= __uint_as_float(phw[J] & 0xffff0000u);
             } else {
                 plw[J] = pack2(p[R], p[R + 1]);
+                asm volatile("" : "+v"(plw[J]));
             }
         } else if constexpr (T == 32) {
             auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(psum), __float_as_uint(psum), false, false);
@@ -473,12 +478,20 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
 
     // ---- phase A: Q.K^T of the tile in ring slot BUF -> am, ac (3 NKS MFMAs), one slot per MFMA: [fragment reads of the next k-step]
     // MFMA, this slot's share of the previous tile's softmax tail (TAIL), scheduling fence.
+    // Which K piece of the DMA goes into slot S of phase A (-1: none).  The slots whose share of the softmax tail is empty or a single
+    // conversion: with DK = 192 (36 slots, 34 steps: slot S carries step S - 1 up to slot 17, slot 18 none, then step S - 2) the pack
+    // steps 4j + 3 sit in slots 4, 8, 12, 16 and slots 0 and 18 are empty.  (Every third slot from slot 1, the first placement, put six
+    // of the twelve pieces beside a pair of exponentials: a piece holds the wave's issue port longer than an MFMA runs.)
+    auto k_dma_slot = [](int S) constexpr -> int {
+        if constexpr (DK == 192) return S == 0 ? 0 : S == 18 ? 5 : (S % 4 == 0 && S <= 16) ? S / 4 : -1;
+        else return (S % 3 == 0 && S / 3 < PW) ? S / 3 : -1;
+    };
     unsigned koff[PW];               // K source offsets of the tile to fetch (kgo, or clamped rows for a partial tile)
     gchar_t* vptr[PW];               // V^T source pointers of the tile to fetch (zero vector for 8-key groups beyond klen)
     // ---- phase A: Q.K^T of the tile in ring slot BUF -> am, ac (3 NKS MFMAs), one slot per MFMA: [fragment reads two k-steps ahead]
-    // MFMA, one LDS-DMA piece of the tiles to fetch every third slot (K pieces first), this slot's share of the previous tile's softmax
+    // MFMA, in the slots k_dma_slot names one LDS-DMA piece of the K tile to fetch, this slot's share of the previous tile's softmax
     // tail (TAIL), scheduling fence.
-    auto phase_a = [&](auto buf_tag, auto tail_tag, gchar_t* kbase_t, unsigned kdst, unsigned vdst) __attribute__((always_inline)) {
+    auto phase_a = [&](auto buf_tag, auto tail_tag, gchar_t* kbase_t, unsigned kdst) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr bool TAIL = decltype(tail_tag)::value != 0, DMA = TAIL;      // (the loop's phase A carries the tail and the DMA; the prologue's neither)
         constexpr int NSLOT = 3 * NKS;
@@ -500,10 +513,9 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
             else mfma_s<0>(ac, kh[BB], ql[C], negm);
             // DMA pieces of the tiles to fetch, one every third slot from the start of the phase (both ring slots they fill were released
             // by the barrier that opened this iteration)
-            if constexpr (DMA && S % 3 == 1 && S / 3 < 2 * PW && !(FS2_W32_ABL & 1)) {
-                constexpr int Q = S / 3;
-                if constexpr (Q < PW) dma16_so(kbase_t, koff[Q], kdst + Q * 4096);
-                else dma16((const void*)vptr[Q - PW], vdst + (Q - PW) * 4096);
+            if constexpr (DMA && !(FS2_W32_ABL & (1 | 128))) {
+                constexpr int Q = k_dma_slot(S);
+                if constexpr (Q >= 0) dma16_so(kbase_t, koff[Q], kdst + Q * 4096);
             }
             if constexpr (TAIL && !(FS2_W32_ABL & 2))
                 steps_of_slot(s_tag, std::integral_constant<int, NSLOT>{}, std::integral_constant<int, kTailSteps>{}, tail_step);
@@ -513,9 +525,9 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
     // ---- phase B: O^T += V^T(tile in ring slot BUF) . P^T (6 NT MFMAs in groups of six: two n-tiles, i.e. two accumulators alternate
     // between dependent MFMAs), one slot per MFMA: [V^T fragment reads two groups ahead] MFMA, this slot's share of the next tile's
     // score sums (HEAD: from slot 6 on, i.e. six MFMAs behind the chains of phase A), scheduling fence.
-    auto phase_b = [&](auto buf_tag, auto head_tag) __attribute__((always_inline)) {
+    auto phase_b = [&](auto buf_tag, auto head_tag, auto dma_tag, unsigned vdst) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value;
-        constexpr bool HEAD = decltype(head_tag)::value != 0;
+        constexpr bool HEAD = decltype(head_tag)::value != 0, DMA = decltype(dma_tag)::value != 0;
         constexpr int GPM = NT / 2;                // groups per 16-key half
         constexpr int NG = 2 * GPM, NSLOT = 6 * NG;
         constexpr int kFB = 2;                     // groups ahead of their MFMAs
@@ -540,6 +552,8 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
             else if constexpr (U == 3) mfma_o<N0 + 1, false>(vh[BB][1], pf_l);
             else if constexpr (U == 4) mfma_o<N0, false>(vh[BB][0], pf_h);
             else mfma_o<N0 + 1, false>(vh[BB][1], pf_h);
+            // the V^T pieces of the DMA: odd slots from the start of the phase (the head's steps start at slot 6 and are two adds each)
+            if constexpr (DMA && (S & 1) && S / 2 < PW && !(FS2_W32_ABL & (1 | 64))) dma16((const void*)vptr[S / 2], vdst + (S / 2) * 4096);
             if constexpr (HEAD && S >= 6 && !(FS2_W32_ABL & 2)) {       // (the adds of head_step are volatile asm: they stay behind the six MFMAs of the slots before)
                 steps_of_slot(std::integral_constant<int, S - 6>{}, std::integral_constant<int, NSLOT - 6>{}, std::integral_constant<int, kHeadSteps>{},
                               [&](auto t_tag) __attribute__((always_inline)) { head_step(t_tag, I0{}, 0); });
@@ -595,7 +609,7 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
         const int dk = min(kt + 3, ntiles - 1), dv = min(kt + 2, ntiles - 1);
 #ifdef FS2_W32_TIMING
         long long tprev = __builtin_readcyclecounter();
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_w32_phase[4] += 1;
+        wstamp[4] += 1;
 #endif
         if (wave_live && !bail) {
             if (has_next) {
@@ -607,21 +621,22 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
                 // block: a branch between them lets hipcc sink the bf16 conversions of the softmax tail out of their slots into phase B's
                 // head (40 instructions nothing covers).
                 if ((kt + 1) * 32 + 32 <= klen) {
-                    phase_a(IK{}, I1{}, kb, kdst, vdst);
+                    phase_a(IK{}, I1{}, kb, kdst);
                     FS2_WT(0)
-                    phase_b(IV{}, I1{});
+                    phase_b(IV{}, I1{}, I1{}, vdst);
                 } else {            // the next tile is the utterance's last and partial: its head needs the key mask
-                    phase_a(IK{}, I1{}, kb, kdst, vdst);
+                    phase_a(IK{}, I1{}, kb, kdst);
                     FS2_WT(0)
-                    phase_b(IV{}, I0{});
+                    phase_b(IV{}, I0{}, I1{}, vdst);
                     for_seq([&](auto t_tag) __attribute__((always_inline)) { head_step(t_tag, I1{}, (kt + 1) * 32); }, std::make_integer_sequence<int, kHeadSteps>{});
                 }
             } else {
                 for_seq(tail_step, std::make_integer_sequence<int, kTailSteps>{});
-                phase_b(IV{}, I0{});
+                phase_b(IV{}, I0{}, I0{}, 0u);
             }
             // (lazily, after the tile went into O: a wave that leaves recomputes its rows from scratch, so what it accumulated does not matter)
             bail = __builtin_amdgcn_readfirstlane(__any(!(psum_row < kW32SumLimit)));
+            if (FS2_W32_ABL & 250) bail = 0;        // (ablations that leave the sums undefined must stay on the fast path to time it)
         } else if (has_next) {
             issue_K(dk, KD);
             issue_V(dv, VD);
@@ -629,13 +644,14 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
         FS2_WT(1)
         if (has_next && !(FS2_W32_ABL & 4)) {
             // this wave's pieces of K(kt + 2) and V^T(kt + 1) -- issued one iteration ago -- have landed: only this iteration's 2 PW are in flight
-            if constexpr (2 * PW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            if constexpr (FS2_W32_ABL & 16) {}
+            else if constexpr (2 * PW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else if constexpr (2 * PW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (2 * PW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             FS2_WT(2)
             if (kt + 2 == ntiles) fix_V(kt + 1, (R + 1) % 3);      // the next tile is the last: mask its straddling key vectors (own pieces)
-            __syncthreads();
+            if constexpr (!(FS2_W32_ABL & 32)) __syncthreads();
             FS2_WT(3)
         }
     };
@@ -649,7 +665,7 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
         issue_V(0, 0);
         issue_V(min(1, ntiles - 1), 1);
         if (wave_live) {
-            phase_a(I0{}, I0{}, kbase, 0u, 0u);
+            phase_a(I0{}, I0{}, kbase, 0u);
             mfma_drain();
             if (32 <= klen) for_seq([&](auto t_tag) __attribute__((always_inline)) { head_step(t_tag, I0{}, 0); }, std::make_integer_sequence<int, kHeadSteps>{});
             else for_seq([&](auto t_tag) __attribute__((always_inline)) { head_step(t_tag, I1{}, 0); }, std::make_integer_sequence<int, kHeadSteps>{});
@@ -738,7 +754,12 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
     }
 #ifdef FS2_W32_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    { const long long t_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_w32_phase[7] = t_ - tpro; }
+    {
+        const long long t_ = __builtin_readcyclecounter();
+        wstamp[7] = t_ - tpro;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+            for (int i = 0; i < 12; ++i) g_w32_phase[i] += wstamp[i];
+    }
 #endif
 }
 

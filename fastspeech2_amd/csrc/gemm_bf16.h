@@ -97,6 +97,12 @@ __device__ __host__ __forceinline__ int kperm(int p) { const int slot = p >> 3, 
 // [D][Rvt], 8 consecutive keys of one channel per 16-byte store (key index contiguous: what the P.V MFMA wants as B operand).
 // Rows that are gaps or beyond R are written as zeros (P = 0 times a non-finite V would poison the P.V sum).
 constexpr int kQkvLd = kB16BN + 4;      // fp32 tile row stride in LDS (floats)
+// Column swizzle of the fp32 tile the V^T planes are transposed through: the transposing read has the four lanes of a column
+// 8 rows apart, and 8 rows of 132 floats are a multiple of 32 banks -- without the term those four lanes meet in one bank (15 %
+// of gemm_qkv8_bf16's LDS cycles were conflicts).  XOR-ing the column with 8 ((row >> 3) & 3) sends the four 8-row groups to
+// four different 8-column bank groups; a multiple of 8, so the 16-byte writes stay aligned and whole.
+__device__ __forceinline__ int qkv_tile_swz(int row) { return ((row >> 3) & 3) << 3; }
+
 template <int BM>
 __device__ __forceinline__ void vt_tile_store(const GemmArgs& a, const float* tile, int m0, int n0, int tid) {
     const int* __restrict__ rpos = a.row_pos;
@@ -116,7 +122,7 @@ __device__ __forceinline__ void vt_tile_store(const GemmArgs& a, const float* ti
         for (int e = 0; e < 8; ++e) {
             const int rr = row + e;
             const bool ok = rr < a.R && (rpos == nullptr || rpos[rr] >= 0);
-            v[e] = ok ? tile[(8 * j + e) * kQkvLd + c] : 0.f;
+            v[e] = ok ? tile[(8 * j + e) * kQkvLd + (c ^ qkv_tile_swz(8 * j))] : 0.f;
         }
         const SplitPair sp = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
         const size_t off = (size_t)(n0 - 2 * D + c) * a.Rvt + row;

@@ -317,8 +317,11 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    *reinterpret_cast<f32x4*>(tile + (wm * (BM / 2) + mt * 16 + rperm(lg * 4 + r)) * kQkvLd + wn * 64 + 4 * lr) =
+                {
+                    const int trow = wm * (BM / 2) + mt * 16 + rperm(lg * 4 + r);
+                    *reinterpret_cast<f32x4*>(tile + trow * kQkvLd + ((wn * 64 + 4 * lr) ^ qkv_tile_swz(trow))) =
                         f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+                }
             __syncthreads();
             vt_tile_store<BM>(a, tile, m0, n0, tid);
             return;
@@ -992,7 +995,8 @@ __global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const f32x4 v = f32x4{acc[mt][4 * g][r], acc[mt][4 * g + 1][r], acc[mt][4 * g + 2][r], acc[mt][4 * g + 3][r]};
-                            *reinterpret_cast<f32x4*>(tile + (wm * RW + mt * 16 + rp[r]) * kQkvLd + (G & 1) * 64 + 4 * lr) =
+                            const int trow = wm * RW + mt * 16 + rp[r];
+                            *reinterpret_cast<f32x4*>(tile + trow * kQkvLd + (((G & 1) * 64 + 4 * lr) ^ qkv_tile_swz(trow))) =
                                 ((vmask >> (mt * 4 + r)) & 1u) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
                         }
                 }
@@ -1004,7 +1008,7 @@ __global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
                     const int c = (idx >> 2) & 127, j = ((idx >> 9) << 2) | (idx & 3);
                     const int row = m0 + 8 * j;
                     if (row >= a.Rvt) continue;
-                    const float* t = tile + (8 * j) * kQkvLd + c;
+                    const float* t = tile + (8 * j) * kQkvLd + (c ^ qkv_tile_swz(8 * j));      // (rows 8j .. 8j + 7 share one swizzle term)
                     const SplitPair sp = split8(make_float4(t[0], t[kQkvLd], t[2 * kQkvLd], t[3 * kQkvLd]),
                                                 make_float4(t[4 * kQkvLd], t[5 * kQkvLd], t[6 * kQkvLd], t[7 * kQkvLd]));
                     const size_t off = (size_t)(pass * 128 + c) * a.Rvt + row;

@@ -210,9 +210,97 @@ __global__ __launch_bounds__(256, 1) void mfma_chain(long long* out, const float
     for (int k = 0; k < NACC; ++k) for (int r = 0; r < 16; ++r) s_ += acc[k][r];
     if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = (long long)s_; }
 }
+// The same stream from every SIMD of the chip for long enough to reach the sustained clock: what a kernel of nothing but MFMAs gets.
+template <int NACC>
+__global__ __launch_bounds__(256, 1) void mfma_chip(long long* out, const float* seed, int iters, int random_data) {
+    bf16x8_t a = __builtin_bit_cast(bf16x8_t, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}), b = a;
+    if (random_data) {      // bf16 values of random sign and mantissa, exponents within +-2 of 1.0 (the accumulators stay finite: the products average out)
+        unsigned x = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u + 12345u), w[8];
+        for (int i = 0; i < 8; ++i) {
+            x = x * 1664525u + 1013904223u; const unsigned lo = (x >> 8) & 0x81ffu; x = x * 1664525u + 1013904223u; const unsigned hi2 = (x >> 8) & 0x81ffu;
+            w[i] = (0x3e80u | lo) | ((0x3e80u | hi2) << 16);
+        }
+        a = __builtin_bit_cast(bf16x8_t, u32x4{w[0], w[1], w[2], w[3]}); b = __builtin_bit_cast(bf16x8_t, u32x4{w[4], w[5], w[6], w[7]});
+    }
+    f32x16 acc[NACC];
+    for (int k = 0; k < NACC; ++k) for (int r = 0; r < 16; ++r) acc[k][r] = seed[threadIdx.x & 15];
+    long long tsum = 0;
+    for (int it = 0; it < iters; ++it) {
+        __builtin_amdgcn_sched_barrier(0);
+        const long long t0 = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 96; ++i) acc[i % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i % NACC], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it >= iters / 2) tsum += __builtin_readcyclecounter() - t0;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s_ = 0.f;
+    for (int k = 0; k < NACC; ++k) for (int r = 0; r < 16; ++r) s_ += acc[k][r];
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = tsum; out[1] = (long long)s_; }
+}
+// The two MFMA streams of attn_w32's tile, bare (the kernel's own asm forms, nothing between them), from every SIMD of the chip:
+// FORM 0 = phase A (accumulators in VGPRs, B operand in AGPRs, order ac am ac | ac am ac ...), FORM 1 = phase B (accumulators in literal
+// AGPRs a[0:95], both operands VGPRs, two accumulators alternating), FORM 2 = phase A's order with all operands in VGPRs.
+template <int FORM>
+__global__ __launch_bounds__(256, 1) void mfma_form(long long* out, const float* seed, int iters) {
+    bf16x8_t a = __builtin_bit_cast(bf16x8_t, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}), b = a, qa = a;
+    f32x16 ac, am, z;
+    for (int r = 0; r < 16; ++r) { ac[r] = seed[threadIdx.x & 15]; am[r] = ac[r]; z[r] = 0.f; }
+    asm volatile("" : "+a"(qa));
+    asm volatile("" : "+v"(a), "+v"(b));
+    if (FORM == 1) fs2::for_seq([&](auto n_tag) __attribute__((always_inline)) { fs2::mfma_o0<decltype(n_tag)::value>(a); }, std::make_integer_sequence<int, 6>{});
+    long long tsum = 0;
+    for (int it = 0; it < iters; ++it) {
+        __builtin_amdgcn_sched_barrier(0);
+        const long long t0 = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+        fs2::for_seq([&](auto s_tag) __attribute__((always_inline)) {
+            constexpr int S = decltype(s_tag)::value;
+            if constexpr (FORM == 0) {
+                if constexpr (S % 3 == 1) fs2::mfma_s<0>(am, a, qa, z); else fs2::mfma_s<0>(ac, b, qa, z);
+            } else if constexpr (FORM == 2) {
+                if constexpr (S % 3 == 1) am = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, am, 0, 0, 0); else ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, ac, 0, 0, 0);
+            } else {
+                constexpr int G = S / 6, U = S % 6, N0 = (G % 3) * 2;
+                if constexpr (U & 1) fs2::mfma_o<N0 + 1, false>(a, b); else fs2::mfma_o<N0, false>(a, b);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }, std::make_integer_sequence<int, 36>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (it >= iters / 2) tsum += __builtin_readcyclecounter() - t0;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s_ = 0.f;
+    for (int r = 0; r < 16; ++r) s_ += ac[r] + am[r];
+    if (FORM == 1) { fs2::mfma_drain(); float e[16]; fs2::read_o<0>(e); s_ += e[0]; }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = tsum; out[1] = (long long)s_; }
+}
 static int mfma_bench() {
     long long* d; float* sd; CK(hipMalloc(&d, 16)); CK(hipMalloc(&sd, 64)); CK(hipMemset(sd, 0, 64));
     long long h[2];
+    {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const int grids[4] = {256, 2048, 2048, 2048}, iters[4] = {2000, 2000, 250, 2000};
+        for (int g = 0; g < 4; ++g) {
+            float best = 1e30f;
+            if (g == 3) printf("(next: operands of random sign / mantissa instead of all ones)\n");
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(e0); hipLaunchKernelGGL((mfma_chip<2>), dim3(grids[g]), dim3(256), 0, 0, d, sd, iters[g], g == 3 ? 1 : 0); hipEventRecord(e1);
+                CK(hipDeviceSynchronize()); float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
+            }
+            CK(hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
+            const double fl = (double)grids[g] * 4 * iters[g] * 96 * 32768.0;
+            printf("whole chip, %d workgroups x 4 waves x %d x 96 MFMAs (2 accumulators): %.3f ms = %.0f TFLOP/s dense bf16; s_memtime cycles per MFMA in wave 0 (second half) %.1f\n",
+                   grids[g], iters[g], best, fl / best * 1e-9, h[0] / (96.0 * (iters[g] - iters[g] / 2)));
+        }
+    }
+    {
+        #define FORM(F, what) { hipLaunchKernelGGL((mfma_form<F>), dim3(2048), dim3(256), 0, 0, d, sd, 1000); CK(hipDeviceSynchronize()); CK(hipMemcpy(h, d, 16, hipMemcpyDeviceToHost)); \
+            printf("whole chip, attn_w32's %s stream bare: %.1f s_memtime cycles per MFMA\n", what, h[0] / (36.0 * 500)); }
+        FORM(0, "phase A (acc VGPR, B operand AGPR; ac am ac)") FORM(2, "phase A order, all VGPR (builtin)") FORM(1, "phase B (acc literal AGPR, two alternating)")
+        #undef FORM
+    }
     #define RUN(N) hipLaunchKernelGGL((mfma_chain<N>), dim3(1), dim3(256), 0, 0, d, sd); CK(hipDeviceSynchronize()); hipLaunchKernelGGL((mfma_chain<N>), dim3(1), dim3(256), 0, 0, d, sd); CK(hipDeviceSynchronize()); \
         CK(hipMemcpy(h, d, 16, hipMemcpyDeviceToHost)); printf("v_mfma_f32_32x32x16_bf16, 96 in a row over %d accumulator(s): %.1f cycles per MFMA\n", N, h[0] / 96.0);
     RUN(1) RUN(2) RUN(3) RUN(4)
