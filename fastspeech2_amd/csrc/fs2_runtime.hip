@@ -88,6 +88,7 @@ struct Options {
     int f32_rows = 0;    // FS2_F32_ROWS row-complete fp32 GEMM for LayerNorm-terminated ops
     int fuse_var = 1;    // FS2_FUSE_VAR the pitch and the energy predictor as one launch per layer (0: separate launches)
     int mt8 = -1;        // FS2_MT8      m-tiles per wave of the 8-wave row-complete kernels (2 | 3: 128 / 192-row workgroups)
+    int qkv_split = -1;  // FS2_QKV_SPLIT  the Q, K and V passes of gemm_qkv8_bf16 as three workgroups per row tile (-1: by the round count)
     int w32 = -1;        // FS2_ATTN_W32 split-bf16 attention with 32 queries per wave (attn_w32.h): 0 never, 1 whenever the head dim allows, -1 by regime
 };
 int env_int(const char* name, int dflt) {
@@ -98,7 +99,7 @@ Options& opts() {
     static Options o = [] {
         Options x;
         x.bm = env_int("FS2_BM", -1); x.row8 = env_int("FS2_ROW8", -1); x.qkv8 = env_int("FS2_QKV8", -1);
-        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 0); x.w32 = env_int("FS2_ATTN_W32", -1);
+        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.qkv_split = env_int("FS2_QKV_SPLIT", -1); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 0); x.w32 = env_int("FS2_ATTN_W32", -1);
         return x;
     }();
     return o;
@@ -326,19 +327,36 @@ hipError_t launch_row8c(hipStream_t s, const GemmArgs& a) {
     return launch_row8c_t<NSPLIT, NB, 2>(s, a);
 }
 
-template <int NSPLIT, int NB, int MT>
+template <int NSPLIT, int NB, int MT, bool APART>
 hipError_t launch_qkv8_t(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
     constexpr size_t lds = qkv8_lds_bytes<NB, MT>();
-    allow_lds(reinterpret_cast<const void*>(&gemm_qkv8_bf16<NSPLIT, NB, MT>), lds, attr);
-    hipLaunchKernelGGL((gemm_qkv8_bf16<NSPLIT, NB, MT>), dim3((a.Rvt + 64 * MT - 1) / (64 * MT)), dim3(512), lds, s, a);
+    allow_lds(reinterpret_cast<const void*>(&gemm_qkv8_bf16<NSPLIT, NB, MT, APART>), lds, attr);
+    hipLaunchKernelGGL((gemm_qkv8_bf16<NSPLIT, NB, MT, APART>), dim3((a.Rvt + 64 * MT - 1) / (64 * MT), APART ? 3 : 1), dim3(512), lds, s, a);
     return hipGetLastError();
+}
+// The Q, K and V passes of a row tile are independent (each re-streams the A tile): as three workgroups per tile (grid.y = 3) the
+// unit of work is a third of a tile and the last, partly filled round of a launch costs a third.  Rounds in units of a 128-row
+// tile's three passes, a 192-row tile at 1.7 (row8_mt): c3, 286 tiles of 128 rows: whole tiles 2.0 (128) / 1.7 (192, one round
+// on 191 of 256 CUs: what ran until round 4), passes apart 4/3 (128) / 1.7 (192).  Never more rounds than whole tiles of the
+// same height.  Results do not depend on either choice.
+inline void qkv8_plan(long rows, int& mt, int& apart) {
+    double best = 1e30;
+    for (int m = 2; m <= 3; ++m)
+        for (int ap = 0; ap <= 1; ++ap) {
+            if (opts().mt8 > 0 && m != std::min(std::max(opts().mt8, 2), 3)) continue;
+            if (opts().qkv_split >= 0 && ap != (opts().qkv_split != 0)) continue;
+            const long tiles = (rows + 64 * m - 1) / (64 * m), units = ap ? 3 * tiles : tiles;
+            const double cost = (double)((units + kCus - 1) / kCus) / (ap ? 3.0 : 1.0) * (m == 3 ? 1.7 : 1.0);
+            if (cost < best - 1e-9) { best = cost; mt = m; apart = ap; }
+        }
 }
 template <int NSPLIT, int NB>
 hipError_t launch_qkv8(hipStream_t s, const GemmArgs& a) {
-    const int mt = opts().mt8 > 0 ? opts().mt8 : row8_mt(rows_in_use(a, a.Rvt));
-    if (mt >= 3) return launch_qkv8_t<NSPLIT, NB, 3>(s, a);
-    return launch_qkv8_t<NSPLIT, NB, 2>(s, a);
+    int mt = 2, apart = 0;
+    qkv8_plan(rows_in_use(a, a.Rvt), mt, apart);
+    if (mt >= 3) return apart ? launch_qkv8_t<NSPLIT, NB, 3, true>(s, a) : launch_qkv8_t<NSPLIT, NB, 3, false>(s, a);
+    return apart ? launch_qkv8_t<NSPLIT, NB, 2, true>(s, a) : launch_qkv8_t<NSPLIT, NB, 2, false>(s, a);
 }
 
 // Fused QKV projection on the 8-wave structure when there is about a CU's worth of 128-row tiles (FS2_QKV8=0|1 forces the choice)
@@ -2007,6 +2025,7 @@ int fs2_set_option(const char* name, int32_t value) {
     else if (n == "FS2_NOSPLITK") o.nosplitk = value > 0;
     else if (n == "FS2_F32_ROWS") o.f32_rows = value > 0;
     else if (n == "FS2_MT8") o.mt8 = value;
+    else if (n == "FS2_QKV_SPLIT") o.qkv_split = value;
     else if (n == "FS2_FUSE_VAR") o.fuse_var = value != 0;
     else if (n == "FS2_BAL") o.bal = value < 0 ? 0 : value;
     else if (n == "FS2_ATTN_W32") o.w32 = value;

@@ -868,7 +868,7 @@ template <int NB, int MT = 2> constexpr size_t qkv8_lds_bytes() {      // operan
     return row8_lds_bytes<NB, MT>() > (size_t)64 * MT * kQkvLd * 4 ? row8_lds_bytes<NB, MT>() : (size_t)64 * MT * kQkvLd * 4;
 }
 
-template <int NSPLIT, int NB, int MT = 2>
+template <int NSPLIT, int NB, int MT = 2, bool APART = false>
 __global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
     constexpr int NT = 4 * NB, BM = 64 * MT, BN = 128 * NB, RW = 16 * MT;
     constexpr int STAGE = (BM + BN) * 128;
@@ -931,8 +931,11 @@ __global__ __launch_bounds__(512, 1) void gemm_qkv8_bf16(GemmArgs a) {
         }
     __bf16* qkh = reinterpret_cast<__bf16*>(a.qk_hi);
     __bf16* qkl = reinterpret_cast<__bf16*>(a.qk_lo);
-    const __bf16* b_src_blk = b_src0;
-    for (int nb = 0; nb < 3; ++nb, b_src_blk += (size_t)BN * niter * 64) {
+    // APART: this workgroup makes one pass (blockIdx.y) only -- a third of a tile as the unit of work (fs2_runtime.hip: qkv8_plan).
+    // (A template parameter: with run-time loop bounds the whole-tile form ran 24 % slower.)
+    const __bf16* b_src_blk = b_src0 + (APART ? (size_t)blockIdx.y * BN * niter * 64 : (size_t)0);
+    for (int nbi = 0; nbi < (APART ? 1 : 3); ++nbi, b_src_blk += (size_t)BN * niter * 64) {
+        const int nb = APART ? (int)blockIdx.y : nbi;
         __syncthreads();                 // every wave is done with the previous pass's operand buffers / LDS tile
         b_src0 = b_src_blk;
         dma_stage(0, 0);

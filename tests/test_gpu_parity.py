@@ -186,7 +186,8 @@ def test_c2_row_complete_kernel_choice(env, row8, fs2_option):
 
 def test_c2_row_complete_tile_heights_are_bit_identical(env, fs2_option):
     """The 8-wave row-complete kernels (LayerNorm-fused k = 1 GEMMs, fused QKV, predictor convolutions) take 128 or 192 rows per
-    workgroup, whichever avoids a nearly empty last round: the choice must not change a single bit."""
+    workgroup, and the fused QKV projection runs its three passes in one workgroup or in three (FS2_QKV_SPLIT), whichever avoids a
+    nearly empty last round: the choices must not change a single bit."""
     model = env[0]
     from fastspeech2_amd.synthetic import make_batch
     b = make_batch("c2")
@@ -195,11 +196,12 @@ def test_c2_row_complete_tile_heights_are_bit_identical(env, fs2_option):
     model.precision = "bf16x3"
     try:
         outs = []
-        for mt in (2, 3):
+        for mt, split in ((2, 0), (3, 0), (2, 1), (3, 1)):
             fs2_option("FS2_MT8", mt)
+            fs2_option("FS2_QKV_SPLIT", split)
             with torch.no_grad():
                 outs.append(model.inference_batch(b["xs"].cuda(), b["ilens"], d_override=b["ds"].cuda())[0])
-        assert torch.equal(outs[0], outs[1])
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
     finally:
         model.precision = "fp32"
 
