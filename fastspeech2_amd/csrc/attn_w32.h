@@ -691,7 +691,14 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
     tpro = __builtin_readcyclecounter();
 #endif
     const bool staged = a.ctxp != nullptr && a.ctx == nullptr;      // the model's form: the context leaves as planes only
-    if (staged) __syncthreads();               // every wave is done with the rings: their memory stages the output tiles
+    if (staged) {
+        // every wave is done with the rings, whose memory stages the output tiles -- AND every DMA piece has landed: the pieces issued in
+        // the last iteration but one (the last tile fetched once more, so that every iteration issues the same number) are waited for
+        // by nobody, and one that lands after the rows below were staged overwrites them (seen as ~17 corrupted frames in one
+        // utterance of c4, a different one from run to run).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     if (!wave_live) return;
     if (bail) {
         attn_w32_rows_slow<DK>(a, s0, len, klen, q0, h, lane);

@@ -494,7 +494,8 @@ def test_errors(env):
                        torch.ones(1, 4, dtype=torch.int64), torch.ones(1, 4), torch.ones(1, 4))
 
 
-_C4_ORACLE = {}      # utterance index -> oracle (mel, energy codes, pitch codes): computed once, shared by the three arithmetic modes
+_C4_ORACLE = {}      # utterance index -> oracle (mel, energy codes, pitch codes, predictor outputs): computed once, shared by the three arithmetic modes
+EDGE_TOL = 5e-5      # a free-running bucket decision may differ from the oracle's only where the oracle's predictor output is this close to a bin edge
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "mix_mx"])
@@ -509,7 +510,12 @@ def test_full_size_c4_length_regulator_stress(env, precision):
     model.precision = precision
     try:
         with torch.no_grad():
-            r = model._run(b["xs"].cuda(), b["ilens"], is_inference=True, d_override=b["ds"].cuda(), want=("after", "lr_index"))
+            r = model._run(b["xs"].cuda(), b["ilens"], is_inference=True, d_override=b["ds"].cuda(), want=("after", "lr_index", "qe", "qp"))
+            # the same launch sequence again, three times: bit-identical (a data race in a kernel shows up here as a handful of frames that
+            # differ from run to run -- attn_w32's staged epilogue had one, ~17 frames of one utterance per few runs at this size)
+            for _ in range(3):
+                r2 = model._run(b["xs"].cuda(), b["ilens"], is_inference=True, d_override=b["ds"].cuda(), want=("after",))
+                assert torch.equal(r2["after"], r["after"])
     finally:
         model.precision = "fp32"
     assert torch.equal(r["olens"], b["olens"])
@@ -525,22 +531,31 @@ def test_full_size_c4_length_regulator_stress(env, precision):
         assert (lri[i, L:] == -1).all()
     order = torch.argsort(b["olens"]).tolist()
     pick = list(range(after.shape[0]))
-    after_h = after.cpu()
+    after_h, qe_h, qp_h = after.cpu(), r["qe"].cpu().long(), r["qp"].cpu().long()
     worst, flipped_utts, flipped_frames = 0.0, [], 0
     for i in pick:
         T, L = int(b["ilens"][i]), int(b["olens"][i])
         if i not in _C4_ORACLE:
             o = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], b["ilens"][i:i + 1], is_inference=True, d_override=b["ds"][i:i + 1, :T])
-            _C4_ORACLE[i] = (o["after"][0], o["qe"][0, :L].long(), o["qp"][0, :L].long())
-        o_after, o_qe, o_qp = _C4_ORACLE[i]
+            _C4_ORACLE[i] = (o["after"][0], o["qe"][0, :L].long(), o["qp"][0, :L].long(), o["e_outs"][0, :L].float(), o["p_outs"][0, :L].float())
+        o_after, o_qe, o_qp, o_e, o_p = _C4_ORACLE[i]
         d = _maxabs(after_h[i, :L], o_after)
         if d > MEL_TOL:
             # The pass is free-running in pitch and energy: ~1 M bucket decisions per mode, each a predictor output within ~1e-5 of the
             # CPU's, so a few land on the other side of a bin edge in the reduced-precision modes (SURVEY.md hard part 2; fp32 has none).
-            # Such an utterance must (a) differ from the oracle in a handful of bucket indices and nowhere else in kind, and (b) match the
-            # oracle within the tolerance once pitch and energy are teacher-forced (the arithmetic, without the decision).
-            flips = int((qe_h[i, :L] != o_qe).sum() + (qp_h[i, :L] != o_qp).sum())
-            assert precision != "fp32" and 0 < flips <= max(3, L // 500), (i, L, d, flips)
+            # Such an utterance must (a) differ from the oracle only in bucket indices that moved to the NEIGHBOURING bucket at frames where
+            # the oracle's own predictor output lies within EDGE_TOL (5 x the 1e-5 predictor error of these modes) of the edge between
+            # the two, and (b) match the oracle within the tolerance once pitch and energy are teacher-forced (the arithmetic, without
+            # the decision).
+            flips = 0
+            for q_dev, q_orc, x_orc, bins in ((qe_h[i, :L], o_qe, o_e, sd["energy_predictor.energy_bins"]), (qp_h[i, :L], o_qp, o_p, sd["pitch_predictor.pitch_bins"])):
+                t = torch.nonzero(q_dev != q_orc).flatten()
+                if len(t):
+                    assert ((q_dev[t] - q_orc[t]).abs() == 1).all(), (i, "a bucket index moved by more than one")
+                    edge = bins.float()[torch.minimum(q_dev[t], q_orc[t])]
+                    assert float((x_orc[t] - edge).abs().max()) <= EDGE_TOL, (i, L, float((x_orc[t] - edge).abs().max()))
+                    flips += len(t)
+            assert precision != "fp32" and flips > 0, (i, L, d, flips)
             sub = {k: b[k][i:i + 1] for k in ("xs", "ilens", "ds", "olens", "es", "ps")}
             sub["xs"], sub["ds"], sub["es"], sub["ps"] = sub["xs"][:, :T], sub["ds"][:, :T], sub["es"][:, :L], sub["ps"][:, :L]
             model.precision = precision
