@@ -378,10 +378,11 @@ __global__ void unpack_rows4(const float* src, int W4, const int* start, const i
     reinterpret_cast<float4*>(dst)[i] = v;
 }
 
-// gapped packed rows -> dense packed rows (valid frames only, utterances back to back): dst row cum[b] + j
-// (ovf as in unpack_rows4; dst then holds R rows: the row capacity)
+// gapped packed rows -> dense packed rows (valid frames only, utterances back to back): dst row cum_scale cum[b] + j
+// (ovf as in unpack_rows4; dst then holds R rows: the row capacity).  cum_scale: the reduction factor when the rows are mel frames
+// (r per decoder frame) and cum[] counts decoder frames.
 __global__ void pack_rows(const float* src, int W, const int* row_pos, const int* row_seq, const int* vlen, const int* cum, int R,
-                          float* dst, const int* ovf = nullptr) {
+                          float* dst, const int* ovf = nullptr, int cum_scale = 1) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int w4 = W / 4;
     if (i >= (int64_t)R * w4) return;
@@ -391,7 +392,7 @@ __global__ void pack_rows(const float* src, int W, const int* row_pos, const int
     if (b < 0) return;
     const int j = row_pos[row];
     if (j >= vlen[b]) return;
-    *reinterpret_cast<float4*>(dst + (size_t)(cum[b] + j) * W + c) = *reinterpret_cast<const float4*>(src + (size_t)row * W + c);
+    *reinterpret_cast<float4*>(dst + ((size_t)cum[b] * cum_scale + j) * W + c) = *reinterpret_cast<const float4*>(src + (size_t)row * W + c);
 }
 
 // device-driven layout: when the overflow flags (dims[2]) are set the outputs of the call are invalid -> fill them with NaN

@@ -1737,7 +1737,6 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     const int R2 = R * rf;
     DevLayout dl2 = dl;
     if (rf > 1) {
-        if (io->after_packed) return fail(h, FS2_ERR_UNSUPPORTED, "after_packed with reduction_factor > 1");
         int* m = f.meta2;
         dl2.start = m; dl2.len = m + b.B; dl2.vlen = m + 2 * b.B; dl2.klen = dl2.len;
         int* rest = reinterpret_cast<int*>(align_up(reinterpret_cast<size_t>(m + 3 * b.B), 16));
@@ -1810,16 +1809,17 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
                 HIP_TRY(h, hipMemcpyAsync(up, cum.data(), cum.size() * sizeof(int), hipMemcpyHostToDevice, s));
                 dcum = up;
             }
-            const int64_t n = (int64_t)R * (c.odim / 4);
-            hipLaunchKernelGGL(pack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mel_after, c.odim, dl.row_pos, dl.row_seq, dl.vlen, dcum, R, io->after_packed,
-                               (devlay && R == io->row_capacity) ? ovf : (const int*)nullptr);
+            // (r > 1: the rows are mel frames -- the Postnet's layout dl2, r rows per decoder row -- and the offsets r times the decoder-frame sums)
+            const int64_t n = (int64_t)R2 * (c.odim / 4);
+            hipLaunchKernelGGL(pack_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mel_after, c.odim, dl2.row_pos, dl2.row_seq, dl2.vlen, dcum, R2, io->after_packed,
+                               (devlay && R == io->row_capacity) ? ovf : (const int*)nullptr, rf);
             HIP_TRY(h, hipGetLastError());
             packed_done = devlay && R == io->row_capacity;
         }
         const bool need_poison = devlay && ((io->after && !after_done) || (io->before && !before_done) || (io->after_packed && !packed_done));
         if (need_poison) {
             hipLaunchKernelGGL(poison_on_overflow, dim3(256), dim3(256), 0, s, dl.dims, io->after, (io->after && !after_done) ? (int64_t)b.B * io->Lmax * rf * c.odim : (int64_t)0,
-                               io->after_packed, (io->after_packed && !packed_done) ? io->row_capacity * c.odim : (int64_t)0, io->before,
+                               io->after_packed, (io->after_packed && !packed_done) ? io->row_capacity * rf * c.odim : (int64_t)0, io->before,
                                (io->before && !before_done) ? (int64_t)b.B * io->Lmax * rf * c.odim : (int64_t)0);
             HIP_TRY(h, hipGetLastError());
         }

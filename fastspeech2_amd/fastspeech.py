@@ -401,7 +401,7 @@ class FeedForwardTransformer(nn.Module):
         ``per_utterance_bound`` frames, ``out["olens"]`` is the DEVICE int64 tensor and ``out["status"]`` a device
         int32[8] = {rows used, attention work items, overflow flags, longest utterance, valid frames, ...}: the results are
         valid only if ``status[2] == 0`` (see ``inference_batch(sync=False)``); ``after_packed`` then has
-        ``fs2_row_capacity(total_frames_bound)`` rows, of which the first ``status[4]`` are filled; ``packed_out`` (a contiguous
+        ``fs2_row_capacity(total_frames_bound)`` x reduction_factor rows, of which the first ``status[4]`` x reduction_factor are filled; ``packed_out`` (a contiguous
         float32 [>= that many rows, odim] tensor) receives them in place instead of a new allocation."""
         _require_device(xs)
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -414,8 +414,6 @@ class FeedForwardTransformer(nn.Module):
         il = torch.as_tensor(ilens).detach().to("cpu", torch.int64).contiguous()   # host lengths (reference: .tolist())
         if il.numel() != B:
             raise ValueError("ilens has %d entries for a batch of %d" % (il.numel(), B))
-        if self.reduction_factor > 1 and ("after_packed" in want or packed_out is not None):
-            raise NotImplementedError("the packed (multi-GPU) output form is implemented for reduction_factor = 1")
         prec = _lib.PRECISIONS[self.precision]
         L = self._ensure_ready(dev, Tmax)
         h = self._handle
@@ -468,13 +466,14 @@ class FeedForwardTransformer(nn.Module):
                     cbuf("lr_index", (B, Lcap), torch.int32), cbuf("decoder_out", (B, Lcap, self._cfg["ddim"])),
                     tok_ws.data_ptr(), frm_ws.data_ptr(), frm_ws.numel(), None, rows, status.data_ptr())
                 if "after_packed" in want:
+                    prows = rows * self.reduction_factor       # mel frames: r per decoder row
                     if packed_out is not None:
                         if (not packed_out.is_contiguous() or packed_out.dtype != torch.float32 or packed_out.device != dev
-                                or packed_out.dim() != 2 or packed_out.shape[1] != odim or packed_out.shape[0] < rows):
-                            raise ValueError("packed_out must be a contiguous float32 [>= %d, %d] tensor on %s" % (rows, odim, dev))
-                        out["after_packed"] = packed_out[:rows]
+                                or packed_out.dim() != 2 or packed_out.shape[1] != odim or packed_out.shape[0] < prows):
+                            raise ValueError("packed_out must be a contiguous float32 [>= %d, %d] tensor on %s" % (prows, odim, dev))
+                        out["after_packed"] = packed_out[:prows]
                     else:
-                        out["after_packed"] = torch.empty((rows, odim), dtype=torch.float32, device=dev)
+                        out["after_packed"] = torch.empty((prows, odim), dtype=torch.float32, device=dev)
                     dio.after_packed = out["after_packed"].data_ptr()
                 if dio.after is None and dio.after_packed is None:
                     raise ValueError("'after' or 'after_packed' must be requested")
@@ -516,7 +515,7 @@ class FeedForwardTransformer(nn.Module):
                 buf("qe", (B, Lmax), torch.int32), buf("qp", (B, Lmax), torch.int32),
                 buf("lr_index", (B, Lmax), torch.int32), buf("decoder_out", (B, Lmax, self._cfg["ddim"])),
                 tok_ws.data_ptr(), frm_ws.data_ptr(), frm_ws.numel(),
-                buf("after_packed", (int(ol.sum()), odim)))
+                buf("after_packed", (int(ol.sum()) * self.reduction_factor, odim)))
             if dio.after is None:
                 raise ValueError("'after' must be requested")
             _lib.check(L.fs2_decode(h, st, C.byref(dio)), h)

@@ -364,7 +364,9 @@ class ShardedSynthesizer:
             mel, ol = gather_packed(packed, olens, mine, xs.shape[0], self.group)
             return mel, ol.to(xs.device)
         total, Lcap = self.capacities(il, parts, kw.get("alpha", 1.0))
-        cap = max(row_capacity(len(p), total) for p in parts)
+        # (capacities count decoder frames; the pack and the padded result hold mel frames: reduction_factor per decoder frame)
+        rf = int(getattr(model, "reduction_factor", 1))
+        cap = max(row_capacity(len(p), total) for p in parts) * rf
         send_buf = None
         if len(mine):
             if coll and xs.is_cuda:      # the model writes its pack straight into the send buffer of the all-gather
@@ -379,18 +381,18 @@ class ShardedSynthesizer:
             self._last = None
         if not coll:
             # same data path without the collective: offsets on the device, one unpack kernel
-            return _unpack_local(packed, olens_dev, Lcap), olens_dev
+            return _unpack_local(packed, olens_dev, Lcap * rf), olens_dev
         if self.overlap and packed.is_cuda:
             cur = torch.cuda.current_stream(xs.device)
             if self._comm is None:
                 self._comm = torch.cuda.Stream(device=xs.device)
             self._comm.wait_stream(cur)                       # the pack of this batch is complete
             with torch.cuda.stream(self._comm):
-                out = gather_shards(packed, olens_dev, parts, Lcap, cap=cap, group=self.group, send_buf=send_buf, unpack=not skip_unpack)
+                out = gather_shards(packed, olens_dev, parts, Lcap * rf, cap=cap, group=self.group, send_buf=send_buf, unpack=not skip_unpack)
             packed.record_stream(self._comm)                  # allocated on the compute stream, read by the side stream
             olens_dev.record_stream(self._comm)
             return out
-        return gather_shards(packed, olens_dev, parts, Lcap, cap=cap, group=self.group, send_buf=send_buf, unpack=not skip_unpack)
+        return gather_shards(packed, olens_dev, parts, Lcap * rf, cap=cap, group=self.group, send_buf=send_buf, unpack=not skip_unpack)
 
     def wait(self):
         """Make the current stream wait for the gathers issued in overlap mode (no host synchronisation)."""

@@ -81,7 +81,7 @@ typedef struct fs2_config {
     int32_t postnet_layers, postnet_chans, postnet_filts, use_batch_norm;
     int32_t use_scaled_pos_enc;
     int32_t reduction_factor;           /* r in [1, 8]: feat_out emits r mel frames per decoder frame; the mel outputs
-                                           (before / after) then hold Lmax * r frames; after_packed needs r = 1 */
+                                           (before / after) then hold Lmax * r frames and after_packed r * sum(olens) rows */
     int32_t device;                     /* HIP device ordinal                                 */
     int32_t decoder_input_layer;        /* 1: Linear -> LN -> ReLU -> +pe (fastspeech.py:120-135, encoder.py:118-125);
                                            0: +pe only (the TorchScript twin, utils/fastspeech2_script.py:112-127;
@@ -150,8 +150,9 @@ typedef struct fs2_decode_io {
     void *token_workspace;    /* the workspace given to fs2_encode                               */
     void *workspace;          /* device, fs2_frame_workspace_bytes()                              */
     size_t workspace_bytes;
-    float *after_packed;      /* device [sum(olens), odim]: the valid frames of `after`, utterances back to
-                                 back in batch order (what the multi-GPU all-gather ships), or NULL          */
+    float *after_packed;      /* device [r * sum(olens), odim] (r = reduction_factor): the valid frames of
+                                 `after`, utterances back to back in batch order (what the multi-GPU
+                                 all-gather ships), or NULL                                                   */
     /* Device-driven frame layout (no host read-back of the frame counts between fs2_encode and fs2_decode):
      * set olens = NULL and give capacities instead.  The frame counts are taken from the device copy fs2_encode
      * left in the token workspace, the packed-row layout and the attention work list are built by a kernel, grids
@@ -160,7 +161,7 @@ typedef struct fs2_decode_io {
      * {total rows used, attention work items, overflow flags, longest utterance, valid frames, 0, 0, 0}; overflow
      * flags != 0 (FS2_OVF_*) means a capacity was too small and the outputs are invalid -- before / after /
      * after_packed are then filled with NaN: rerun with larger capacities or with host olens.  after_packed,
-     * if given, must hold row_capacity rows in this mode. */
+     * if given, must hold r * row_capacity rows in this mode. */
     int64_t row_capacity;     /* 0 = host-driven layout (olens required)                                      */
     int32_t *status;
 } fs2_decode_io;

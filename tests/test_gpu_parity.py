@@ -863,7 +863,8 @@ def test_g7_block_variants_on_device(name, precision, golden_dir):
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 def test_g8_reduction_factor_on_device(precision, golden_dir):
     """reduction_factor = 2 (reference fastspeech.py:153,228-230): the HIP path against the real reference's outputs (fixture G8),
-    teacher-forced (_forward) and free-running (inference, inference_batch in both layout modes); mel frames = 2 x decoder frames."""
+    teacher-forced (_forward) and free-running (inference, inference_batch in both layout modes, padded and packed, and through
+    ShardedSynthesizer); mel frames = 2 x decoder frames."""
     from tests.test_oracle_golden import reduction_setup
     g = np.load(golden_dir + "/g8_reduction_factor2_b2.npz")
     hp, model, sd, cfg = reduction_setup()
@@ -894,8 +895,25 @@ def test_g8_reduction_factor_on_device(precision, golden_dir):
             assert float((mels[i, : want.shape[0]].cpu() - want).abs().max()) < tol
             assert torch.equal(mels[i, : want.shape[0]], mels2[i, : want.shape[0]])
             assert float(mels[i, want.shape[0]:].abs().max()) == 0.0 if mels.shape[1] > want.shape[0] else True
-        with pytest.raises(NotImplementedError):
-            model.inference_batch(xs.cuda(), il, packed=True)
+        # the packed form (what the multi-GPU gather ships) holds MEL frames: 2 per decoder frame, utterances back to back -- in both
+        # layout modes -- and ShardedSynthesizer (the sharded path minus the collective on this one-GPU box) returns the padded result
+        packed, olp = model.inference_batch(xs.cuda(), il, packed=True)
+        assert torch.equal(olp, ol) and packed.shape == (int(ol.sum()), mels.shape[2])
+        ap = model.inference_batch(xs.cuda(), il, packed=True, sync=False)
+        packed2, olp2 = ap
+        assert ap.ok() and torch.equal(olp2.cpu(), ol) and packed2.shape[0] >= int(ol.sum())
+        s0 = 0
+        for i in range(2):
+            n = int(ol[i])
+            assert torch.equal(packed[s0:s0 + n], mels[i, :n]) and torch.equal(packed2[s0:s0 + n], mels[i, :n])
+            s0 += n
+        from fastspeech2_amd.parallel import ShardedSynthesizer
+        synth = ShardedSynthesizer(model)
+        m1, o1 = synth(xs.cuda(), il)              # synchronous first call
+        m2, o2 = synth(xs.cuda(), il)              # sync-free: device layout, capacities in decoder frames, result in mel frames
+        assert synth.ok() and torch.equal(o1.cpu(), ol) and torch.equal(o2.cpu(), ol)
+        Lm = mels.shape[1]
+        assert torch.equal(m1[:, :Lm], mels) and torch.equal(m2[:, :Lm], mels) and float(m2[:, Lm:].abs().sum()) == 0.0
 
 
 def test_packed_output_and_unpack_kernel(env):
