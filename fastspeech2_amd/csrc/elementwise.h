@@ -395,6 +395,21 @@ __global__ void pack_rows(const float* src, int W, const int* row_pos, const int
     *reinterpret_cast<float4*>(dst + ((size_t)cum[b] * cum_scale + j) * W + c) = *reinterpret_cast<const float4*>(src + (size_t)row * W + c);
 }
 
+// split-bf16 planes [R][nchunks x 128 B] -> fp32 rows [R][ld] (hi + lo, exact): what fs2_op_attention hands back when asked to run
+// the attention kernels in the model's output form (FS2_OP_ATT_PLANES: the context leaves the kernel as planes only)
+__global__ void planes_to_rows(const void* planes, int nchunks, int R, int D, float* dst, int ld) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d4 = D / 4;
+    if (i >= (int64_t)R * d4) return;
+    const int row = (int)(i / d4), c = (int)(i - (int64_t)row * d4) * 4;
+    const char* p = reinterpret_cast<const char*>(planes) + plane_byte((size_t)row, nchunks, c);
+    const bf16x4_t h = *reinterpret_cast<const bf16x4_t*>(p), l = *reinterpret_cast<const bf16x4_t*>(p + 64);
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (float)h[j] + (float)l[j];
+    *reinterpret_cast<f32x4*>(dst + (size_t)row * ld + c) = v;
+}
+
 // device-driven layout: when the overflow flags (dims[2]) are set the outputs of the call are invalid -> fill them with NaN
 __global__ void poison_on_overflow(const int* dims, float* a, int64_t na, float* b, int64_t nb, float* c, int64_t nc) {
     if (dims[2] == 0) return;

@@ -88,6 +88,7 @@ struct Options {
     int f32_rows = 0;    // FS2_F32_ROWS row-complete fp32 GEMM for LayerNorm-terminated ops
     int fuse_var = 1;    // FS2_FUSE_VAR the pitch and the energy predictor as one launch per layer (0: separate launches)
     int mt8 = -1;        // FS2_MT8      m-tiles per wave of the 8-wave row-complete kernels (2 | 3: 128 / 192-row workgroups)
+    int op_att_planes = 0;   // FS2_OP_ATT_PLANES  fs2_op_attention (split-bf16 modes) takes the context from the kernels as planes, the model's form, and converts (tests)
     int qkv_split = -1;  // FS2_QKV_SPLIT  the Q, K and V passes of gemm_qkv8_bf16 as three workgroups per row tile (-1: by the round count)
     int w32 = -1;        // FS2_ATTN_W32 split-bf16 attention with 32 queries per wave (attn_w32.h): 0 never, 1 whenever the head dim allows, -1 by regime
 };
@@ -99,7 +100,7 @@ Options& opts() {
     static Options o = [] {
         Options x;
         x.bm = env_int("FS2_BM", -1); x.row8 = env_int("FS2_ROW8", -1); x.qkv8 = env_int("FS2_QKV8", -1);
-        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.qkv_split = env_int("FS2_QKV_SPLIT", -1); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 0); x.w32 = env_int("FS2_ATTN_W32", -1);
+        x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.qkv_split = env_int("FS2_QKV_SPLIT", -1); x.op_att_planes = env_int("FS2_OP_ATT_PLANES", 0); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 0); x.w32 = env_int("FS2_ATTN_W32", -1);
         return x;
     }();
     return o;
@@ -1934,7 +1935,20 @@ int fs2_op_attention(void* stream, const float* qkv, float* ctx, int32_t D, int3
         __bf16* planes = nullptr;
         OP_TRY(tmp.alloc((void**)&planes, (size_t)Rvt * D * 6 * sizeof(__bf16)));
         __bf16 *qkh = planes, *qkl = planes + (size_t)Rvt * 2 * D, *vth = qkl + (size_t)Rvt * 2 * D, *vtl = vth + (size_t)Rvt * D;
-        rc = launch_attention_b16(nullptr, s, "op.attention", qkv, ctx, D, heads, R, Rvt, dl, (int)work.size(), mask_q, 0.0, precision, qkh, qkl, vth, vtl);
+        if (opts().op_att_planes > 0 && D % 32 == 0) {
+            // the model's output form: the kernels write the context as planes only (attn_w32: the LDS-staged epilogue), converted here
+            void* ctxp = nullptr;
+            OP_TRY(tmp.alloc(&ctxp, (size_t)Rvt * D * 4));
+            OP_TRY(hipMemsetAsync(ctxp, 0, (size_t)Rvt * D * 4, s));
+            rc = launch_attention_b16(nullptr, s, "op.attention", qkv, nullptr, D, heads, R, Rvt, dl, (int)work.size(), mask_q, 0.0, precision, qkh, qkl, vth, vtl, ctxp);
+            if (rc == FS2_OK) {
+                const int64_t n = (int64_t)R * (D / 4);
+                hipLaunchKernelGGL(planes_to_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ctxp, D / 32, R, D, ctx, D);
+                OP_TRY(hipGetLastError());
+            }
+        } else {
+            rc = launch_attention_b16(nullptr, s, "op.attention", qkv, ctx, D, heads, R, Rvt, dl, (int)work.size(), mask_q, 0.0, precision, qkh, qkl, vth, vtl);
+        }
     }
     return rc;      // (tmp drains the stream and frees)
 }
@@ -2026,6 +2040,7 @@ int fs2_set_option(const char* name, int32_t value) {
     else if (n == "FS2_F32_ROWS") o.f32_rows = value > 0;
     else if (n == "FS2_MT8") o.mt8 = value;
     else if (n == "FS2_QKV_SPLIT") o.qkv_split = value;
+    else if (n == "FS2_OP_ATT_PLANES") o.op_att_planes = value;
     else if (n == "FS2_FUSE_VAR") o.fuse_var = value != 0;
     else if (n == "FS2_BAL") o.bal = value < 0 ? 0 : value;
     else if (n == "FS2_ATTN_W32") o.w32 = value;

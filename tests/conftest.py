@@ -30,7 +30,7 @@ def fs2_option():
 
     yield set_
     for name in touched:
-        _lib.set_option(name, 0 if name in ("FS2_NOSPLITK", "FS2_F32_ROWS") else (1 if name == "FS2_FUSE_VAR" else -1))
+        _lib.set_option(name, 0 if name in ("FS2_NOSPLITK", "FS2_F32_ROWS", "FS2_OP_ATT_PLANES") else (1 if name == "FS2_FUSE_VAR" else -1))
 
 
 def record_measurement(name, value):

@@ -192,14 +192,17 @@ ATT_TOL = {"fp32": 5e-6, "bf16x3": 7e-5, "bf16": 3.5e-2}
 
 # "bf16x3/w32": the same arithmetic through attn_w32 (32 queries per wave; forced with FS2_ATTN_W32 = 1: the automatic choice takes it
 # only for grids that fill the chip); "bf16x3" pins the 64-query kernel (FS2_ATTN_W32 = 0)
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x3/w32", "bf16"])
+# ".../planes": the kernels hand the context back as split-bf16 planes only, the form the model uses (attn_w32: the LDS-staged epilogue),
+# and the operator converts (FS2_OP_ATT_PLANES); hi + lo carries 16 mantissa bits: ~1.5e-5 on |ctx| <= 2
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x3/w32", "bf16x3/planes", "bf16x3/w32/planes", "bf16"])
 @pytest.mark.parametrize("D,heads", [(256, 2), (384, 2)])
 @pytest.mark.parametrize("mask_q", [0, 1])
 def test_attention(D, heads, mask_q, precision, fs2_option):
     from tests import ops_binding as ops
     dev = _dev()
     if precision.startswith("bf16x3"):
-        fs2_option("FS2_ATTN_W32", 1 if precision.endswith("/w32") else 0)
+        fs2_option("FS2_ATTN_W32", 1 if "/w32" in precision else 0)
+        fs2_option("FS2_OP_ATT_PLANES", 1 if precision.endswith("/planes") else 0)
         precision = "bf16x3"
     rs = np.random.RandomState(D + mask_q)
     # (lengths around the tile sizes of both kernels: 32-key tiles, 64- and 128-query blocks; a 1-frame utterance; klen % 8 != 0)
@@ -236,7 +239,7 @@ def test_attention(D, heads, mask_q, precision, fs2_option):
 
 
 @pytest.mark.parametrize("spike", [40.0, 400.0])
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x3/w32"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x3/w32", "bf16x3/w32/planes"])
 def test_attention_spiked_key_forces_rescale(precision, spike, fs2_option):
     """One key far above the others late in the sequence: exercises the online-softmax rescale branch of the 64-query kernels and, in
     attn_w32 (which never rescales: its reference maximum is the first tile's, attn_w32.h), probabilities far above 1 (rows whose
@@ -245,7 +248,8 @@ def test_attention_spiked_key_forces_rescale(precision, spike, fs2_option):
     from tests import ops_binding as ops
     dev = _dev()
     if precision.startswith("bf16x3"):
-        fs2_option("FS2_ATTN_W32", 1 if precision.endswith("/w32") else 0)
+        fs2_option("FS2_ATTN_W32", 1 if "/w32" in precision else 0)
+        fs2_option("FS2_OP_ATT_PLANES", 1 if precision.endswith("/planes") else 0)
         precision = "bf16x3"
     rs = np.random.RandomState(5)
     D, heads, l = 256, 2, 130
