@@ -1,7 +1,8 @@
 // attn_w32: split-bf16 flash-style self-attention with 32 queries per wavefront on v_mfma_f32_32x32x16_bf16, one wavefront per
 // SIMD (the whole 512-entry register file), K / V^T tiles brought in by LDS-DMA into a ring of three.  Same arithmetic as
 // attn_bf16<DK,3> (every operand x = hi + lo in bf16, lo*hi + hi*lo + hi*hi, fp32 accumulate, base-2 online softmax);
-// replaces reference core/attention.py:55-70 for the frame-level (decoder) launches.
+// replaces reference core/attention.py:55-70 for the launches whose grid fills the chip (fs2_runtime.hip: use_attn_w32 -- the
+// decoder's at c2 .. c5, the encoder's at c4).
 //
 // Why a second kernel: attn_bf16 keeps 16 queries per wave, so every 1-KB fragment read from
 // LDS feeds ONE 16-cycle MFMA, a tile costs two workgroup barriers, and 238 registers leave no room to overlap anything.  Here
@@ -13,8 +14,9 @@
 //   * O^T = V^T.P^T (A = V^T rows from LDS, B = P^T from registers): column = the lane's own query, so the running max and the
 //     normaliser are lane-local (attn_bf16 fetches them with ds_bpermute);
 //   * the wave is alone on its SIMD, so nothing but its own instruction stream covers the softmax: the exponentials of tile t sit
-//     between the MFMAs of Q.K^T of tile t + 1, the score sums of tile t + 1 between the MFMAs of P.V of tile t, the LDS-DMA of the
-//     tiles to come between the MFMAs of Q.K^T -- one MFMA per "slot", every slot closed by a scheduling fence; ONE workgroup barrier
+//     between the MFMAs of Q.K^T of tile t + 1, the score sums of tile t + 1 between the MFMAs of P.V of tile t, the LDS-DMA pieces
+//     of the tiles to come in the slots with the least other work (K pieces in Q.K^T, V^T pieces in P.V) -- one MFMA per "slot",
+//     every slot closed by a scheduling fence; ONE workgroup barrier
 //     per tile; rings of THREE tiles per operand, so that a DMA piece has two iterations to land (the closing wait of an iteration is
 //     vmcnt(this iteration's own pieces): an LDS-DMA round trip under load is ~2,500 cycles, half a tile);
 //   * NO rescale of O and no running maximum inside the loop: the reference maximum m of a row is the maximum of its FIRST tile; the
@@ -25,6 +27,10 @@
 //     tile, stops computing, keeps feeding the DMA ring, and afterwards redoes its 32 rows in a plain fp32 two-pass loop
 //     (attn_w32_rows_slow).  Reason: a single compiler-visible VALU use of the O accumulators inside the loop makes hipcc treat
 //     them as either-file values and copy all 96 registers into and out of the accumulator file around every P.V phase.
+// Prologue and epilogue: the wave's 32 Q rows arrive as one more K-layout tile by LDS-DMA, staged in the ring slots the first K / V^T
+// tiles do not use yet, and are read into the accumulator file once; the context leaves as split-bf16 planes staged through the (then
+// idle) ring memory -- behind `s_waitcnt vmcnt(0)` + a barrier: pieces of the redundant last fetch may still be in flight -- and is
+// stored as whole rows (fp32 output, the operator tests' form, goes straight from the registers).
 // Register files (the MFMAs are inline asm so that the file of every operand is ours to choose; left alone, hipcc's allocator
 // shuffled 1,700 v_accvgpr_* per kernel and spilled): O^T (96 registers at d_k = 192) and the Q fragments (96) live in the
 // accumulator half, everything the VALU touches in the architectural half (<= 170).  hipcc pads no hazards around asm (cdna guide
@@ -70,7 +76,7 @@ __device__ __forceinline__ void dma16_so(gchar_t* base, unsigned off, unsigned l
 // their clobbers (which keeps every value that lives across the tile loop -- the Q fragments -- out of a[0 : 16 NT) and makes the
 // kernel descriptor allocate the range).  With O as "+a" operands hipcc kept two copies of every accumulator tuple and moved 64-96
 // registers between them per P.V phase; pinned with "{a[..]}" it kept O in the architectural file and copied it in and out.
-// AUDIT after every edit (tools/probes/audit_w32.sh): no compiler v_accvgpr_* touching a0 .. a(16 NT - 1), no scratch.
+// AUDIT after every edit (tools/probes/audit_w32.py): no compiler v_accvgpr_* touching a0 .. a(16 NT - 1), no scratch.
 template <int N>
 __device__ __forceinline__ void mfma_o0(const bf16x8_t& z_v) {                             // a[16N..] = 0 (padded: z_v is VALU-written)
     if constexpr (N == 0) asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 a[0:15], %0, %0, 0" : : "v"(z_v) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
