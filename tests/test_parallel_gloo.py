@@ -70,6 +70,27 @@ class FakeModel:
         return _Async((pk, ol.clone()))
 
 
+class FakeModelR2(FakeModel):
+    """The same contract at reduction_factor = 2: every decoder frame yields two (identical) mel frames; `olens` and the packs count
+    MEL frames, the capacities handed in by ShardedSynthesizer and the learned frames-per-phoneme ratio count DECODER frames."""
+    reduction_factor = 2
+
+    def inference_batch(self, xs, ilens, packed=False, sync=True, capacity=None, alpha=1.0):
+        from fastspeech2_amd.parallel import row_capacity
+        assert packed and alpha == 1.0
+        mel, ol = _fake_run_local(xs, ilens)
+        valid = torch.cat([mel[i, : int(ol[i])].repeat_interleave(2, dim=0) for i in range(len(ol))])
+        il = torch.as_tensor(ilens)
+        if sync:
+            self._frames_per_token = (float(ol.sum()) / float(il.sum()), float((ol.float() / il.float()).max()))
+            return valid, 2 * ol
+        rows = 2 * row_capacity(len(ol), capacity[0])
+        assert valid.shape[0] <= rows and int(ol.max()) <= capacity[1], "capacities (decoder frames) too small"
+        pk = torch.full((rows, ODIM), float("nan"))
+        pk[: valid.shape[0]] = valid
+        return _Async((pk, 2 * ol))
+
+
 def _make_inputs(B=11):
     g = torch.Generator().manual_seed(7)
     il = torch.randint(3, 40, (B,), generator=g)
@@ -128,6 +149,16 @@ def _worker(rank, world, port, q):
         raise AssertionError("alpha = 0 must be rejected")
     except ValueError:
         pass
+    # (3e) reduction_factor = 2: capacities in decoder frames, packs / results / olens in mel frames (two per decoder frame)
+    synth2 = ShardedSynthesizer(FakeModelR2())
+    want2 = want_mel.repeat_interleave(2, dim=1)
+    for _ in range(2):          # synchronous first call, then the sync-free one
+        m7, o7 = synth2(xs, il)
+        assert synth2.ok() and torch.equal(o7, 2 * want_ol) and torch.equal(m7[:, : 2 * L], want2) and not torch.isnan(m7).any()
+    recv7, st7, o7p = synth2(xs, il, packed=True)
+    for g in range(xs.shape[0]):
+        s0, n = int(st7[g]), int(o7p[g])
+        assert n == 2 * int(want_ol[g]) and torch.equal(recv7[s0:s0 + n], want2[g, :n])
     # (4) fewer utterances than ranks: some rank has an EMPTY shard and still takes part in the collectives
     for form in (ShardedSynthesizer(_fake_run_local), synth):
         for _ in range(2):
