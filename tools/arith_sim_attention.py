@@ -62,6 +62,34 @@ def run(L, dk, temp, rs):
     return {k_: (np.abs(o - ref).max() / m, np.sqrt(((o - ref) ** 2).mean()) / m) for k_, o in out.items()}, float(1.0 / (p / l).max(-1).mean())
 
 
+def run_qk(L, dk, temp, rs):
+    """the same split on Q.K^T (Q pre-scaled by log2 e / sqrt d_k as the QKV epilogue leaves it): error of the context when only the scores are computed in the scheme"""
+    q = (rs.standard_normal((L, dk)) * np.sqrt(temp)).astype(np.float32)
+    k = (rs.standard_normal((L, dk)) * np.sqrt(temp)).astype(np.float32)
+    v = rs.standard_normal((L, dk)).astype(np.float32)
+    qs = (q * (1.4426950408889634 / np.sqrt(dk))).astype(np.float32)
+    f64 = lambda a, b: a.astype(np.float64) @ b.astype(np.float64)
+
+    def ctx_of(s):
+        p = np.exp2(s - s.max(-1, keepdims=True))
+        return (p @ v.astype(np.float64)) / p.sum(-1, keepdims=True)
+    s_ref = f64(qs, k.T)
+    ref = ctx_of(s_ref)
+    out = {}
+    qh = to_bf16(qs); ql = to_bf16(qs - qh); kh = to_bf16(k); kl = to_bf16(k - kh)
+    out["bf16x3"] = ctx_of(f64(qh, kh.T) + f64(qh, kl.T) + f64(ql, kh.T))
+    q16, k16 = to_f16(qs), to_f16(k)
+    rq, rk = qs - q16, k - k16
+    out["f16x1"] = ctx_of(f64(q16, k16.T))
+    sc = lambda x: 2.0 ** np.floor(np.log2(448.0 / np.abs(x).max()))
+    rq8, rk8 = to_e4m3(rq * sc(rq)) / sc(rq), to_e4m3(rk * sc(rk)) / sc(rk)
+    q8, k8 = to_e4m3(q16 * sc(q16)) / sc(q16), to_e4m3(k16 * sc(k16)) / sc(k16)
+    out["f16 + mx"] = ctx_of(f64(q16, k16.T) + f64(rq8, k16.T) + f64(q16, rk8.T))
+    out["f16 + mx8"] = ctx_of(f64(q16, k16.T) + f64(rq8, k8.T) + f64(q8, rk8.T))
+    m = np.abs(ref).max()
+    return {k_: (np.abs(o - ref).max() / m, np.sqrt(((o - ref) ** 2).mean()) / m) for k_, o in out.items()}, float(np.abs(s_ref).max())
+
+
 def main():
     rs = np.random.RandomState(0)
     print("P.V arithmetic, context error relative to max|ctx| (max | rms); L = 1024 keys, d_k = 192")
@@ -69,6 +97,11 @@ def main():
     for temp, name in ((1.0, "N(0,1): ~flat rows"), (3.0, "x3: a few keys dominate"), (8.0, "x8: near one-hot rows")):
         r, eff = run(1024, 192, temp, rs)
         print("%-34s " % ("%s (1/mean max p = %.1f)" % (name, eff)) + " ".join("%.1e | %.1e     " % r[k] for k in ("bf16x3", "f16x1", "f16 + mx", "f16 + mx8")))
+    print()
+    print("Q.K^T in the scheme (P.V exact), context error relative to max|ctx| (max | rms)")
+    for temp in (1.0, 3.0, 8.0):
+        r, smax = run_qk(1024, 192, temp, rs)
+        print("%-34s " % ("max |score| = %.0f (log2 domain)" % smax) + " ".join("%.1e | %.1e     " % r[k] for k in ("bf16x3", "f16x1", "f16 + mx", "f16 + mx8")))
 
 
 if __name__ == "__main__":
