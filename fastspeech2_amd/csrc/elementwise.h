@@ -263,7 +263,9 @@ __global__ __launch_bounds__(256) void lr_expand(const float* hs, int D, const i
                                                  const int* cum, int Tmax, const int* row_pos, const int* row_seq,
                                                  int uniform_len, const int* vlen, int R, float* out,
                                                  int* index_rows, void* planes = nullptr) {     // planes: also as split-bf16 planes (D / 32 chunks)
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // (the row as a scalar: everything up to the copy -- utterance, position, the binary search over the duration sums -- is then scalar
+    //  loads and SALU, a chain of K$ round trips instead of vector-memory ones)
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     if (row >= R) return;
     int b, j;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(256) void bucket_embed(float* h, int D, const int* 
                                                     const float* e_rows, const float* p_rows,
                                                     const float* ebins, const float* pbins, int nb,
                                                     const float* Te, const float* Tp, int* qe_rows, int* qp_rows, void* planes = nullptr) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // (scalar: the two bin searches become scalar-load chains)
     const int lane = threadIdx.x & 63;
     if (row >= R) return;
     const int j = row_pos[row];
