@@ -8,7 +8,9 @@
 
 One "step" = one full free-running forward of the hot path over one synthetic batch already resident in
 HBM: phoneme ids -> encoder -> duration predictor -> length regulator -> pitch/energy -> decoder -> mel
-projection -> Postnet -> padded mels (and, for N > 1, the RCCL all-gather of the mels over xGMI).
+projection -> Postnet -> padded mels on one GPU; for N > 1 the valid frames leave as a pack and ONE RCCL all-gather over xGMI returns
+every rank the gathered packs + offsets (`config.gather` = "packed", the default since round 4) or, with --padded, the ordered padded
+[B, Lcap, odim] tensor ("padded", what rounds 1-3 measured): lines of different `gather` forms do not compare.
 
 Workloads (BASELINE.json configs, fastspeech2_amd/synthetic.py):
   N = 1 : c3, "batch=64 LJSpeech-shape" -- the config the >= 50x-CPU target is quoted on.
@@ -122,10 +124,116 @@ def cpu_baseline(sd, cfg, batch, gpu, budget_s=14.0):
     flips = dict(utterances_compared=utt, dur_exact_rate=round(tok_eq / max(tok, 1), 6), olens_exact_rate=round(utt_eq / max(utt, 1), 6),
                  qe_agree_rate=round(qe_eq / max(fr, 1), 6), qp_agree_rate=round(qp_eq / max(fr, 1), 6), frames_compared=fr,
                  note="free-running GPU vs free-running CPU oracle; bucket indices compared on utterances whose durations all agree")
-    return dict(value=round(best, 1), unit="mel-frames/s", cores=torch.get_num_threads(), kind="port",
+    cpu_model, phys, logical = host_cpu()
+    return dict(value=round(best, 1), unit="mel-frames/s", cores=torch.get_num_threads(), threads=torch.get_num_threads(), host_physical_cores=phys,
+                host_logical_cores=logical, cpu_model=cpu_model, kind="port",
+                cores_note="cores = threads the oracle ran on (the fastest of 4 .. all logical cores for this op mix), not the host's core count",
                 sample="oracle (validated fp32 PyTorch port of the reference path; measured equal to the real reference within noise, "
                        "BASELINE.md section 3) on the c3 batch: per-utterance loop over the first %d utterances (%d frames) = %.0f fr/s; "
                        "one padded batch of %d = %.0f fr/s; faster quoted" % (n, frames, per_utt, nb, padded)), worst, flips
+
+
+def host_cpu():
+    """(model string, physical cores, logical cores) of the host the CPU baseline runs on (north_star: "core count stated")."""
+    model, phys = None, set()
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None and cid is not None:
+                phys.add((pid, cid))
+                pid = cid = None
+        if pid is not None and cid is not None:
+            phys.add((pid, cid))
+    except OSError:
+        pass
+    return model, (len(phys) or None), os.cpu_count()
+
+
+def sclk_reader(local):
+    """Reader of the current shader clock (MHz) from the amdgpu sysfs node of GPU `local` (pp_dpm_sclk: the level marked '*'), or None."""
+    import glob
+    import re
+    nodes = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"), key=lambda q: int(re.search(r"card(\d+)", q).group(1)))
+    if not nodes:
+        return None
+    path = nodes[min(local, len(nodes) - 1)]
+
+    def read():
+        try:
+            for ln in open(path):
+                if ln.rstrip().endswith("*"):
+                    return float(re.search(r"(\d+)\s*[Mm][Hh]z", ln).group(1))
+        except (OSError, AttributeError, ValueError):
+            pass
+        return None
+    return read if read() is not None else None
+
+
+def mfma_peak_record():
+    """Whole-chip bf16 MFMA issue rates measured on this chip family by a committed probe (profiles/mfma_rate_probe.json <- r04_mfma_rate_probe.txt)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "mfma_rate_probe.json")))
+    except (OSError, ValueError):
+        return None
+
+
+def dist_diagnostics(model, synth, xs, il, parts, rank, world, dev, k, ms_per_step):
+    """What an N-GPU line needs to be read (run AFTER the timed region, by every rank): the cost model's imbalance, each
+    rank's forward alone (min / max over ranks), and the same step with the collective serialised behind the forward -- so that a scaling
+    efficiency below target can be attributed to compute imbalance, to the all-gather or to neither."""
+    from fastspeech2_amd.parallel import ShardedSynthesizer, utterance_cost
+    costs = [sum(utterance_cost(int(il[i])) for i in p) for p in parts]
+    mine = parts[rank]
+    fwd = 0.0
+    if mine:
+        sel = torch.as_tensor(mine, dtype=torch.int64)
+        il_loc = il[sel]
+        xs_loc = xs[sel.to(dev)][:, : int(il_loc.max())]
+        cap = synth.capacities(il, parts)
+        run = lambda: model.inference_batch(xs_loc, il_loc, packed=True, sync=False, capacity=cap)
+        run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(k):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        fwd = e0.elapsed_time(e1) / k
+    t = torch.tensor([fwd], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    fwd_all = [round(float(x), 3) for x in every]
+    ser = ShardedSynthesizer(model, overlap=False)
+    ser._ratio = synth._ratio
+    ser(xs, il, packed=True)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        ser(xs, il, packed=True)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t = torch.tensor([(time.perf_counter() - t0) / k * 1e3], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    serial = float(t)
+    model.async_ok()
+    busiest = max(fwd_all)
+    return dict(backend=dist.get_backend(), world_size=dist.get_world_size(), steps_measured=k,
+                lpt_cost_imbalance_max_over_mean=round(max(costs) / (sum(costs) / len(costs)), 4),
+                forward_ms_per_rank=fwd_all, forward_ms_min=min(fwd_all), forward_ms_max=busiest,
+                ms_per_step_serial_collective=round(serial, 3), collective_ms_exposed_serial=round(serial - busiest, 3),
+                collective_ms_exposed_overlapped=round(ms_per_step - busiest, 3),
+                note="forward alone = this rank's shard through the sync-free single-GPU path (no collective); serial = the same step with the all-gather on "
+                     "the compute stream (FS2_DIST_SERIAL=1's form); exposed = step time - the busiest rank's forward")
 
 
 def free_port():
@@ -163,10 +271,21 @@ def fake_main(args, json_fd):
     dist.barrier()
     dt = time.perf_counter() - t0
     frames = int(torch.as_tensor(out[-1]).sum())
+    # the fields of dist_diagnostics() that exist without a GPU: the same collectives in the same order, stand-in numbers
+    from fastspeech2_amd.parallel import shard_indices, utterance_cost
+    parts = shard_indices(il.tolist(), world)
+    costs = [sum(utterance_cost(int(il[i])) for i in p) for p in parts]
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    fwd_all = [float(x) for x in every]
+    diag = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), lpt_cost_imbalance_max_over_mean=round(max(costs) / (sum(costs) / len(costs)), 4),
+                forward_ms_per_rank=fwd_all, forward_ms_min=min(fwd_all), forward_ms_max=max(fwd_all))
     if rank == 0:
         os.write(json_fd, (json.dumps({"metric": "mel-frames/sec", "value": round(frames * args.steps / dt, 1), "unit": "mel-frames/s", "n_gpus": world,
                                        "steps": args.steps, "warmup": args.warmup, "data": "FAKE (FS2_BENCH_FAKE test harness: gloo, stand-in model, measures nothing)",
-                                       "config": {"workload": "fake", "gather": "padded" if args.padded else "packed"}}) + "\n").encode())
+                                       "config": {"workload": "fake", "gather": "padded" if args.padded else "packed", "collective_world_size": dist.get_world_size()},
+                                       "multi_gpu": diag}) + "\n").encode())
     dist.destroy_process_group()
 
 
@@ -180,6 +299,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-kernels", action="store_true", help="print the per-kernel hipEvent table to stderr")
     ap.add_argument("--graph", action="store_true", help="replay the forward as one captured HIP graph (single GPU; the launch-bound small configs)")
+    ap.add_argument("--sustain", type=float, default=2.0, help="seconds the step keeps running after the timed region for `sustained_ms_per_step` (0: off)")
     ap.add_argument("--padded", action="store_true", help="N > 1: every rank also unpacks the gathered mels into the padded [B, Lcap, odim] tensor "
                                                            "(default: the packed form, gathered packs + offsets, no unpack launch)")
     args = ap.parse_args()
@@ -307,10 +427,46 @@ def main():
         step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
         prof = model.get_profile() if graph_run is None else scout_prof      # (graph mode: the roofline comes from the eager scouting step)
         model.set_profiling(False)
+        # ---- steady state: the timed region above is K steps (0.1 s at c3) after ~0.05 s of warm-up, and sustained MFMA load
+        # lowers the shader clock within tens of ms.  The same step runs on for >= args.sustain seconds (not part of `value`), timed the same way,
+        # while the host samples the shader clock from sysfs between enqueues.
+        sustained = None
+        if args.sustain > 0:
+            n_sus = max(args.steps, int(args.sustain / max(dt / args.steps, 1e-6)) + 1)
+            read_clk = sclk_reader(local)
+            clk = []
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for i in range(n_sus):
+                mel, olens_all = step()
+                if read_clk is not None and i % 4 == 0:
+                    v = read_clk()
+                    if v:
+                        clk.append(v)
+            if synth is not None:
+                synth.wait()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            dts = time.perf_counter() - ts
+            assert all_ok(), "capacities of the asynchronous path were exceeded in the sustained region"
+            if use_dist:
+                t = torch.tensor([dts], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dts = float(t.item())
+            sustained = dict(steps=n_sus, seconds=round(dts, 3), ms_per_step=round(1e3 * dts / n_sus, 3),
+                             sclk_mhz=(dict(min=min(clk), median=statistics.median(clk), max=max(clk), samples=len(clk),
+                                            source="amdgpu sysfs pp_dpm_sclk, sampled by the host while the queue is full") if clk else None))
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    multi_gpu = None
+    if use_dist and synth is not None and graph_run is None:
+        with torch.no_grad():
+            multi_gpu = dist_diagnostics(model, synth, xs, il, parts, rank, world, dev, max(2, min(args.steps, 5)), 1e3 * dt / args.steps)
 
     # ---- per-kernel table (hipEvents on the launch stream, accumulated over the timed steps) ----
     agg = {}
@@ -348,9 +504,16 @@ def main():
     if args.precision != "fp32":
         # what the chip sustains on random bf16 operands with nothing but MFMAs in flight (tools/probes/mfma_shape_probe.hip,
         # profiles/r02_mfma_shape_power_probe.txt: 1.8-2.1 PFLOP/s at 1.8-2.1 GHz, power-limited); `peak` stays the nominal figure
-        roofline["measured_mfma_peak"] = 1950.0
-        roofline["issued_frac_of_measured_peak"] = round(achieved * {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1, "mix_mx": 2}.get(args.precision, 1) / 1950.0, 4) \
-            if dom_name.endswith("ffn1") or args.precision == "bf16x3" else None
+        # -- and the chip's clock gives way under that load: the figure is a band, quoted from the committed probe record
+        # (profiles/mfma_rate_probe.json: random operands 1,710, all-ones 2,470 TFLOP/s at 32.0 cycles per MFMA in both cases)
+        rec = mfma_peak_record()
+        if rec is not None:
+            roofline["measured_mfma_peak"] = rec["random_operands_tflops"]
+            roofline["measured_mfma_peak_all_ones"] = rec["all_ones_operands_tflops"]
+            roofline["measured_mfma_peak_source"] = rec["source"]
+            roofline["issued_frac_of_measured_peak"] = round(achieved * {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1, "mix_mx": 2}.get(args.precision, 1)
+                                                             / rec["random_operands_tflops"], 4) \
+                if dom_name.endswith("ffn1") or args.precision == "bf16x3" else None
     # Algorithmic HBM bytes of one launch of the dominant kernel, from the launch's own shapes (valid rows of this rank): every operand read
     # once, every result written once.  bf16 modes: an activation travels as planes of 4 bytes per element (hi + lo bf16, or the mx image
     # of the same size), a weight image has 4 bytes per weight; the attention kernel reads the Q | K | V^T planes and writes the context planes.
@@ -404,6 +567,22 @@ def main():
             gbps = nbytes / (ms * 1e-3) / 1e9
             roofline_hbm.append(dict(kernel=name, bytes=int(nbytes), avg_launch_ms=round(ms, 4), achieved=round(gbps, 1), peak=HBM_PEAK_GBPS,
                                      unit="GB/s", frac=round(gbps / HBM_PEAK_GBPS, 4)))
+    # the weak end of the step: the three largest launch sites that run below 0.10 of the peak, from the fully
+    # bracketed (untimed) scouting step: FLOPs as the launches count them (rows in use incl. ~1.5 % gap rows), time by hipEvents
+    scout_fl = {}
+    for name, ms, fl, by in scout_prof:
+        scout_fl[name] = scout_fl.get(name, 0.0) + fl
+    weak = []
+    for name, ms in scout.items():
+        if scout_fl.get(name, 0.0) > 0 and ms > 0:
+            tf = scout_fl[name] / (ms * 1e-3) / 1e12
+            if tf / peak < 0.10:
+                weak.append(dict(site=name, launches_per_step=scout_n[name], ms_per_step=round(ms, 4), tflops=round(tf, 1), frac=round(tf / peak, 4),
+                                 share_of_step_kernel_time=round(ms / max(kernel_ms_per_step, 1e-9), 4)))
+    weak.sort(key=lambda w: -w["ms_per_step"])
+    below = sum(w["ms_per_step"] for w in weak)
+    roofline_worst = dict(threshold_frac=0.10, sites=weak[:3], sites_below_threshold=len(weak),
+                          share_of_step_kernel_time_below_threshold=round(below / max(kernel_ms_per_step, 1e-9), 4))
     if args.profile_kernels and rank == 0:
         tot = sum(v[1] for v in agg.values())
         for name, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -435,8 +614,17 @@ def main():
                                       if use_dist else "single GPU",
                        "launch": launch},
             "roofline": roofline,
+            "roofline_worst": roofline_worst,
             "roofline_hbm": roofline_hbm,
         }
+        if sustained is not None:
+            line["sustained_ms_per_step"] = sustained["ms_per_step"]
+            line["sustained"] = dict(sustained, ratio_to_timed=round(sustained["ms_per_step"] / (1e3 * dt / args.steps), 4),
+                                     value=round(total_frames * 1e3 / sustained["ms_per_step"], 1))
+        if use_dist:
+            line["config"]["gather"] = "padded" if (args.padded or args.profile_kernels) else "packed"
+            line["config"]["collective_world_size"] = dist.get_world_size()
+            line["multi_gpu"] = multi_gpu
         if world == 1 and not use_dist and not args.no_cpu_baseline:      # the only leg of this script that touches oracle/ (as the measured CPU baseline and the checker)
             from oracle import fs2_oracle as O
             cfg = O.config_from_hp(hp, N_PHONEME_SYMBOLS, odim)

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(1024) void frame_layout_dev(const int* olens, int B
         if (row > row_cap || depth * 8 > work_cap) ovf |= 1;
         if (mx > lmax_cap) ovf |= 2;
         if (mx > pe_rows) ovf |= 4;
-        if (s_min <= 0) ovf |= 8;
+        if (s_min < 0) ovf |= 16;           // FS2_OVF_BAD_ID: dur_scan marked an utterance whose phoneme ids leave [0, idim)
+        else if (s_min <= 0) ovf |= 8;
         dims[0] = row; dims[1] = ovf ? 0 : depth * 8; dims[2] = ovf; dims[3] = mx; dims[4] = frames; dims[5] = 0; dims[6] = 0; dims[7] = 0;
         if (status) {     // the caller's copy of the same eight words
             status[0] = row; status[1] = ovf ? 0 : depth * 8; status[2] = ovf; status[3] = mx; status[4] = frames; status[5] = 0; status[6] = 0; status[7] = 0;
@@ -214,16 +215,27 @@ __device__ __forceinline__ int scaled_duration(int64_t d, float alpha) {
     return f > 0.f ? (int)f : 0;
 }
 
+// ids != nullptr (fs2_encode): an utterance that holds a phoneme id outside [0, idim) gets the frame count -1 -- the reference's
+// torch.nn.Embedding raises for it (fastspeech.py:65-67, core/encoder.py:196); embed_pe reads row 0 instead of indexing out of range, and
+// the marker reaches the caller with the frame counts it reads anyway (host-driven layout) or as FS2_OVF_BAD_ID in the status word of
+// fs2_decode's device-driven layout (frame_layout_dev), whose outputs are then NaN-filled.
 __global__ __launch_bounds__(256) void dur_scan(const int64_t* ds, int Tmax, const int* ilen, int* cum,
-                                                int64_t* olens, int* olens32, float alpha = 1.0f) {
+                                                int64_t* olens, int* olens32, float alpha = 1.0f, const int64_t* ids = nullptr, int idim = 0) {
     __shared__ int wsum[4];
     __shared__ int carry_s;
+    __shared__ int bad_s;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = ilen[b];
     const int64_t* d = ds + (size_t)b * Tmax;
+    if (tid == 0) bad_s = 0;
+    __syncthreads();
     // pass 1: total
-    int tot = 0;
-    for (int t = tid; t < T; t += 256) tot += scaled_duration(d[t], alpha);
+    int tot = 0, bad = 0;
+    for (int t = tid; t < T; t += 256) {
+        tot += scaled_duration(d[t], alpha);
+        if (ids != nullptr) { const int64_t id = ids[(size_t)b * Tmax + t]; bad |= (id < 0 || id >= idim) ? 1 : 0; }
+    }
+    if (bad) bad_s = 1;
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
     if (lane == 0) wsum[wave] = tot;
     __syncthreads();
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(256) void dur_scan(const int64_t* ds, int Tmax, con
         __syncthreads();
     }
     if (tid == 0) {
-        const int tt = ones ? T : total;
+        const int tt = bad_s ? -1 : (ones ? T : total);
         if (olens) olens[b] = tt;
         if (olens32) olens32[b] = tt;
     }

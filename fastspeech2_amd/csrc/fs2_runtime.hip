@@ -23,6 +23,7 @@
 #include "elementwise.h"
 #include "gemm_bf16.h"
 #include "gemm_planes.h"
+#include "gemm_row4.h"
 #include "gemm_mx.h"
 #include "gemm_f32.h"
 
@@ -91,6 +92,9 @@ struct Options {
     int op_att_planes = 0;   // FS2_OP_ATT_PLANES  fs2_op_attention (split-bf16 modes) takes the context from the kernels as planes, the model's form, and converts (tests)
     int qkv_split = -1;  // FS2_QKV_SPLIT  the Q, K and V passes of gemm_qkv8_bf16 as three workgroups per row tile (-1: by the round count)
     int w32 = -1;        // FS2_ATTN_W32 split-bf16 attention with 32 queries per wave (attn_w32.h): 0 never, 1 whenever the head dim allows, -1 by regime
+    int row4 = -1;       // FS2_ROW4     the one-wave-per-SIMD row-complete kernel (gemm_row4.h) wherever gemm_row8_bf16 would run and it has the epilogue: 0 never, else yes
+    int mt4 = -1;        // FS2_MT4      its m-tiles per wave (4 | 5: 128 / 160-row workgroups; -1: by the round count)
+    int sched4 = 1;      // FS2_SCHED4   its LDS-DMA pieces dealt out over three MFMA groups (1) or issued in one burst behind the barrier (0)
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -101,6 +105,7 @@ Options& opts() {
         Options x;
         x.bm = env_int("FS2_BM", -1); x.row8 = env_int("FS2_ROW8", -1); x.qkv8 = env_int("FS2_QKV8", -1);
         x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.qkv_split = env_int("FS2_QKV_SPLIT", -1); x.op_att_planes = env_int("FS2_OP_ATT_PLANES", 0); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 0); x.w32 = env_int("FS2_ATTN_W32", -1);
+        x.row4 = env_int("FS2_ROW4", -1); x.mt4 = env_int("FS2_MT4", -1); x.sched4 = env_int("FS2_SCHED4", 1);
         return x;
     }();
     return o;
@@ -313,6 +318,39 @@ hipError_t launch_row8(hipStream_t s, const GemmArgs& a) {
     return launch_row8_t<NSPLIT, NB, 2>(s, a);
 }
 
+// gemm_row4_bf16 (gemm_row4.h): one wave per SIMD, 128- or 160-row workgroups, one per CU.  The tile height that minimises rounds x height
+// (ties: the taller tile -- fewer weight bytes per row): c3 (36.6 k rows) 160 rows = 229 workgroups in one round, the c5 shard (78 k rows) 160 rows =
+// 2 rounds instead of 3, c4 either.  Results do not depend on the height (nor on the kernel: bit-identical to gemm_row8_bf16).
+inline int row4_mt(long rows) {
+    const long r4 = ((rows + 127) / 128 + kCus - 1) / kCus * 128, r5 = ((rows + 159) / 160 + kCus - 1) / kCus * 160;
+    return r5 <= r4 ? 5 : 4;
+}
+// the epilogues it has (gemm_row4.h: EPI); -1: none, the launch stays on gemm_row8_bf16
+inline int row4_epi(const GemmArgs& a) {
+    if (a.ktaps != 1 || a.N != 384 || !a.ln_g || !a.Y || !a.Yp || a.relu_pre || a.dot_w || a.k_groups > 1 || a.ln_groups > 1 || a.qk_hi || a.yp_col_off) return -1;
+    if (a.Cpad % 64 != 0 || a.yp_chunks * 32 != a.N) return -1;      // an even number of k-steps; planes exactly N wide
+    if (a.pe) return (a.act_post == 1 && a.yp_f16 == 0) ? 2 : -1;
+    if (a.act_post != 0) return -1;
+    return a.yp_f16 == 0 ? 0 : (a.yp_f16 == 2 ? 1 : -1);
+}
+template <int MT, int EPI, int SCHED>
+hipError_t launch_row4_t(hipStream_t s, const GemmArgs& a) {
+    static LdsAttr attr;
+    constexpr size_t lds = row4_lds_bytes<3, MT>();
+    allow_lds(reinterpret_cast<const void*>(&gemm_row4_bf16<3, 3, MT, EPI, SCHED>), lds, attr);
+    hipLaunchKernelGGL((gemm_row4_bf16<3, 3, MT, EPI, SCHED>), dim3((a.R + 32 * MT - 1) / (32 * MT)), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+template <int EPI>
+hipError_t launch_row4_e(hipStream_t s, const GemmArgs& a) {
+    const int mt = (opts().mt4 == 4 || opts().mt4 == 5) ? opts().mt4 : row4_mt(rows_in_use(a, a.R));
+    if (opts().sched4) return mt == 5 ? launch_row4_t<5, EPI, 1>(s, a) : launch_row4_t<4, EPI, 1>(s, a);
+    return mt == 5 ? launch_row4_t<5, EPI, 0>(s, a) : launch_row4_t<4, EPI, 0>(s, a);
+}
+hipError_t launch_row4(hipStream_t s, const GemmArgs& a, int epi) {
+    return epi == 0 ? launch_row4_e<0>(s, a) : (epi == 1 ? launch_row4_e<1>(s, a) : launch_row4_e<2>(s, a));
+}
+
 template <int NSPLIT, int NB, int MT, int GROUPS = 1>
 hipError_t launch_row8c_t(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
@@ -516,6 +554,8 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
                 if (a.k_groups > 1) { t.N = a.N / a.k_groups; t.ln_groups = 0; }      // grouped conv: a workgroup row per group (grid.y), N = one group's outputs
                 if (t.N == 384) e = (precision == FS2_PREC_BF16X3) ? launch_row8c<3, 3>(s, t) : launch_row8c<1, 3>(s, t);
                 else e = (precision == FS2_PREC_BF16X3) ? launch_row8c<3, 2>(s, t) : launch_row8c<1, 2>(s, t);
+            } else if (row8 && precision == FS2_PREC_BF16X3 && opts().row4 != 0 && row4_epi(t) >= 0) {
+                e = launch_row4(s, t, row4_epi(t));
             } else if (row8) {
                 if (a.N == 384) e = (precision == FS2_PREC_BF16X3) ? launch_row8<3, 3>(s, t) : launch_row8<1, 3>(s, t);
                 else e = (precision == FS2_PREC_BF16X3) ? launch_row8<3, 2>(s, t) : launch_row8<1, 2>(s, t);
@@ -1599,7 +1639,7 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
         hipLaunchKernelGGL(dur_finalize, dim3((n + 255) / 256), dim3(256), 0, s, dlog_rows, dl.start, dl.vlen, b.B, b.Tmax, io->d_log, dint, io->d_int);
         HIP_TRY(h, hipGetLastError());
         hipLaunchKernelGGL(dur_scan, dim3(b.B), dim3(256), 0, s, io->ds ? io->ds : dint, b.Tmax, dl.vlen, cum, io->olens, o32,
-                           io->duration_alpha > 0.f ? io->duration_alpha : 1.f);
+                           io->duration_alpha > 0.f ? io->duration_alpha : 1.f, io->xs, c.idim);
         HIP_TRY(h, hipGetLastError());
     }
     if (io->enc_out) {
@@ -1659,6 +1699,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     } else {
         int mx = 0;
         for (int i = 0; i < b.B; ++i) {
+            if (io->olens[i] == -1) return fail(h, FS2_ERR_ARG, "utterance %d holds a phoneme id outside [0, %d) (fs2_encode marks it with the frame count -1)", i, h->cfg.idim);
             if (io->olens[i] <= 0) return fail(h, FS2_ERR_ARG, "olens[%d]=%lld", i, (long long)io->olens[i]);
             mx = std::max(mx, (int)io->olens[i]);
         }
@@ -2044,6 +2085,9 @@ int fs2_set_option(const char* name, int32_t value) {
     else if (n == "FS2_FUSE_VAR") o.fuse_var = value != 0;
     else if (n == "FS2_BAL") o.bal = value < 0 ? 0 : value;
     else if (n == "FS2_ATTN_W32") o.w32 = value;
+    else if (n == "FS2_ROW4") o.row4 = value;
+    else if (n == "FS2_MT4") o.mt4 = value;
+    else if (n == "FS2_SCHED4") o.sched4 = value != 0;
     else return fail(nullptr, FS2_ERR_ARG, "fs2_set_option: unknown option %s", name);
     return FS2_OK;
 }

@@ -1,0 +1,400 @@
+// gemm_row4_bf16: the row-complete k = 1 GEMM + LayerNorm of the decoder (out-proj + LN1, FFN2 + LN2, the decoder input layer;
+// reference core/encoder.py:60-69,118-125, core/modules.py:248, core/attention.py:71-74) with ONE wavefront per SIMD and the whole
+// 512-entry register file: 4 waves as 2(M) x 2(N), wave tile 16 MT rows x 64 NB columns, workgroup tile BM = 32 MT rows x all
+// N = 128 NB columns.  Same operands, LDS images, lane -> row / column permutations and per-accumulator MFMA order as
+// gemm_row8_bf16 (gemm_planes.h), so the results are bit-identical to it for every tile height.
+//
+// Why a second structure.  gemm_row8_bf16 holds 128 rows per workgroup in 8 waves x 96 accumulators; its
+// 192-row form (144 accumulators, 256 registers: 42 spilled) was the only way to run c3's 36.6 k rows in one round of workgroups
+// and cost 1.4-1.9 x a 128-row tile.  With 512 registers per wave a 160-row tile is 240 accumulators and nothing spills: c3 runs
+// 229 workgroups of 160 rows (one round on 89 % of the CUs) instead of 191 of 192 rows on 75 %, the c5 shard 2 rounds instead
+// of 3.  The launcher picks the tile height that minimises rounds x height (fs2_runtime.hip: row4_mt).
+//
+// The accumulators never appear as compiler values.  Left to hipcc (f32x4 acc[MT][NT] and the MFMA builtins under
+// __launch_bounds__(256, 1)) the 192 / 240 accumulators were split between the two register files, copied with v_accvgpr_* around
+// every group of MFMAs and spilled to scratch INSIDE the k-loop (127 - 821 registers spilled; the experience of attn_w32.h once more).
+// Here accumulator tuple T = mt NT + n IS a[4 T : 4 T + 3], named literally in the MFMA / v_accvgpr statements below and listed
+// as their clobbers; the compiler keeps only the fragments and addresses (< 256 architectural registers, no AGPR of its own).
+// tools/probes/audit_rows.py checks the generated ISA after every edit: no compiler v_accvgpr_*, no scratch.
+//
+// A wave that is alone on its SIMD has nobody to cover its stalls, so the k-loop is software-pipelined by hand:
+//   * a k-step = NT / 2 groups of 6 MT MFMAs (one pair of n-tiles each); the B fragments of pair p + 1 are requested before the
+//     MFMAs of pair p (register double buffer);
+//   * the step's ONE barrier sits in front of its LAST group: behind it (every wave has fetched all fragments of stage `it`, and
+//     stage it + 1 has landed everywhere) the A fragments and the first B pair of step it + 1 are requested and the LDS-DMA of
+//     stage it + 2 starts -- all of it under the last group's MFMAs, so the matrix pipe never drains at a step boundary;
+//   * the 4 NB + MT one-KB LDS-DMA pieces a wave issues per stage are dealt out between MFMAs (a piece costs its wave ~60 cycles
+//     of issue, which only the MFMAs already in the pipe cover): SCHED = 1 spreads them over the last group of a step and the
+//     first two of the next, SCHED = 0 issues them in one burst behind the barrier.
+#pragma once
+#include <type_traits>
+#include "gemm_planes.h"
+
+namespace fs2 {
+
+// compile-time loop: f(integral_constant<int, LO>) ... f(integral_constant<int, HI - 1>)
+template <int LO, int HI, class F>
+__device__ __forceinline__ void for_seq_i(F&& f) {
+    if constexpr (LO < HI) { f(std::integral_constant<int, LO>{}); for_seq_i<LO + 1, HI>(f); }
+}
+
+// accumulator tuple T = a[4 T : 4 T + 3] (X-macro: tuple index, its four registers)
+#define FS2_ACC_TUPLES(X) \
+    X(0, 0, 1, 2, 3) X(1, 4, 5, 6, 7) X(2, 8, 9, 10, 11) X(3, 12, 13, 14, 15) \
+    X(4, 16, 17, 18, 19) X(5, 20, 21, 22, 23) X(6, 24, 25, 26, 27) X(7, 28, 29, 30, 31) \
+    X(8, 32, 33, 34, 35) X(9, 36, 37, 38, 39) X(10, 40, 41, 42, 43) X(11, 44, 45, 46, 47) \
+    X(12, 48, 49, 50, 51) X(13, 52, 53, 54, 55) X(14, 56, 57, 58, 59) X(15, 60, 61, 62, 63) \
+    X(16, 64, 65, 66, 67) X(17, 68, 69, 70, 71) X(18, 72, 73, 74, 75) X(19, 76, 77, 78, 79) \
+    X(20, 80, 81, 82, 83) X(21, 84, 85, 86, 87) X(22, 88, 89, 90, 91) X(23, 92, 93, 94, 95) \
+    X(24, 96, 97, 98, 99) X(25, 100, 101, 102, 103) X(26, 104, 105, 106, 107) X(27, 108, 109, 110, 111) \
+    X(28, 112, 113, 114, 115) X(29, 116, 117, 118, 119) X(30, 120, 121, 122, 123) X(31, 124, 125, 126, 127) \
+    X(32, 128, 129, 130, 131) X(33, 132, 133, 134, 135) X(34, 136, 137, 138, 139) X(35, 140, 141, 142, 143) \
+    X(36, 144, 145, 146, 147) X(37, 148, 149, 150, 151) X(38, 152, 153, 154, 155) X(39, 156, 157, 158, 159) \
+    X(40, 160, 161, 162, 163) X(41, 164, 165, 166, 167) X(42, 168, 169, 170, 171) X(43, 172, 173, 174, 175) \
+    X(44, 176, 177, 178, 179) X(45, 180, 181, 182, 183) X(46, 184, 185, 186, 187) X(47, 188, 189, 190, 191) \
+    X(48, 192, 193, 194, 195) X(49, 196, 197, 198, 199) X(50, 200, 201, 202, 203) X(51, 204, 205, 206, 207) \
+    X(52, 208, 209, 210, 211) X(53, 212, 213, 214, 215) X(54, 216, 217, 218, 219) X(55, 220, 221, 222, 223) \
+    X(56, 224, 225, 226, 227) X(57, 228, 229, 230, 231) X(58, 232, 233, 234, 235) X(59, 236, 237, 238, 239) \
+    X(60, 240, 241, 242, 243) X(61, 244, 245, 246, 247) X(62, 248, 249, 250, 251) X(63, 252, 253, 254, 255)
+
+// acc[T] += A.B   (v_mfma_f32_16x16x32_bf16, fragments in architectural registers)
+template <int T>
+__device__ __forceinline__ void acc_mfma(const bf16x8_t& fa, const bf16x8_t& fb) {
+#define X(t, r0, r1, r2, r3) if constexpr (T == t) asm volatile("v_mfma_f32_16x16x32_bf16 a[" #r0 ":" #r3 "], %0, %1, a[" #r0 ":" #r3 "]" : : "v"(fa), "v"(fb) : "a" #r0, "a" #r1, "a" #r2, "a" #r3);
+    FS2_ACC_TUPLES(X)
+#undef X
+}
+// acc[T] = v
+template <int T>
+__device__ __forceinline__ void acc_set(const f32x4& v) {
+#define X(t, r0, r1, r2, r3) if constexpr (T == t) asm volatile("v_accvgpr_write_b32 a" #r0 ", %0\n\tv_accvgpr_write_b32 a" #r1 ", %1\n\tv_accvgpr_write_b32 a" #r2 ", %2\n\tv_accvgpr_write_b32 a" #r3 ", %3" : : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a" #r0, "a" #r1, "a" #r2, "a" #r3);
+    FS2_ACC_TUPLES(X)
+#undef X
+}
+// v = acc[T]   (the caller has drained the matrix pipe: acc_drain)
+template <int T>
+__device__ __forceinline__ f32x4 acc_get() {
+    float x0, x1, x2, x3;
+#define X(t, r0, r1, r2, r3) if constexpr (T == t) asm volatile("v_accvgpr_read_b32 %0, a" #r0 "\n\tv_accvgpr_read_b32 %1, a" #r1 "\n\tv_accvgpr_read_b32 %2, a" #r2 "\n\tv_accvgpr_read_b32 %3, a" #r3 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3));
+    FS2_ACC_TUPLES(X)
+#undef X
+    return f32x4{x0, x1, x2, x3};
+}
+__device__ __forceinline__ void acc_drain() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory"); }      // 20 states: the last 8-pass MFMA's result is readable
+
+template <int NB, int MT> constexpr size_t row4_lds_bytes() { return 2 * (size_t)(32 * MT + 128 * NB) * 128; }
+
+// Phase stamps for tools/probes/row_probe.hip (compiled only with -DFS2_ROW_TIMING): shader cycles of wave 0 of a few workgroups at
+// [0] entry, [1] first stage + residual landed, [2] k-loop done, [3] LayerNorm statistics done, [4] stores issued; [5] = s_memrealtime span.
+#ifdef FS2_ROW_TIMING
+__device__ long long g_row_phase[8][8];
+#define FS2_RT(i) { if (threadIdx.x == 0 && (blockIdx.x & 31) == 0 && (blockIdx.x >> 5) < 8) g_row_phase[blockIdx.x >> 5][i] = __builtin_readcyclecounter(); }
+#else
+#define FS2_RT(i)
+#endif
+
+// EPI (compile time: the epilogue is unrolled over the accumulator tuples, and every launch-uniform choice left to run time would sit in that
+// instruction stream 12 MT times -- the first build, with gemm_row8_bf16's run-time switches, was 400 KB of code): 0 = LayerNorm -> fp32 rows +
+// split-bf16 planes (FFN2 + LN2; out-proj + LN1 in bf16x3 mode), 1 = LayerNorm -> fp32 rows + mx planes (out-proj + LN1 in mix_mx mode),
+// 2 = LayerNorm -> ReLU -> x_scale v + alpha pe -> fp32 rows + split-bf16 planes (the decoder input layer).  Everything else stays on gemm_row8_bf16
+// (fs2_runtime.hip: use_row4).
+template <int NSPLIT, int NB, int MT, int EPI = 0, int SCHED = 1>
+__global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
+    constexpr int NT = 4 * NB, NP = NT / 2, BM = 32 * MT, BN = 128 * NB, RW = 16 * MT;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int PIECES = MT + 4 * NB;                       // one-KB LDS-DMA pieces per wave and stage: A pieces first (they come from HBM), then B
+    // pieces issued behind the barrier (last group of a step) | in the first | second group of the next step
+    constexpr int kPL = SCHED ? (PIECES + 2) / 3 : PIECES, kP0 = SCHED ? (PIECES - kPL + 1) / 2 : 0, kP1 = PIECES - kPL - kP0;
+    static_assert(NP >= 3 && NP % 2 == 0, "an even number of n-tile pairs per wave (N = 256 or 384)");
+    extern __shared__ __attribute__((aligned(16))) char smem_q[];
+    FS2_RT(0)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM;
+    if (a.Rp != nullptr && m0 >= ((*a.Rp + 127) & ~127)) return;      // device-driven layout: tile beyond the rows in use
+    const int lr = lane & 15, lg = lane >> 4;
+    const int lp = rperm(lr);
+    const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
+    const __bf16* Xp = reinterpret_cast<const __bf16*>(a.Xp);
+    const int niter = a.Cpad / 32;
+    const int jrow = lane >> 3, jslot = lane & 7;
+
+    // A: piece i of wave w fills tile rows 32 i + 8 w + jrow (piece index q = w + 4 i, q & 1 == w & 1: the swizzle term is a per-lane constant)
+    const int sA = jslot ^ (jrow >> 1) ^ ((wave & 1) << 2);
+    const int arow0 = m0 + wave * 8 + jrow;
+    const __bf16* a_src0 = Xp + (size_t)arow0 * niter * 64 + sA * 8;
+    const size_t a_qstride = (size_t)32 * niter * 64;
+    // B: piece u of wave w (q = w + 4 u) fills LDS rows 32 u + 8 w + jrow = n-tile 2 u + (w >> 1), tile row jB; that row belongs to
+    // weight row 64 (u >> 1) + 4 rperm_inv(jB) + 2 (u & 1) + (w >> 1) (gemm_planes.h: four consecutive channels per lane)
+    const int jB = (wave & 1) * 8 + jrow;
+    const int sB = jslot ^ ((jB >> 1) & 7);
+    const __bf16* b_src0 = Wb + ((size_t)(4 * rperm_inv(jB) + (wave >> 1)) * niter) * 64 + sB * 8;
+    const size_t b_o1 = (size_t)2 * niter * 64, b_o2 = (size_t)64 * niter * 64;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t*)smem_q);
+    const unsigned ldsw = lds0 + wave * 1024;
+    // piece k (compile time) of stage `it` into ring slot `buf`
+    auto piece = [&](auto k_tag, int it, int buf) __attribute__((always_inline)) {
+        constexpr int k = decltype(k_tag)::value;
+        if constexpr (k < MT) {
+            const bool ok = arow0 + 32 * k < a.R;
+            const void* sp = ok ? static_cast<const void*>(a_src0 + (size_t)it * 64 + k * a_qstride) : static_cast<const void*>(g_zero16);
+            dma16(sp, ldsw + buf * STAGE + k * 4096);
+        } else {
+            constexpr int u = k - MT;
+            dma16(b_src0 + (size_t)it * 64 + (u & 1) * b_o1 + (u >> 1) * b_o2, ldsw + buf * STAGE + BM * 128 + u * 4096);
+        }
+    };
+    auto pieces = [&](auto lo_tag, auto hi_tag, int it, int buf) __attribute__((always_inline)) {
+        constexpr int lo = decltype(lo_tag)::value, hi = decltype(hi_tag)::value;
+        for_seq_i<lo, hi>([&](auto k_tag) __attribute__((always_inline)) { piece(k_tag, it, buf); });
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using IPL = std::integral_constant<int, kPL>;
+    using IP0 = std::integral_constant<int, kPL + kP0>;
+    using IPA = std::integral_constant<int, PIECES>;
+
+    pieces(I0{}, IPA{}, 0, 0);
+    // accumulators start at bias + residual (loaded under the first DMA round trip): acc[mt][4 g + j][r] is channel col0 + 64 g + j of tile row (mt, r)
+    const int col0 = wn * (64 * NB) + 4 * lr;
+    const int rowb = m0 + wm * RW;
+    int rp[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rp[r] = rperm(lg * 4 + r);
+    // (residual rows of m-tile mt + 1 are requested before those of m-tile mt go into the accumulators: one exposed round trip, 24 NB registers)
+    static_assert(MT * NT <= 64, "the accumulators are a[0 : 4 MT NT)");
+    f32x4 rv[2][NB][4];
+    auto load_resid = [&](auto mt_tag) __attribute__((always_inline)) {
+        constexpr int mt = decltype(mt_tag)::value;
+#pragma unroll
+        for (int g = 0; g < NB; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rowb + mt * 16 + rp[r];
+                rv[mt & 1][g][r] = load4_or_zero(a.resid + (size_t)row * a.ldr + col0 + 64 * g, a.resid != nullptr && row < a.R);
+            }
+    };
+    f32x4 bv[NB];
+#pragma unroll
+    for (int g = 0; g < NB; ++g) bv[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + col0 + 64 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+    load_resid(I0{});
+    for_seq_i<0, MT>([&](auto mt_tag) __attribute__((always_inline)) {
+        constexpr int mt = decltype(mt_tag)::value;
+        if constexpr (mt + 1 < MT) load_resid(std::integral_constant<int, mt + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        for_seq_i<0, NB>([&](auto g_tag) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_tag)::value;
+            f32x4 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = bv[g] + rv[mt & 1][g][r];
+            for_seq_i<0, 4>([&](auto j_tag) __attribute__((always_inline)) {      // tuple (mt, 4 g + j): register r = row r, channel col0 + 64 g + j
+                constexpr int j = decltype(j_tag)::value;
+                acc_set<mt * NT + 4 * g + j>(f32x4{v[0][j], v[1][j], v[2][j], v[3][j]});
+            });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+
+    // fragment addresses: one base per operand half, everything else is an immediate (the swizzle term does not depend on the m- / n-tile)
+    const char* ap0 = smem_q + swz(wm * RW + lp, lg);
+    const char* ap1 = smem_q + swz(wm * RW + lp, 4 + lg);
+    const char* bp0 = smem_q + BM * 128 + swz(wn * (64 * NB) + lp, lg);
+    const char* bp1 = smem_q + BM * 128 + swz(wn * (64 * NB) + lp, 4 + lg);
+    struct AFrag { bf16x8_t h[MT], l[MT]; };
+    struct BPair { bf16x8_t h[2], l[2]; };
+    auto load_A = [&](AFrag& f, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f.h[mt] = *reinterpret_cast<const bf16x8_t*>(ap0 + buf * STAGE + mt * 2048);
+            if (NSPLIT == 3) f.l[mt] = *reinterpret_cast<const bf16x8_t*>(ap1 + buf * STAGE + mt * 2048);
+        }
+    };
+    auto load_B = [&](BPair& f, int buf, int n2) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f.h[u] = *reinterpret_cast<const bf16x8_t*>(bp0 + buf * STAGE + (n2 + u) * 2048);
+            if (NSPLIT == 3) f.l[u] = *reinterpret_cast<const bf16x8_t*>(bp1 + buf * STAGE + (n2 + u) * 2048);
+        }
+    };
+    // the MFMAs of one group (n-tiles n2, n2 + 1), flat index m = 0 .. in gemm_row8_bf16's order (per accumulator: lo.hi, hi.lo, hi.hi);
+    // after MFMA number m the callback `between(m)` may issue something else (a DMA piece).  asm volatile: issued in program order.
+    auto mfma_group = [&](const AFrag& fa, const BPair& fb, auto n2_tag, auto&& between) __attribute__((always_inline)) {
+        constexpr int n2 = decltype(n2_tag)::value;
+        for_seq_i<0, (NSPLIT == 3 ? 6 : 2) * MT>([&](auto m_tag) __attribute__((always_inline)) {
+            constexpr int m = decltype(m_tag)::value;
+            constexpr int blk = m / (2 * MT), u = (m % (2 * MT)) / MT, mt = m % MT;
+            constexpr int T = mt * NT + n2 + u;
+            if constexpr (NSPLIT == 3) {
+                if constexpr (blk == 0) acc_mfma<T>(fa.l[mt], fb.h[u]);
+                else if constexpr (blk == 1) acc_mfma<T>(fa.h[mt], fb.l[u]);
+                else acc_mfma<T>(fa.h[mt], fb.h[u]);
+            } else {
+                acc_mfma<T>(fa.h[mt], fb.h[u]);
+            }
+            between(m_tag);
+        });
+    };
+    // deal the pieces [first, first + cnt) of stage `it` (ring slot buf) out evenly over a group's MFMAs: piece j goes behind MFMA number
+    // floor((j + 1) gm / (cnt + 1)) - 1.  `between` callback of mfma_group.
+    auto deal = [&](auto m_tag, auto first_tag, auto cnt_tag, int it, int buf) __attribute__((always_inline)) {
+        constexpr int first = decltype(first_tag)::value, cnt = decltype(cnt_tag)::value, m = decltype(m_tag)::value;
+        constexpr int gm = (NSPLIT == 3 ? 6 : 2) * MT;
+        for_seq_i<0, cnt>([&](auto j_tag) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_tag)::value;
+            constexpr int raw = ((j + 1) * gm) / (cnt + 1) - 1, slot = raw < 0 ? 0 : (raw > gm - 1 ? gm - 1 : raw);
+            if constexpr (slot == m) {
+                __builtin_amdgcn_sched_barrier(0);
+                piece(std::integral_constant<int, first + j>{}, it, buf);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+    auto nothing = [](auto) __attribute__((always_inline)) {};
+    using IK0 = std::integral_constant<int, kP0>;
+    using IK1 = std::integral_constant<int, kP1>;
+
+    // ---- prologue of the pipeline: stage 0 landed; request the first fragments; start stage 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    FS2_RT(1)
+    AFrag fa0, fa1;
+    BPair fb0, fb1;
+    load_A(fa0, 0);
+    load_B(fb0, 0, 0);
+    pieces(I0{}, IPL{}, 1, 1);
+
+    // one k-step: fragments of step `it` in (fc: A, fb0: first B pair); leaves those of step it + 1 in (fn, fb0).  MORE1 / MORE2 (compile
+    // time): stages it + 1 / it + 2 exist -- the loop's last two steps are instantiations of their own, so no DMA piece sits behind a branch.
+    auto k_step = [&](AFrag& fc, AFrag& fn, int it, auto more1_tag, auto more2_tag) __attribute__((always_inline)) {
+        constexpr bool MORE1 = decltype(more1_tag)::value, MORE2 = decltype(more2_tag)::value;
+        const int cur = it & 1;
+        for_seq_i<0, NP>([&](auto p_tag) __attribute__((always_inline)) {
+            constexpr int p = decltype(p_tag)::value;
+            BPair& fthis = (p & 1) ? fb1 : fb0;
+            BPair& fnext = (p & 1) ? fb0 : fb1;
+            using N2 = std::integral_constant<int, 2 * p>;
+            if constexpr (p + 1 < NP) {
+                load_B(fnext, cur, 2 * (p + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (p == 0 && MORE1 && kP0 > 0) mfma_group(fc, fthis, N2{}, [&](auto m_tag) __attribute__((always_inline)) { deal(m_tag, IPL{}, IK0{}, it + 1, cur ^ 1); });
+                else if constexpr (p == 1 && MORE1 && kP1 > 0) mfma_group(fc, fthis, N2{}, [&](auto m_tag) __attribute__((always_inline)) { deal(m_tag, IP0{}, IK1{}, it + 1, cur ^ 1); });
+                else mfma_group(fc, fthis, N2{}, nothing);
+            } else {
+                // every fragment of stage `it` is in registers (the last pair was requested a group ago); stage it + 1 must have landed everywhere
+                if constexpr (MORE1) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    load_A(fn, cur ^ 1);
+                    load_B(fnext, cur ^ 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MORE2) mfma_group(fc, fthis, N2{}, [&](auto m_tag) __attribute__((always_inline)) { deal(m_tag, I0{}, IPL{}, it + 2, cur); });
+                else mfma_group(fc, fthis, N2{}, nothing);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    // (niter is even and >= 2: the launcher checks)
+    int it = 0;
+    for (; it + 2 < niter; it += 2) {
+        k_step(fa0, fa1, it, std::true_type{}, std::true_type{});
+        k_step(fa1, fa0, it + 1, std::true_type{}, std::true_type{});
+    }
+    k_step(fa0, fa1, it, std::true_type{}, std::false_type{});
+    k_step(fa1, fa0, it + 1, std::false_type{}, std::false_type{});
+    FS2_RT(2)
+
+    // ---- epilogue (gemm_row8_bf16's arithmetic): the rows stay in the accumulator file and are read three times -- row sums, centred sums of
+    // squares (completed across the two N-waves through LDS), then normalise + affine (+ ReLU + positional encoding) on the way out
+    acc_drain();
+    const int* __restrict__ rpos = a.row_pos;
+    float* __restrict__ Y = a.Y;
+    void* __restrict__ Yp = a.Yp;
+    float* red = reinterpret_cast<float*>(smem_q);      // [2 passes][4 waves][RW rows]
+    float mean[MT][4], rstd[MT][4];
+    {
+        float rsum[MT][4];
+        for_seq_i<0, MT>([&](auto mt_tag) __attribute__((always_inline)) {
+            constexpr int mt = decltype(mt_tag)::value;
+            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+            for_seq_i<0, NT>([&](auto n_tag) __attribute__((always_inline)) { s += acc_get<mt * NT + decltype(n_tag)::value>(); });
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rsum[mt][r] = wave16_sum(s[r]);
+        });
+        __syncthreads();                                // operand buffers are dead
+        if (lr == 0)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * RW + mt * 16 + lg * 4 + r] = rsum[mt][r];
+        __syncthreads();
+        for_seq_i<0, MT>([&](auto mt_tag) __attribute__((always_inline)) {
+            constexpr int mt = decltype(mt_tag)::value;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mean[mt][r] = (rsum[mt][r] + red[(wave ^ 1) * RW + mt * 16 + lg * 4 + r]) / (float)a.N;
+            f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+            for_seq_i<0, NT>([&](auto n_tag) __attribute__((always_inline)) {
+                const f32x4 x = acc_get<mt * NT + decltype(n_tag)::value>();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = x[r] - mean[mt][r]; q[r] += d * d; }
+            });
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rsum[mt][r] = wave16_sum(q[r]);
+        });
+        if (lr == 0)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[4 * RW + wave * RW + mt * 16 + lg * 4 + r] = rsum[mt][r];
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                rstd[mt][r] = 1.f / sqrtf((rsum[mt][r] + red[4 * RW + (wave ^ 1) * RW + mt * 16 + lg * 4 + r]) / (float)a.N + a.ln_eps);
+    }
+    FS2_RT(3)
+    constexpr bool PE = EPI == 2;
+    const float alpha = (PE && a.pe_alpha) ? a.pe_alpha[0] : 1.f;
+    f32x4 gam[NB], bet[NB];
+#pragma unroll
+    for (int g = 0; g < NB; ++g) { gam[g] = *reinterpret_cast<const f32x4*>(a.ln_g + col0 + 64 * g); bet[g] = *reinterpret_cast<const f32x4*>(a.ln_b + col0 + 64 * g); }
+    for_seq_i<0, MT>([&](auto mt_tag) __attribute__((always_inline)) {
+        constexpr int mt = decltype(mt_tag)::value;
+        int pos[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {           // (the four loads go out together, as address selects: see load4_or_zero)
+            const int row = rowb + mt * 16 + rp[r];
+            const int pv = loadi_or_zero(rpos + row, rpos != nullptr && row < a.R);
+            pos[r] = row < a.R ? pv : -1;
+        }
+        for_seq_i<0, NB>([&](auto g_tag) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_tag)::value;
+            const int col = col0 + 64 * g;
+            f32x4 x[4];      // x[j][r]: channel col + j of row r
+            for_seq_i<0, 4>([&](auto j_tag) __attribute__((always_inline)) { x[decltype(j_tag)::value] = acc_get<mt * NT + 4 * g + decltype(j_tag)::value>(); });
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rowb + mt * 16 + rp[r];
+                const bool live = pos[r] >= 0;
+                f32x4 pe4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (PE) pe4 = load4_or_zero(a.pe + (size_t)(live ? pos[r] : 0) * a.pe_ld + col, live);
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = (x[j][r] - mean[mt][r]) * rstd[mt][r];
+                    t = t * gam[g][j] + bet[g][j];
+                    if (PE) { t = fmaxf(t, 0.f); t = t * a.x_scale + alpha * pe4[j]; }
+                    v[j] = live ? t : 0.f;
+                }
+                if (row < a.R) {
+                    *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
+                    if constexpr (EPI == 1) store_planes4_mx(Yp, row, a.yp_chunks, col, v, a.yp_scale);
+                    else store_planes4(Yp, row, a.yp_chunks, col, v);
+                }
+            }
+        });
+    });
+    FS2_RT(4)
+}
+
+}  // namespace fs2

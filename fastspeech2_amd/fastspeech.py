@@ -28,6 +28,15 @@ class Fs2CapacityError(RuntimeError):
     """A capacity of the device-driven frame layout was too small: the mels of that call are NaN-filled (invalid)."""
 
 
+FS2_OVF_BAD_ID = 16      # include/fs2.h: an utterance holds a phoneme id outside [0, idim)
+
+
+class Fs2IndexError(IndexError):
+    """A phoneme id outside [0, idim): what torch.nn.Embedding raises for in the reference (fastspeech.py:65-67, core/encoder.py:196).  The
+    synchronous entry points raise it before any mel is returned; an asynchronous call reports it through ``AsyncMels.check()`` /
+    ``model.async_ok()`` / ``ShardedSynthesizer.ok()`` (its mels are NaN-filled)."""
+
+
 class AsyncMels(tuple):
     """What ``inference_batch(sync=False)`` returns: unpacks like ``(mels, olens_dev)`` and carries the call's own validity
     record.  ``status`` is the device int32[8] of fs2_decode ({rows, work items, overflow flags, longest utterance, valid frames,
@@ -45,8 +54,11 @@ class AsyncMels(tuple):
 
     def check(self):
         if not self.ok():
+            fl = self._record.flags(block=True)
+            if fl & FS2_OVF_BAD_ID:
+                raise Fs2IndexError("a phoneme id of this batch lies outside [0, idim) (status flags %d); the mels of the call are NaN-filled" % fl)
             raise Fs2CapacityError("device-driven layout overflow (flags %d): rerun this batch with sync=True or a larger "
-                                   "capacity" % self._record.flags(block=True))
+                                   "capacity" % fl)
         return self
 
 
@@ -485,6 +497,9 @@ class FeedForwardTransformer(nn.Module):
                     out["encoder_out"] = enc_out
                 return out
             ol = olens_dev.cpu()                     # the one host sync of the path (frame counts)
+            if int(ol.min()) < 0:                    # fs2_encode's marker (include/fs2.h: olens = -1)
+                bad = [i for i, v in enumerate(ol.tolist()) if v < 0]
+                raise Fs2IndexError("index out of range in self: utterance(s) %s hold a phoneme id outside [0, %d)" % (bad, self.idim))
             self.last_olens = ol
             if olens is not None:
                 given = torch.as_tensor(olens).detach().to("cpu", torch.int64)

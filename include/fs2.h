@@ -120,7 +120,11 @@ typedef struct fs2_encode_io {
     float *d_log;             /* device [B, Tmax] log-domain predictor output, pads = 0, or NULL */
     int64_t *d_int;           /* device [B, Tmax] clamp(round(exp(y)-1),0), pads = 0, or NULL    */
     int64_t *olens;           /* device [B] frames per utterance = sum of the durations used
-                                 (an all-zero row counts as all ones, length_regulator.py:86-88) */
+                                 (an all-zero row counts as all ones, length_regulator.py:86-88);
+                                 -1 for an utterance that holds a phoneme id outside [0, idim): the
+                                 reference's nn.Embedding raises there (fastspeech.py:65-67), a caller
+                                 of the host-driven layout must too (fs2_decode refuses the value), the
+                                 device-driven layout reports FS2_OVF_BAD_ID                     */
     float *enc_out;           /* device [B, Tmax, adim] encoder output, pads = 0, or NULL        */
     void *workspace;          /* device, fs2_token_workspace_bytes(); must stay alive and
                                  untouched until the matching fs2_decode returns                 */
@@ -170,6 +174,8 @@ typedef struct fs2_decode_io {
 #define FS2_OVF_LMAX 2        /* an utterance is longer than Lmax                                            */
 #define FS2_OVF_PE 4          /* an utterance is longer than the decoder's positional table                  */
 #define FS2_OVF_EMPTY 8       /* an utterance has no frames                                                  */
+#define FS2_OVF_BAD_ID 16     /* an utterance holds a phoneme id outside [0, idim): fs2_encode left the frame count -1
+                                 for it (the reference's torch.nn.Embedding raises, fastspeech.py:65-67)                */
 
 /* rows to reserve for fs2_decode's device-driven layout given an estimate of the total frame count (alignment
  * and gap rows of the packed layout included) */

@@ -1,0 +1,158 @@
+// gemm_row4_bf16 (one wave per SIMD, accumulators in literal AGPRs) against gemm_row8_bf16 on synthetic operands: bit-for-bit comparison of
+// the fp32 rows and the planes, and launch times at a given shape.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I fastspeech2_amd/csrc tools/probes/row_probe.hip -o tools/probes/row_probe.bin
+//   (-DFS2_ROW_TIMING: phase stamps of gemm_row4_bf16, printed per sampled workgroup)
+//   row_probe.bin R C [reps]      N = 384; C = 384 (out-proj + LN, decoder input layer) or 1024 (FFN2 + LN)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include "gemm_row4.h"
+using namespace fs2;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+static unsigned short bf16_of(float v) { unsigned u; memcpy(&u, &v, 4); u += 0x7fff + ((u >> 16) & 1); return (unsigned short)(u >> 16); }
+static float f_of(unsigned short h) { unsigned u = (unsigned)h << 16; float v; memcpy(&v, &u, 4); return v; }
+
+struct Bufs { float* y; void* yp; };
+
+template <class K>
+static float time_kernel(K launch, int reps) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) launch(i);
+    CK(hipDeviceSynchronize());
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) launch(i);
+    hipEventRecord(e1); CK(hipDeviceSynchronize());
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e3f / reps;
+}
+
+template <int MT>
+static void launch_row8(const GemmArgs& a) {
+    constexpr size_t lds = row8_lds_bytes<3, MT>();
+    static bool done = false;
+    if (!done) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_row8_bf16<3, 3, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    hipLaunchKernelGGL((gemm_row8_bf16<3, 3, MT>), dim3((a.R + 64 * MT - 1) / (64 * MT)), dim3(512), lds, 0, a);
+}
+template <int MT, int EPI, int SCHED>
+static void launch_row4(const GemmArgs& a) {
+    constexpr size_t lds = row4_lds_bytes<3, MT>();
+    static bool done = false;
+    if (!done) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_row4_bf16<3, 3, MT, EPI, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    hipLaunchKernelGGL((gemm_row4_bf16<3, 3, MT, EPI, SCHED>), dim3((a.R + 32 * MT - 1) / (32 * MT)), dim3(256), lds, 0, a);
+}
+
+static size_t compare(const char* what, const void* d_ref, const void* d_got, size_t bytes) {
+    std::vector<unsigned> r(bytes / 4), g(bytes / 4);
+    CK(hipMemcpy(r.data(), d_ref, bytes, hipMemcpyDeviceToHost)); CK(hipMemcpy(g.data(), d_got, bytes, hipMemcpyDeviceToHost));
+    size_t bad = 0, first = (size_t)-1;
+    for (size_t i = 0; i < r.size(); ++i) if (r[i] != g[i]) { if (!bad) first = i; ++bad; }
+    printf("    %-8s %zu of %zu words differ%s", what, bad, r.size(), bad ? "" : "\n");
+    if (bad) printf(" (first at word %zu: %08x vs %08x)\n", first, r[first], g[first]);
+    return bad;
+}
+
+int main(int argc, char** argv) {
+    const int R = argc > 1 ? atoi(argv[1]) : 36611, C = argc > 2 ? atoi(argv[2]) : 384, reps = argc > 3 ? atoi(argv[3]) : 20;
+    const int N = 384, nchunks = C / 32;
+    const int Rpad = (R + 191) / 192 * 192 + 192;
+    srand(12345);
+    // A planes [Rpad][nchunks][hi 32 | lo 32] and the weight image [N][nchunks][hi 32 | lo 32]: any finite bf16 pairs (hi + small lo)
+    auto fill_planes = [&](std::vector<unsigned short>& h, size_t rows, float amp) {
+        h.resize(rows * nchunks * 64);
+        for (size_t i = 0; i < rows * nchunks; ++i)
+            for (int k = 0; k < 32; ++k) {
+                const float v = amp * ((rand() & 0xffff) - 32768) / 32768.f;
+                const unsigned short hi = bf16_of(v);
+                h[i * 64 + k] = hi;
+                h[i * 64 + 32 + k] = bf16_of(v - f_of(hi));
+            }
+    };
+    std::vector<unsigned short> hx, hw;
+    fill_planes(hx, Rpad, 1.f);
+    fill_planes(hw, N, 0.06f);
+    std::vector<float> hres((size_t)Rpad * N), hb(N), hg(N), hbe(N), hpe((size_t)1024 * N);
+    for (auto& v : hres) v = ((rand() & 0xffff) - 32768) / 32768.f;
+    for (int i = 0; i < N; ++i) { hb[i] = 0.01f * (i % 7); hg[i] = 0.8f + 0.001f * i; hbe[i] = 0.02f * (i % 5) - 0.03f; }
+    for (auto& v : hpe) v = ((rand() & 0xffff) - 32768) / 32768.f;
+    std::vector<int> hpos(Rpad);
+    for (int r = 0; r < Rpad; ++r) hpos[r] = (r % 509 < 8 || r >= R) ? -1 : (r % 509) - 8;      // an "utterance" of 501 rows behind every 8 gap rows
+    void *xp[2], *wb; float *res[2], *bias, *g, *be, *pe, *alpha; int* pos;
+    for (int s = 0; s < 2; ++s) {
+        CK(hipMalloc(&xp[s], hx.size() * 2)); CK(hipMemcpy(xp[s], hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMalloc(&res[s], hres.size() * 4)); CK(hipMemcpy(res[s], hres.data(), hres.size() * 4, hipMemcpyHostToDevice));
+    }
+    CK(hipMalloc(&wb, hw.size() * 2)); CK(hipMemcpy(wb, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&bias, N * 4)); CK(hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&g, N * 4)); CK(hipMemcpy(g, hg.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&be, N * 4)); CK(hipMemcpy(be, hbe.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&pe, hpe.size() * 4)); CK(hipMemcpy(pe, hpe.data(), hpe.size() * 4, hipMemcpyHostToDevice));
+    const float al = 0.9f;
+    CK(hipMalloc(&alpha, 4)); CK(hipMemcpy(alpha, &al, 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&pos, Rpad * 4)); CK(hipMemcpy(pos, hpos.data(), Rpad * 4, hipMemcpyHostToDevice));
+    const size_t ybytes = (size_t)Rpad * N * 4;
+    Bufs ref, out[2];
+    CK(hipMalloc(&ref.y, ybytes)); CK(hipMalloc(&ref.yp, ybytes));
+    for (int s = 0; s < 2; ++s) { CK(hipMalloc(&out[s].y, ybytes)); CK(hipMalloc(&out[s].yp, ybytes)); }
+
+    auto args = [&](int epi, int set, const Bufs& o) {
+        GemmArgs a;
+        memset(&a, 0, sizeof a);
+        a.C = C; a.Cpad = C; a.ktaps = 1; a.N = N; a.R = R; a.W = (const float*)wb; a.Wb = wb; a.Xp = xp[set]; a.row_pos = pos;
+        a.bias = bias; a.resid = epi == 2 ? nullptr : res[set]; a.ldr = N; a.ln_g = g; a.ln_b = be; a.ln_eps = 1e-5f;
+        a.Y = o.y; a.ldy = N; a.Yp = o.yp; a.yp_chunks = N / 32; a.x_scale = 1.f;
+        if (epi == 1) { a.yp_f16 = 2; a.yp_scale = 8.f; }
+        if (epi == 2) { a.act_post = 1; a.pe = pe; a.pe_ld = N; a.pe_alpha = alpha; a.x_scale = 1.25f; }
+        return a;
+    };
+    const double flop = 2.0 * R * (double)N * C;
+    printf("row-complete GEMM + LayerNorm: R = %d rows, C = %d, N = %d (%.1f GFLOP)\n", R, C, N, flop * 1e-9);
+    size_t bad = 0;
+    for (int epi = 0; epi < 3; ++epi) {
+        printf("  EPI %d (%s)\n", epi, epi == 0 ? "LN -> rows + split-bf16 planes" : (epi == 1 ? "LN -> rows + mx planes" : "LN -> ReLU -> PE -> rows + planes"));
+        CK(hipMemset(ref.y, 0xff, ybytes)); CK(hipMemset(ref.yp, 0xff, ybytes));
+        launch_row8<2>(args(epi, 0, ref));
+        CK(hipDeviceSynchronize());
+        auto check = [&](const char* nm, auto launch) {
+            CK(hipMemset(out[0].y, 0xff, ybytes)); CK(hipMemset(out[0].yp, 0xff, ybytes));
+            launch(args(epi, 0, out[0]));
+            CK(hipDeviceSynchronize());
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { printf("    %s: %s\n", nm, hipGetErrorString(e)); ++bad; return; }
+            printf("   %s vs row8<128 rows>:\n", nm);
+            bad += compare("rows", ref.y, out[0].y, (size_t)R * N * 4);
+            bad += compare("planes", ref.yp, out[0].yp, (size_t)R * N * 4);
+        };
+        if (epi == 0) { check("row4<128,s1>", [&](const GemmArgs& a) { launch_row4<4, 0, 1>(a); }); check("row4<160,s1>", [&](const GemmArgs& a) { launch_row4<5, 0, 1>(a); }); check("row4<160,s0>", [&](const GemmArgs& a) { launch_row4<5, 0, 0>(a); }); }
+        if (epi == 1) { check("row4<128,s1>", [&](const GemmArgs& a) { launch_row4<4, 1, 1>(a); }); check("row4<160,s1>", [&](const GemmArgs& a) { launch_row4<5, 1, 1>(a); }); }
+        if (epi == 2) { check("row4<128,s1>", [&](const GemmArgs& a) { launch_row4<4, 2, 1>(a); }); check("row4<160,s1>", [&](const GemmArgs& a) { launch_row4<5, 2, 1>(a); }); }
+    }
+    printf("bit-identity: %s\n", bad ? "FAILED" : "ok");
+    // ---- timing (two operand / output sets in turn: 2 x (A planes + residual + rows + planes) exceed the MALL at the c3 shape)
+    for (int epi = 0; epi < 3; ++epi) {
+        auto T = [&](const char* nm, auto launch) {
+            const float us = time_kernel([&](int i) { launch(args(epi, i & 1, out[i & 1])); }, reps);
+            printf("  EPI %d  %-16s %8.1f us   %7.1f TFLOP/s\n", epi, nm, us, flop / us * 1e-6);
+        };
+        T("row8<128>", [&](const GemmArgs& a) { launch_row8<2>(a); });
+        T("row8<192>", [&](const GemmArgs& a) { launch_row8<3>(a); });
+        if (epi == 0) { T("row4<128,s1>", [&](const GemmArgs& a) { launch_row4<4, 0, 1>(a); }); T("row4<160,s1>", [&](const GemmArgs& a) { launch_row4<5, 0, 1>(a); });
+                        T("row4<128,s0>", [&](const GemmArgs& a) { launch_row4<4, 0, 0>(a); }); T("row4<160,s0>", [&](const GemmArgs& a) { launch_row4<5, 0, 0>(a); }); }
+        if (epi == 1) { T("row4<128,s1>", [&](const GemmArgs& a) { launch_row4<4, 1, 1>(a); }); T("row4<160,s1>", [&](const GemmArgs& a) { launch_row4<5, 1, 1>(a); }); }
+        if (epi == 2) { T("row4<128,s1>", [&](const GemmArgs& a) { launch_row4<4, 2, 1>(a); }); T("row4<160,s1>", [&](const GemmArgs& a) { launch_row4<5, 2, 1>(a); }); }
+    }
+#ifdef FS2_ROW_TIMING
+    for (int mtv = 4; mtv <= 5; ++mtv) {
+        long long z[8][8]; memset(z, 0, sizeof z);
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_row_phase), z, sizeof z));
+        if (mtv == 4) launch_row4<4, 0, 1>(args(0, 0, out[0])); else launch_row4<5, 0, 1>(args(0, 0, out[0]));
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_row_phase), sizeof z));
+        printf("  phase stamps row4<%d rows> (shader cycles from entry; wave 0 of workgroups 0, 32, ...): landed | k-loop done | LN stats | stores issued\n", 32 * mtv);
+        for (int w = 0; w < 8; ++w) if (z[w][4]) printf("    wg %3d: %7lld | %7lld | %7lld | %7lld\n", 32 * w, z[w][1] - z[w][0], z[w][2] - z[w][0], z[w][3] - z[w][0], z[w][4] - z[w][0]);
+    }
+#endif
+    return bad ? 1 : 0;
+}
