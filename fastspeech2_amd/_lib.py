@@ -85,20 +85,63 @@ EXPORTS = ["fs2_abi_version", "fs2_create", "fs2_destroy", "fs2_last_error", "fs
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
 
 
+AUDIT_PATH = os.path.join(_HERE, "libfs2_hip.audit.json")
+
+
+def _sha16(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
-    """Compile csrc/fs2_runtime.hip for gfx950 into fastspeech2_amd/libfs2_hip.so (in-tree)."""
-    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    """Compile csrc/fs2_runtime.hip for gfx950 into fastspeech2_amd/libfs2_hip.so (in-tree) and audit the device assembly of exactly
+    this binary (_audit.py: the kernels whose accumulators are literal registers -- attn_w32, gemm_row4_bf16); the outcome is recorded
+    next to the library (libfs2_hip.audit.json, tied to the binary's hash).  A violation raises: such a library must not ship."""
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(_HERE, "_audit.py")]
     hdr = os.path.join(_HERE, "..", "include", "fs2.h")
     if not force and os.path.exists(LIB_PATH):
         newest = max(os.path.getmtime(p) for p in srcs + [hdr])
-        if os.path.getmtime(LIB_PATH) >= newest:
+        if os.path.getmtime(LIB_PATH) >= newest and audit_record() is not None:
             return LIB_PATH
+    import glob
+    import json
+    import tempfile
+    from . import _audit
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "fs2_runtime.hip"), "-o", LIB_PATH]
+    cmd = [hipcc] + HIPCC_FLAGS + ["-save-temps", os.path.join(CSRC, "fs2_runtime.hip"), "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    with tempfile.TemporaryDirectory(prefix="fs2_build_") as td:      # (-save-temps drops the intermediates into the working directory)
+        subprocess.run(cmd, check=True, cwd=td)
+        asm = glob.glob(os.path.join(td, "*gfx950*.s"))
+        if len(asm) != 1:
+            raise Fs2LibraryError("build: expected one gfx950 assembly listing from -save-temps, found %s" % asm)
+        kernels = _audit.audit_file(asm[0])
+    bad = {k: v["violations"] for k, v in kernels.items() if v["violations"]}
+    rec = dict(so_sha16=_sha16(LIB_PATH), hipcc=subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().split("\n")[0],
+               kernels={k: {a: b for a, b in v.items() if a != "violations"} for k, v in kernels.items()},
+               violations=sum(len(v) for v in bad.values()), clean=not bad and any(v["kind"] == "attn_w32" for v in kernels.values()))
+    with open(AUDIT_PATH, "w") as f:
+        json.dump(rec, f, indent=1)
+    if bad:
+        raise Fs2LibraryError("ISA audit of %s failed (the library stays on disk with FS2_ATTN_W32 / FS2_ROW4 forced off, see libfs2_hip.audit.json):\n%s"
+                              % (LIB_PATH, "\n".join("%s: %s" % (k, v[:3]) for k, v in bad.items())))
     return LIB_PATH
+
+
+def audit_record():
+    """The audit record of the library on disk, or None if there is none / it belongs to another binary."""
+    import json
+    try:
+        with open(AUDIT_PATH) as f:
+            rec = json.load(f)
+        return rec if rec.get("so_sha16") == _sha16(LIB_PATH) else None
+    except (OSError, ValueError):
+        return None
 
 
 TORCH_OP_PATH = os.path.join(_HERE, "libfs2_torch.so")
@@ -199,6 +242,15 @@ def lib():
     L.fs2_op_duration.restype = C.c_int
     L.fs2_set_option.argtypes = [C.c_char_p, i32]
     L.fs2_set_option.restype = C.c_int
+    # the kernels with literal-register accumulators run only in a library whose ISA was audited (build()): otherwise the compiler-scheduled
+    # kernels take their place (attn_bf16, gemm_row8_bf16) -- slower, never silently wrong
+    rec = audit_record()
+    if rec is None or not rec.get("clean"):
+        import warnings
+        warnings.warn("%s has no clean ISA audit record (%s): attn_w32 and gemm_row4_bf16 are switched off; rebuild with "
+                      "`python -c 'import __graft_entry__ as g; g.build()'`" % (LIB_PATH, "missing or stale" if rec is None else "violations"))
+        L.fs2_set_option(b"FS2_ATTN_W32", 0)
+        L.fs2_set_option(b"FS2_ROW4", 0)
     _lib = L
     return L
 

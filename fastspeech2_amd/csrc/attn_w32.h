@@ -57,21 +57,6 @@ constexpr size_t attn_w32_lds_bytes() { return (size_t)3 * (32 * DK * 4 + DK * 1
 template <class F, int... I>
 __device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 
-// Global-memory bytes: the K / V^T tile sources keep their address space through the pointer arithmetic below (rebuilt from integers as
-// generic pointers they turn the register-staged loads into FLAT loads, which count on lgkmcnt as well and take a 64-bit address each).
-typedef const __attribute__((address_space(1))) char gchar_t;
-// a wave-uniform pointer as the compiler can see it (an "s" asm operand must be provably uniform)
-__device__ __forceinline__ gchar_t* uniform_ptr(const void* p) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return reinterpret_cast<gchar_t*>(((unsigned long long)hi << 32) | lo);
-}
-
-// One LDS-DMA instruction: wave-uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset -> 1 KB of LDS at lds_off.
-__device__ __forceinline__ void dma16_so(gchar_t* base, unsigned off, unsigned lds_off) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_off) : "memory");
-}
-
 // O^T never appears as a compiler value: n-tile N IS a[16 N : 16 N + 15], written literally in the statements below and listed as
 // their clobbers (which keeps every value that lives across the tile loop -- the Q fragments -- out of a[0 : 16 NT) and makes the
 // kernel descriptor allocate the range).  With O as "+a" operands hipcc kept two copies of every accumulator tuple and moved 64-96

@@ -94,7 +94,7 @@ struct Options {
     int w32 = -1;        // FS2_ATTN_W32 split-bf16 attention with 32 queries per wave (attn_w32.h): 0 never, 1 whenever the head dim allows, -1 by regime
     int row4 = -1;       // FS2_ROW4     the one-wave-per-SIMD row-complete kernel (gemm_row4.h) wherever gemm_row8_bf16 would run and it has the epilogue: 0 never, else yes
     int mt4 = -1;        // FS2_MT4      its m-tiles per wave (4 | 5: 128 / 160-row workgroups; -1: by the round count)
-    int sched4 = 1;      // FS2_SCHED4   its LDS-DMA pieces dealt out over three MFMA groups (1) or issued in one burst behind the barrier (0)
+    int sched4 = 2;      // FS2_SCHED4   groups of the next k-step its LDS-DMA pieces are spread over beside the last group of the current one (0 | 2 | 4; 0: one burst)
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -105,7 +105,7 @@ Options& opts() {
         Options x;
         x.bm = env_int("FS2_BM", -1); x.row8 = env_int("FS2_ROW8", -1); x.qkv8 = env_int("FS2_QKV8", -1);
         x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.qkv_split = env_int("FS2_QKV_SPLIT", -1); x.op_att_planes = env_int("FS2_OP_ATT_PLANES", 0); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 0); x.w32 = env_int("FS2_ATTN_W32", -1);
-        x.row4 = env_int("FS2_ROW4", -1); x.mt4 = env_int("FS2_MT4", -1); x.sched4 = env_int("FS2_SCHED4", 1);
+        x.row4 = env_int("FS2_ROW4", -1); x.mt4 = env_int("FS2_MT4", -1); x.sched4 = env_int("FS2_SCHED4", 2);
         return x;
     }();
     return o;
@@ -329,6 +329,7 @@ inline int row4_mt(long rows) {
 inline int row4_epi(const GemmArgs& a) {
     if (a.ktaps != 1 || a.N != 384 || !a.ln_g || !a.Y || !a.Yp || a.relu_pre || a.dot_w || a.k_groups > 1 || a.ln_groups > 1 || a.qk_hi || a.yp_col_off) return -1;
     if (a.Cpad % 64 != 0 || a.yp_chunks * 32 != a.N) return -1;      // an even number of k-steps; planes exactly N wide
+    if ((unsigned long long)a.R * (unsigned)a.Cpad * 4ull >= (1ull << 32)) return -1;      // the LDS-DMA pieces address the A planes as base + 32-bit byte offset
     if (a.pe) return (a.act_post == 1 && a.yp_f16 == 0) ? 2 : -1;
     if (a.act_post != 0) return -1;
     return a.yp_f16 == 0 ? 0 : (a.yp_f16 == 2 ? 1 : -1);
@@ -344,7 +345,8 @@ hipError_t launch_row4_t(hipStream_t s, const GemmArgs& a) {
 template <int EPI>
 hipError_t launch_row4_e(hipStream_t s, const GemmArgs& a) {
     const int mt = (opts().mt4 == 4 || opts().mt4 == 5) ? opts().mt4 : row4_mt(rows_in_use(a, a.R));
-    if (opts().sched4) return mt == 5 ? launch_row4_t<5, EPI, 1>(s, a) : launch_row4_t<4, EPI, 1>(s, a);
+    if (opts().sched4 >= 4) return mt == 5 ? launch_row4_t<5, EPI, 4>(s, a) : launch_row4_t<4, EPI, 4>(s, a);
+    if (opts().sched4 >= 1) return mt == 5 ? launch_row4_t<5, EPI, 2>(s, a) : launch_row4_t<4, EPI, 2>(s, a);
     return mt == 5 ? launch_row4_t<5, EPI, 0>(s, a) : launch_row4_t<4, EPI, 0>(s, a);
 }
 hipError_t launch_row4(hipStream_t s, const GemmArgs& a, int epi) {
@@ -2087,7 +2089,7 @@ int fs2_set_option(const char* name, int32_t value) {
     else if (n == "FS2_ATTN_W32") o.w32 = value;
     else if (n == "FS2_ROW4") o.row4 = value;
     else if (n == "FS2_MT4") o.mt4 = value;
-    else if (n == "FS2_SCHED4") o.sched4 = value != 0;
+    else if (n == "FS2_SCHED4") o.sched4 = value;
     else return fail(nullptr, FS2_ERR_ARG, "fs2_set_option: unknown option %s", name);
     return FS2_OK;
 }

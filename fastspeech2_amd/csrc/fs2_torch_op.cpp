@@ -105,10 +105,14 @@ struct JsonParser {
                     case 'f': j.str.push_back('\f'); break;
                     case 'u': {      // json.dumps writes every non-ASCII character of an hp value this way
                         unsigned cp = hex4();
-                        if (cp >= 0xD800 && cp < 0xDC00 && i + 1 < s.size() && s[i] == '\\' && s[i + 1] == 'u') {
+                        // a surrogate is only ever half of a pair: a lone one (high without a following \u low, or a low on its own) would
+                        // become a three-byte sequence that is not UTF-8 (round-4 advisor finding)
+                        TORCH_CHECK(!(cp >= 0xDC00 && cp < 0xE000), "config_json: unpaired low surrogate");
+                        if (cp >= 0xD800 && cp < 0xDC00) {
+                            TORCH_CHECK(i + 1 < s.size() && s[i] == '\\' && s[i + 1] == 'u', "config_json: unpaired high surrogate");
                             i += 2;
                             const unsigned lo = hex4();
-                            TORCH_CHECK(lo >= 0xDC00 && lo < 0xE000, "config_json: unpaired surrogate");
+                            TORCH_CHECK(lo >= 0xDC00 && lo < 0xE000, "config_json: unpaired high surrogate");
                             cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
                         }
                         put_utf8(j.str, cp);
@@ -265,7 +269,12 @@ Entry& get_entry(const at::Tensor& flat, const std::string& config, hipStream_t 
         fs2_destroy(e.h);
         throw;
     }
-    while (g_lru.size() >= max_entries()) { fs2_destroy(g_lru.back().h); g_lru.pop_back(); }
+    while (g_lru.size() >= max_entries()) {
+        // (said once: a process that alternates between more scripted models than the cache holds re-uploads the weights on every call)
+        TORCH_WARN_ONCE("fs2::twin_inference: evicting a cached model (FS2_TWIN_CACHE = ", max_entries(), " handles per process); set FS2_TWIN_CACHE "
+                        "to the number of scripted models this process alternates between");
+        fs2_destroy(g_lru.back().h); g_lru.pop_back();
+    }
     g_lru.push_front(std::move(e));
     return g_lru.front();
 }

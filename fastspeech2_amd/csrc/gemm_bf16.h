@@ -53,7 +53,25 @@ template <int N> __device__ __forceinline__ void dma_wait_barrier() {
 // DMA instructions of a k-step costing 13-30 % of the step.  The compiler does not see this VMEM operation: completion is
 // always awaited explicitly (dma_barrier), and its own vmcnt bookkeeping for other loads only becomes more conservative.
 __device__ __forceinline__ void dma16(const void* src, unsigned lds_off) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_off) : "memory");      // (M0 is reserved: hipcc never keeps a value in it across statements)
+    // M0 is not on the clobber list on purpose: for the AMDGPU backend M0 is a RESERVED register -- never allocated to a value; every compiler use
+    // (LDS-DMA builtins, movrel, sendmsg, GWS) writes it immediately in front of the instruction that reads it -- and hipcc says so itself when
+    // "m0" is listed: "inline asm clobber list contains reserved registers: m0 ... clobbering them may lead to undefined behaviour" (-Winline-asm).
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_off) : "memory");
+}
+
+// Global-memory bytes (attn_w32.h, gemm_row4.h): the tile sources keep their address space through the pointer arithmetic below (rebuilt from integers as
+// generic pointers they turn the register-staged loads into FLAT loads, which count on lgkmcnt as well and take a 64-bit address each).
+typedef const __attribute__((address_space(1))) char gchar_t;
+// a wave-uniform pointer as the compiler can see it (an "s" asm operand must be provably uniform)
+__device__ __forceinline__ gchar_t* uniform_ptr(const void* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<gchar_t*>(((unsigned long long)hi << 32) | lo);
+}
+
+// One LDS-DMA instruction: wave-uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset -> 1 KB of LDS at lds_off.
+__device__ __forceinline__ void dma16_so(gchar_t* base, unsigned off, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_off) : "memory");
 }
 
 #ifndef FS2_SETPRIO

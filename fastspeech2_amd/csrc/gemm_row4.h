@@ -24,8 +24,10 @@
 //     stage it + 1 has landed everywhere) the A fragments and the first B pair of step it + 1 are requested and the LDS-DMA of
 //     stage it + 2 starts -- all of it under the last group's MFMAs, so the matrix pipe never drains at a step boundary;
 //   * the 4 NB + MT one-KB LDS-DMA pieces a wave issues per stage are dealt out between MFMAs (a piece costs its wave ~60 cycles
-//     of issue, which only the MFMAs already in the pipe cover): SCHED = 1 spreads them over the last group of a step and the
-//     first two of the next, SCHED = 0 issues them in one burst behind the barrier.
+//     of issue, which only the MFMAs already in the pipe cover): SCHED = number of groups of the NEXT step they are spread over beside
+//     the last group of this one (0: one burst behind the barrier; 2: the default); a piece is `s_mov m0` + ONE VMEM instruction -- uniform
+//     64-bit stage base in SGPRs + a per-lane 32-bit byte offset computed once (as address arithmetic per piece it was 5 VALU
+//     instructions each, ~400 issue cycles of a 3,700-cycle step).
 #pragma once
 #include <type_traits>
 #include "gemm_planes.h"
@@ -98,14 +100,14 @@ __device__ long long g_row_phase[8][8];
 // split-bf16 planes (FFN2 + LN2; out-proj + LN1 in bf16x3 mode), 1 = LayerNorm -> fp32 rows + mx planes (out-proj + LN1 in mix_mx mode),
 // 2 = LayerNorm -> ReLU -> x_scale v + alpha pe -> fp32 rows + split-bf16 planes (the decoder input layer).  Everything else stays on gemm_row8_bf16
 // (fs2_runtime.hip: use_row4).
-template <int NSPLIT, int NB, int MT, int EPI = 0, int SCHED = 1>
+template <int NSPLIT, int NB, int MT, int EPI = 0, int SCHED = 2>
 __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     constexpr int NT = 4 * NB, NP = NT / 2, BM = 32 * MT, BN = 128 * NB, RW = 16 * MT;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int PIECES = MT + 4 * NB;                       // one-KB LDS-DMA pieces per wave and stage: A pieces first (they come from HBM), then B
-    // pieces issued behind the barrier (last group of a step) | in the first | second group of the next step
-    constexpr int kPL = SCHED ? (PIECES + 2) / 3 : PIECES, kP0 = SCHED ? (PIECES - kPL + 1) / 2 : 0, kP1 = PIECES - kPL - kP0;
-    static_assert(NP >= 3 && NP % 2 == 0, "an even number of n-tile pairs per wave (N = 256 or 384)");
+    // pieces [cut(0), cut(1)) are issued behind the barrier (last group of a step), [cut(g + 1), cut(g + 2)) in group g < SCHED of the next step
+    static_assert(NP >= 3 && NP % 2 == 0 && SCHED >= 0 && SCHED <= NP - 2, "an even number of n-tile pairs per wave (N = 256 or 384)");
+    auto cut = [](int i) constexpr { return (PIECES * i) / (SCHED + 1); };
     extern __shared__ __attribute__((aligned(16))) char smem_q[];
     FS2_RT(0)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -120,38 +122,36 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     const int niter = a.Cpad / 32;
     const int jrow = lane >> 3, jslot = lane & 7;
 
-    // A: piece i of wave w fills tile rows 32 i + 8 w + jrow (piece index q = w + 4 i, q & 1 == w & 1: the swizzle term is a per-lane constant)
+    // A: piece i of wave w fills tile rows 32 i + 8 w + jrow (piece index q = w + 4 i, q & 1 == w & 1: the swizzle term is a per-lane constant).
+    // Rows beyond R (the last tile) repeat row R - 1: their results are never stored, and rows of a GEMM do not interact.
     const int sA = jslot ^ (jrow >> 1) ^ ((wave & 1) << 2);
     const int arow0 = m0 + wave * 8 + jrow;
-    const __bf16* a_src0 = Xp + (size_t)arow0 * niter * 64 + sA * 8;
-    const size_t a_qstride = (size_t)32 * niter * 64;
+    unsigned a_off[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_off[i] = (unsigned)min(arow0 + 32 * i, a.R - 1) * (unsigned)(niter * 128) + (unsigned)(sA * 16);
     // B: piece u of wave w (q = w + 4 u) fills LDS rows 32 u + 8 w + jrow = n-tile 2 u + (w >> 1), tile row jB; that row belongs to
     // weight row 64 (u >> 1) + 4 rperm_inv(jB) + 2 (u & 1) + (w >> 1) (gemm_planes.h: four consecutive channels per lane)
     const int jB = (wave & 1) * 8 + jrow;
     const int sB = jslot ^ ((jB >> 1) & 7);
-    const __bf16* b_src0 = Wb + ((size_t)(4 * rperm_inv(jB) + (wave >> 1)) * niter) * 64 + sB * 8;
-    const size_t b_o1 = (size_t)2 * niter * 64, b_o2 = (size_t)64 * niter * 64;
+    unsigned b_off[4 * NB];
+#pragma unroll
+    for (int u = 0; u < 4 * NB; ++u) b_off[u] = (unsigned)(64 * (u >> 1) + 4 * rperm_inv(jB) + 2 * (u & 1) + (wave >> 1)) * (unsigned)(niter * 128) + (unsigned)(sB * 16);
+    gchar_t* abase0 = uniform_ptr(Xp);
+    gchar_t* bbase0 = uniform_ptr(Wb);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t*)smem_q);
     const unsigned ldsw = lds0 + wave * 1024;
-    // piece k (compile time) of stage `it` into ring slot `buf`
+    // piece k (compile time) of stage `it` into ring slot `buf`: k-step `it` of either operand starts 128 it bytes into the rows
     auto piece = [&](auto k_tag, int it, int buf) __attribute__((always_inline)) {
         constexpr int k = decltype(k_tag)::value;
-        if constexpr (k < MT) {
-            const bool ok = arow0 + 32 * k < a.R;
-            const void* sp = ok ? static_cast<const void*>(a_src0 + (size_t)it * 64 + k * a_qstride) : static_cast<const void*>(g_zero16);
-            dma16(sp, ldsw + buf * STAGE + k * 4096);
-        } else {
-            constexpr int u = k - MT;
-            dma16(b_src0 + (size_t)it * 64 + (u & 1) * b_o1 + (u >> 1) * b_o2, ldsw + buf * STAGE + BM * 128 + u * 4096);
-        }
+        if constexpr (k < MT) dma16_so(abase0 + (size_t)it * 128, a_off[k], ldsw + buf * STAGE + k * 4096);
+        else dma16_so(bbase0 + (size_t)it * 128, b_off[k - MT], ldsw + buf * STAGE + BM * 128 + (k - MT) * 4096);
     };
     auto pieces = [&](auto lo_tag, auto hi_tag, int it, int buf) __attribute__((always_inline)) {
         constexpr int lo = decltype(lo_tag)::value, hi = decltype(hi_tag)::value;
         for_seq_i<lo, hi>([&](auto k_tag) __attribute__((always_inline)) { piece(k_tag, it, buf); });
     };
     using I0 = std::integral_constant<int, 0>;
-    using IPL = std::integral_constant<int, kPL>;
-    using IP0 = std::integral_constant<int, kPL + kP0>;
+    using IPL = std::integral_constant<int, cut(1)>;
     using IPA = std::integral_constant<int, PIECES>;
 
     pieces(I0{}, IPA{}, 0, 0);
@@ -250,8 +250,6 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
         });
     };
     auto nothing = [](auto) __attribute__((always_inline)) {};
-    using IK0 = std::integral_constant<int, kP0>;
-    using IK1 = std::integral_constant<int, kP1>;
 
     // ---- prologue of the pipeline: stage 0 landed; request the first fragments; start stage 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -276,8 +274,9 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
             if constexpr (p + 1 < NP) {
                 load_B(fnext, cur, 2 * (p + 1));
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (p == 0 && MORE1 && kP0 > 0) mfma_group(fc, fthis, N2{}, [&](auto m_tag) __attribute__((always_inline)) { deal(m_tag, IPL{}, IK0{}, it + 1, cur ^ 1); });
-                else if constexpr (p == 1 && MORE1 && kP1 > 0) mfma_group(fc, fthis, N2{}, [&](auto m_tag) __attribute__((always_inline)) { deal(m_tag, IP0{}, IK1{}, it + 1, cur ^ 1); });
+                if constexpr (p < SCHED && MORE1 && (cut(p + 2) > cut(p + 1)))
+                    mfma_group(fc, fthis, N2{}, [&](auto m_tag) __attribute__((always_inline)) {
+                        deal(m_tag, std::integral_constant<int, cut(p + 1)>{}, std::integral_constant<int, cut(p + 2) - cut(p + 1)>{}, it + 1, cur ^ 1); });
                 else mfma_group(fc, fthis, N2{}, nothing);
             } else {
                 // every fragment of stage `it` is in registers (the last pair was requested a group ago); stage it + 1 must have landed everywhere
@@ -367,6 +366,15 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
             const int pv = loadi_or_zero(rpos + row, rpos != nullptr && row < a.R);
             pos[r] = row < a.R ? pv : -1;
         }
+        // (a wave alone on its SIMD has nobody to cover a load's latency: the positional-encoding rows of the whole m-tile are requested here, in
+        //  one batch behind the four positions, not one by one in front of their use -- the first build ran this epilogue 13 % behind gemm_row8_bf16's)
+        f32x4 pe4[NB][4];
+        if constexpr (PE) {
+#pragma unroll
+            for (int g = 0; g < NB; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pe4[g][r] = load4_or_zero(a.pe + (size_t)(pos[r] >= 0 ? pos[r] : 0) * a.pe_ld + col0 + 64 * g, pos[r] >= 0);
+        }
         for_seq_i<0, NB>([&](auto g_tag) __attribute__((always_inline)) {
             constexpr int g = decltype(g_tag)::value;
             const int col = col0 + 64 * g;
@@ -376,14 +384,12 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int row = rowb + mt * 16 + rp[r];
                 const bool live = pos[r] >= 0;
-                f32x4 pe4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (PE) pe4 = load4_or_zero(a.pe + (size_t)(live ? pos[r] : 0) * a.pe_ld + col, live);
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float t = (x[j][r] - mean[mt][r]) * rstd[mt][r];
                     t = t * gam[g][j] + bet[g][j];
-                    if (PE) { t = fmaxf(t, 0.f); t = t * a.x_scale + alpha * pe4[j]; }
+                    if constexpr (PE) { t = fmaxf(t, 0.f); t = t * a.x_scale + alpha * pe4[g][r][j]; }
                     v[j] = live ? t : 0.f;
                 }
                 if (row < a.R) {

@@ -125,9 +125,9 @@ int main(int argc, char** argv) {
             bad += compare("rows", ref.y, out[0].y, (size_t)R * N * 4);
             bad += compare("planes", ref.yp, out[0].yp, (size_t)R * N * 4);
         };
-        if (epi == 0) { check("row4<128,s1>", [&](const GemmArgs& a) { launch_row4<4, 0, 1>(a); }); check("row4<160,s1>", [&](const GemmArgs& a) { launch_row4<5, 0, 1>(a); }); check("row4<160,s0>", [&](const GemmArgs& a) { launch_row4<5, 0, 0>(a); }); }
-        if (epi == 1) { check("row4<128,s1>", [&](const GemmArgs& a) { launch_row4<4, 1, 1>(a); }); check("row4<160,s1>", [&](const GemmArgs& a) { launch_row4<5, 1, 1>(a); }); }
-        if (epi == 2) { check("row4<128,s1>", [&](const GemmArgs& a) { launch_row4<4, 2, 1>(a); }); check("row4<160,s1>", [&](const GemmArgs& a) { launch_row4<5, 2, 1>(a); }); }
+        if (epi == 0) { check("row4<128,s2>", [&](const GemmArgs& a) { launch_row4<4, 0, 2>(a); }); check("row4<160,s2>", [&](const GemmArgs& a) { launch_row4<5, 0, 2>(a); }); check("row4<160,s0>", [&](const GemmArgs& a) { launch_row4<5, 0, 0>(a); }); check("row4<160,s4>", [&](const GemmArgs& a) { launch_row4<5, 0, 4>(a); }); }
+        if (epi == 1) { check("row4<128,s2>", [&](const GemmArgs& a) { launch_row4<4, 1, 2>(a); }); check("row4<160,s2>", [&](const GemmArgs& a) { launch_row4<5, 1, 2>(a); }); }
+        if (epi == 2) { check("row4<128,s2>", [&](const GemmArgs& a) { launch_row4<4, 2, 2>(a); }); check("row4<160,s2>", [&](const GemmArgs& a) { launch_row4<5, 2, 2>(a); }); }
     }
     printf("bit-identity: %s\n", bad ? "FAILED" : "ok");
     // ---- timing (two operand / output sets in turn: 2 x (A planes + residual + rows + planes) exceed the MALL at the c3 shape)
@@ -138,16 +138,16 @@ int main(int argc, char** argv) {
         };
         T("row8<128>", [&](const GemmArgs& a) { launch_row8<2>(a); });
         T("row8<192>", [&](const GemmArgs& a) { launch_row8<3>(a); });
-        if (epi == 0) { T("row4<128,s1>", [&](const GemmArgs& a) { launch_row4<4, 0, 1>(a); }); T("row4<160,s1>", [&](const GemmArgs& a) { launch_row4<5, 0, 1>(a); });
-                        T("row4<128,s0>", [&](const GemmArgs& a) { launch_row4<4, 0, 0>(a); }); T("row4<160,s0>", [&](const GemmArgs& a) { launch_row4<5, 0, 0>(a); }); }
-        if (epi == 1) { T("row4<128,s1>", [&](const GemmArgs& a) { launch_row4<4, 1, 1>(a); }); T("row4<160,s1>", [&](const GemmArgs& a) { launch_row4<5, 1, 1>(a); }); }
-        if (epi == 2) { T("row4<128,s1>", [&](const GemmArgs& a) { launch_row4<4, 2, 1>(a); }); T("row4<160,s1>", [&](const GemmArgs& a) { launch_row4<5, 2, 1>(a); }); }
+        if (epi == 0) { T("row4<128,s2>", [&](const GemmArgs& a) { launch_row4<4, 0, 2>(a); }); T("row4<160,s2>", [&](const GemmArgs& a) { launch_row4<5, 0, 2>(a); });
+                        T("row4<160,s0>", [&](const GemmArgs& a) { launch_row4<5, 0, 0>(a); }); T("row4<160,s4>", [&](const GemmArgs& a) { launch_row4<5, 0, 4>(a); }); }
+        if (epi == 1) { T("row4<128,s2>", [&](const GemmArgs& a) { launch_row4<4, 1, 2>(a); }); T("row4<160,s2>", [&](const GemmArgs& a) { launch_row4<5, 1, 2>(a); }); }
+        if (epi == 2) { T("row4<128,s2>", [&](const GemmArgs& a) { launch_row4<4, 2, 2>(a); }); T("row4<160,s2>", [&](const GemmArgs& a) { launch_row4<5, 2, 2>(a); }); }
     }
 #ifdef FS2_ROW_TIMING
     for (int mtv = 4; mtv <= 5; ++mtv) {
         long long z[8][8]; memset(z, 0, sizeof z);
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_row_phase), z, sizeof z));
-        if (mtv == 4) launch_row4<4, 0, 1>(args(0, 0, out[0])); else launch_row4<5, 0, 1>(args(0, 0, out[0]));
+        if (mtv == 4) launch_row4<4, 0, 2>(args(0, 0, out[0])); else launch_row4<5, 0, 2>(args(0, 0, out[0]));
         CK(hipDeviceSynchronize());
         CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_row_phase), sizeof z));
         printf("  phase stamps row4<%d rows> (shader cycles from entry; wave 0 of workgroups 0, 32, ...): landed | k-loop done | LN stats | stores issued\n", 32 * mtv);
