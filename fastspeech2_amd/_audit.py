@@ -198,7 +198,7 @@ def audit_row4(lines, nb, mt):
 
 
 _W32 = re.compile(r'^(_ZN3fs28attn_w32ILi(\d+)EEEvNS_11AttnB16ArgsE):')
-_ROW4 = re.compile(r'^(_ZN3fs214gemm_row4_bf16ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEEvNS_8GemmArgsE):')
+_ROW4 = re.compile(r'^(_ZN3fs214gemm_row4_bf16I((?:Li\d+E)+)EEvNS_8GemmArgsE):')      # template arguments: NSPLIT, NB, MT, EPI, SCHED, ARITH
 
 
 def audit_text(text):
@@ -221,7 +221,8 @@ def audit_text(text):
         if m1:
             out[m1.group(1)] = audit_w32(body, int(m1.group(2)))
         else:
-            out[m2.group(1)] = audit_row4(body, int(m2.group(3)), int(m2.group(4)))
+            targs = [int(x) for x in re.findall(r'Li(\d+)E', m2.group(2))]
+            out[m2.group(1)] = audit_row4(body, targs[1], targs[2])
         i = j
     return out
 

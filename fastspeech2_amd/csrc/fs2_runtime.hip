@@ -48,6 +48,8 @@ struct Layer {
     float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
     int ka = 0;              // "mx" mode: exponent of the static scale of the FFN input (the LN1 output): |x| 2^ka <= 448 from the bound
                              // |LN(x)_c| <= sqrt(D) |gamma_c| + |beta_c|
+    int kh = 0;              // ... and of the FFN hidden layer (w_2's input in the mx arithmetic, gemm_row4.h ARITH = 2): |h| 2^kh <= 448 from the bound
+                             // |h_n| <= sum_{c,tap} |w_1[n,c,tap]| xmax + |b_1[n]|, xmax = the LayerNorm bound above (w2.wm != nullptr: the mode exists)
 };
 struct Predictor {
     std::vector<Gemm> conv;
@@ -94,7 +96,7 @@ struct Options {
     int w32 = -1;        // FS2_ATTN_W32 split-bf16 attention with 32 queries per wave (attn_w32.h): 0 never, 1 whenever the head dim allows, -1 by regime
     int row4 = -1;       // FS2_ROW4     the one-wave-per-SIMD row-complete kernel (gemm_row4.h) wherever gemm_row8_bf16 would run and it has the epilogue: 0 never, else yes
     int mt4 = -1;        // FS2_MT4      its m-tiles per wave (4 | 5: 128 / 160-row workgroups; -1: by the round count)
-    int sched4 = 2;      // FS2_SCHED4   groups of the next k-step its LDS-DMA pieces are spread over beside the last group of the current one (0 | 2 | 4; 0: one burst)
+    int ffn2_mx = 1;     // FS2_FFN2_MX  mix_mx mode: the second FFN GEMM in the mx arithmetic too, wherever gemm_row4_bf16 runs it (0: split-bf16 as in round 4)
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -105,7 +107,7 @@ Options& opts() {
         Options x;
         x.bm = env_int("FS2_BM", -1); x.row8 = env_int("FS2_ROW8", -1); x.qkv8 = env_int("FS2_QKV8", -1);
         x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.qkv_split = env_int("FS2_QKV_SPLIT", -1); x.op_att_planes = env_int("FS2_OP_ATT_PLANES", 0); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 0); x.w32 = env_int("FS2_ATTN_W32", -1);
-        x.row4 = env_int("FS2_ROW4", -1); x.mt4 = env_int("FS2_MT4", -1); x.sched4 = env_int("FS2_SCHED4", 2);
+        x.row4 = env_int("FS2_ROW4", -1); x.mt4 = env_int("FS2_MT4", -1); x.ffn2_mx = env_int("FS2_FFN2_MX", 1);
         return x;
     }();
     return o;
@@ -123,6 +125,28 @@ inline int base_precision(int p) { return (p == FS2_PREC_MIX_F16X2 || p == FS2_P
 constexpr int kFfnMx = 9;      // value of "ffn_terms" that selects the fp16 + block-scaled-fp8 arithmetic (gemm_mx.h)
 inline int ffn_f16_terms(int p) { return p == FS2_PREC_MIX_F16X2 ? 2 : (p == FS2_PREC_MIX_F16X1 ? 1 : (p == FS2_PREC_MIX_MX ? kFfnMx : 0)); }
 inline int scale_byte4(int e) { const int b = std::min(std::max(e, 1), 254); return b * 0x01010101; }
+
+// max over the rows n of a [N][K] weight of (sum_k |w[n][k]|) xmax + |b[n]|: the a-priori bound of relu(w x + b) for |x| <= xmax (weight-load time only)
+__global__ void row_l1_bound_kernel(const float* w, const float* b, int N, int K, float xmax, unsigned* out) {
+    const int n = blockIdx.x;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) s += fabsf(w[(size_t)n * K + k]);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint((part[0] + part[1] + part[2] + part[3]) * xmax + (b ? fabsf(b[n]) : 0.f)));
+}
+float device_row_l1_bound(hipStream_t s, const float* w, const float* b, int N, int K, float xmax, unsigned* scratch) {
+    hipMemsetAsync(scratch, 0, 4, s);
+    hipLaunchKernelGGL(row_l1_bound_kernel, dim3(N), dim3(256), 0, s, w, b, N, K, xmax, scratch);
+    unsigned u = 0;
+    hipMemcpyAsync(&u, scratch, 4, hipMemcpyDeviceToHost, s);
+    hipStreamSynchronize(s);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
 
 // max |x| of a device array (weight-load time only: one small launch + a blocking 4-byte read-back)
 __global__ void absmax_kernel(const float* x, int64_t n, unsigned* out) {
@@ -334,23 +358,23 @@ inline int row4_epi(const GemmArgs& a) {
     if (a.act_post != 0) return -1;
     return a.yp_f16 == 0 ? 0 : (a.yp_f16 == 2 ? 1 : -1);
 }
-template <int MT, int EPI, int SCHED>
+template <int MT, int EPI, int ARITH>
 hipError_t launch_row4_t(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
     constexpr size_t lds = row4_lds_bytes<3, MT>();
-    allow_lds(reinterpret_cast<const void*>(&gemm_row4_bf16<3, 3, MT, EPI, SCHED>), lds, attr);
-    hipLaunchKernelGGL((gemm_row4_bf16<3, 3, MT, EPI, SCHED>), dim3((a.R + 32 * MT - 1) / (32 * MT)), dim3(256), lds, s, a);
+    allow_lds(reinterpret_cast<const void*>(&gemm_row4_bf16<3, 3, MT, EPI, 2, ARITH>), lds, attr);
+    hipLaunchKernelGGL((gemm_row4_bf16<3, 3, MT, EPI, 2, ARITH>), dim3((a.R + 32 * MT - 1) / (32 * MT)), dim3(256), lds, s, a);
     return hipGetLastError();
 }
-template <int EPI>
+template <int EPI, int ARITH>
 hipError_t launch_row4_e(hipStream_t s, const GemmArgs& a) {
     const int mt = (opts().mt4 == 4 || opts().mt4 == 5) ? opts().mt4 : row4_mt(rows_in_use(a, a.R));
-    if (opts().sched4 >= 4) return mt == 5 ? launch_row4_t<5, EPI, 4>(s, a) : launch_row4_t<4, EPI, 4>(s, a);
-    if (opts().sched4 >= 1) return mt == 5 ? launch_row4_t<5, EPI, 2>(s, a) : launch_row4_t<4, EPI, 2>(s, a);
-    return mt == 5 ? launch_row4_t<5, EPI, 0>(s, a) : launch_row4_t<4, EPI, 0>(s, a);
+    return mt == 5 ? launch_row4_t<5, EPI, ARITH>(s, a) : launch_row4_t<4, EPI, ARITH>(s, a);
 }
+// (the DMA-spreading schedule is fixed at SCHED = 2: same-box A/B in the model, c3: 0 -> 7.21, 2 -> 7.20, 4 -> 7.17 M frames/s; stand-alone 2 and 4 are 5-13 % ahead of 0)
 hipError_t launch_row4(hipStream_t s, const GemmArgs& a, int epi) {
-    return epi == 0 ? launch_row4_e<0>(s, a) : (epi == 1 ? launch_row4_e<1>(s, a) : launch_row4_e<2>(s, a));
+    if (a.mx) return launch_row4_e<0, 2>(s, a);
+    return epi == 0 ? launch_row4_e<0, 0>(s, a) : (epi == 1 ? launch_row4_e<1, 0>(s, a) : launch_row4_e<2, 0>(s, a));
 }
 
 template <int NSPLIT, int NB, int MT, int GROUPS = 1>
@@ -419,6 +443,12 @@ bool use_row8(const GemmArgs& a) {
     } else if (a.dot_w || !(a.ln_g || a.pe) || a.k_groups > 1 || a.ln_groups > 1) return false;
     if (opts().row8 >= 0) return opts().row8 != 0;
     return ((a.regime_rows ? a.regime_rows : a.R) + 127) / 128 >= 128;
+}
+
+// Will launch_gemm run this LayerNorm-terminated k = 1 GEMM on gemm_row4_bf16, and does that kernel's mx form exist for it?  (run_stack asks before it
+// decides the format of the A planes; launch_gemm makes the same test.)
+bool ffn2_on_row4_mx(const fs2_handle*, const GemmArgs& a) {
+    return use_row8(a) && opts().row4 != 0 && row4_epi(a) == 0 && a.Cpad % 128 == 0 && a.Xp != nullptr;
 }
 
 // In the 256-row regime the conv kernel runs two workgroups per CU: a launch of T y-tiles per N tile takes ceil(T nN / 512) rounds, and a nearly
@@ -530,8 +560,9 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
             t.kpart = a.kpart + y_slab * (size_t)a.R * a.N;
             t.kpart_stride = (size_t)a.R * t.ldy;
         }
-        if ((a.f16_terms || a.mx) && (a.ktaps == 1 || need_rows || a.qk_hi)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: the fp16 arithmetic exists for plain convolutions only", name);
-        if (a.mx && (a.ktaps < 3 || a.C % 128 != 0 || a.N % 128 != 0)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: the mx arithmetic needs a convolution with C %% 128 == 0 and N %% 128 == 0", name);
+        const bool mx_row4 = a.mx && a.ktaps == 1 && precision == FS2_PREC_BF16X3 && ffn2_on_row4_mx(h, a);      // FFN2 + LN2 in the mx arithmetic (gemm_row4.h)
+        if ((a.f16_terms || a.mx) && !mx_row4 && (a.ktaps == 1 || need_rows || a.qk_hi)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: the fp16 arithmetic exists for plain convolutions only", name);
+        if (a.mx && !mx_row4 && (a.ktaps < 3 || a.C % 128 != 0 || a.N % 128 != 0)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: the mx arithmetic needs a convolution with C %% 128 == 0 and N %% 128 == 0", name);
 
         if (!a.Xp) {
             char nm[112];
@@ -543,7 +574,10 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         }
         {
             Scope sc(h, s, name, flops, bytes);
-            if (a.mx) {
+            if (mx_row4) {
+                t.W = reinterpret_cast<const float*>(a.Wb);
+                e = launch_row4(s, t, 0);
+            } else if (a.mx) {
                 e = launch_mx(s, t);
             } else if (a.f16_terms) {
                 e = a.f16_terms == 3 ? launch_pl_f16<3>(s, t) : (a.f16_terms == 2 ? launch_pl_f16<2>(s, t) : launch_pl_f16<1>(s, t));
@@ -873,20 +907,25 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         const int f16t = (pl && ffn_terms && ffn_terms != kFfnMx && ly.w1.ktaps > 1 && ly.w1.wf) ? ffn_terms : 0;      // ... or on fp16 operands?
         if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; a.yp_f16 = mxl ? 2 : (f16t ? 1 : 0); a.yp_scale = mxl ? exp2f((float)ly.ka) : 1.f; }       // x1p feeds only that conv
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
+        // the second FFN GEMM: built first, because WHERE it will run decides the format the hidden layer leaves FFN1 in (mx planes for gemm_row4_bf16's
+        // mx form, split-bf16 planes for everything else)
+        GemmArgs a2 = gemm_args(ly.w2, b.hid, ly.w1.N, R, dl.row_pos, b.x0, D);
+        a2.Rp = dl.dims; a2.regime_rows = regime_rows;
+        a2.resid = b.x1; a2.ldr = D; a2.ln_g = ly.ln2g; a2.ln_b = ly.ln2b; a2.ln_eps = 1e-5f;
+        if (pl) { a2.Xp = hidp; a2.Yp = b.x0p; a2.yp_chunks = D / 32; }
+        const bool mx2 = mxl && ly.w2.wm && opts().ffn2_mx && prec == FS2_PREC_BF16X3 && ffn2_on_row4_mx(h, a2);
+        if (mx2) { a2.mx = 1; a2.Wb = ly.w2.wm; a2.mx_scale = scale_byte4(127 - ly.kh - 11); a2.mx_scale_b = scale_byte4(127 - ly.w2.kw); }
         snprintf(nm, sizeof nm, "%s.ffn1", tag);
         a = gemm_args(ly.w1, b.x1, D, R, dl.row_pos, pl ? nullptr : b.hid, ly.w1.N);
         a.Rp = dl.dims;
         a.act_post = 1;
         if (pl) { a.Xp = b.x1p; a.Yp = hidp; a.yp_chunks = round_up(ly.w1.N, 32) / 32; }
+        if (mx2) { a.yp_f16 = 2; a.yp_scale = exp2f((float)ly.kh); }
         if (f16t) { a.f16_terms = f16t; a.Wb = ly.w1.wf; }
         if (mxl) { a.mx = 1; a.Wb = ly.w1.wm; a.mx_scale = scale_byte4(127 - ly.ka - 11); a.mx_scale_b = scale_byte4(127 - ly.w1.kw); }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.ffn2_ln", tag);
-        a = gemm_args(ly.w2, b.hid, ly.w1.N, R, dl.row_pos, b.x0, D);
-        a.Rp = dl.dims; a.regime_rows = regime_rows;
-        a.resid = b.x1; a.ldr = D; a.ln_g = ly.ln2g; a.ln_b = ly.ln2b; a.ln_eps = 1e-5f;
-        if (pl) { a.Xp = hidp; a.Yp = b.x0p; a.yp_chunks = D / 32; }
-        if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
+        if ((rc = launch_gemm(h, s, nm, a2, prec))) return rc;
     }
     return FS2_OK;
 }
@@ -1144,7 +1183,7 @@ struct Loader {
     // parts: weights stacked along N (q|k|v); each [n_i, C, k] (k omitted for Linear)
     // col_off / src_cols: take columns [col_off, col_off + C) of a Linear weight stored [Neach, src_cols] (concat_linear halves)
     Gemm gemm(std::vector<std::string> wnames, std::vector<std::string> bnames, int Neach, int C, int k, bool linear,
-              const std::string& bn_prefix = "", bool f16_image = false, int col_off = 0, int src_cols = 0) {
+              const std::string& bn_prefix = "", bool f16_image = false, int col_off = 0, int src_cols = 0, bool mx_k1 = false) {
         Gemm g;
         const int parts = (int)wnames.size();
         g.N = Neach * parts; g.C = C; g.ktaps = k; g.Cpad = round_up(C, kBK);
@@ -1168,8 +1207,8 @@ struct Loader {
             g.wb = pb;
             hipMemsetAsync(pb, 0, wb_elems * 2, s);
         }
-        if (f16_image && k > 1 && parts == 1 && !linear && g.N % 128 == 0 && C % 128 == 0 && bn_prefix.empty()) {      // "mx" mode: its weight image (gemm_mx.h)
-            const fs2_tensor_desc* d = get(wnames[0], {Neach, C, k});
+        if (((f16_image && k > 1 && !linear) || (mx_k1 && k == 1 && !src_cols)) && parts == 1 && g.N % 128 == 0 && C % 128 == 0 && bn_prefix.empty()) {      // "mx" mode: its weight image (gemm_mx.h)
+            const fs2_tensor_desc* d = (k == 1 && linear) ? get(wnames[0], {Neach, C}) : get(wnames[0], {Neach, C, k});
             if (!d) return g;
             if (!absmax_scratch && hipMalloc((void**)&absmax_scratch, 16) != hipSuccess) { if (!rc) rc = fail(h, FS2_ERR_HIP, "hipMalloc failed"); return g; }
             g.kw = fp8_scale_exponent(device_absmax(s, (const float*)d->data, (int64_t)Neach * C * k, absmax_scratch));
@@ -1251,7 +1290,8 @@ void load_stack(Loader& L, Stack& st, const std::string& pre, int nlayers, int D
                         "", /*f16_image=*/k > 1);
         {
             const bool lin2 = L.m.count(p + ".feed_forward.w_2.weight") && L.m[p + ".feed_forward.w_2.weight"]->ndim == 2;
-            ly.w2 = L.gemm({p + ".feed_forward.w_2.weight"}, {p + ".feed_forward.w_2.bias"}, D, units, 1, lin2);
+            // (mx image of w_2 where the one-wave-per-SIMD row kernel exists for this width: gemm_row4.h is instantiated for N = 384)
+            ly.w2 = L.gemm({p + ".feed_forward.w_2.weight"}, {p + ".feed_forward.w_2.bias"}, D, units, 1, lin2, "", false, 0, 0, /*mx_k1=*/k > 1 && D == 384);
         }
         if (concat) {
             ly.cat_x = L.gemm({p + ".concat_linear.weight"}, {p + ".concat_linear.bias"}, D, D, 1, true, "", false, /*col_off=*/0, /*src_cols=*/2 * D);
@@ -1260,8 +1300,15 @@ void load_stack(Loader& L, Stack& st, const std::string& pre, int nlayers, int D
         ly.ln1g = L.copy(p + ".norm1.weight", {D}); ly.ln1b = L.copy(p + ".norm1.bias", {D});
         if (ly.w1.wm && ly.ln1g && ly.ln1b && L.absmax_scratch) {      // a-priori bound of the LayerNorm output that feeds the FFN conv
             const float gm = device_absmax(L.s, ly.ln1g, D, L.absmax_scratch), bm = device_absmax(L.s, ly.ln1b, D, L.absmax_scratch);
-            ly.ka = fp8_scale_exponent(std::sqrt((float)D) * gm + bm);
+            const float xmax = std::sqrt((float)D) * gm + bm;
+            ly.ka = fp8_scale_exponent(xmax);
+            if (ly.w2.wm) {      // the hidden layer's bound: l1 norms of w_1's rows (the fp32 tensor the caller handed in is still there during the load)
+                const fs2_tensor_desc* dw = L.m.count(p + ".feed_forward.w_1.weight") ? L.m[p + ".feed_forward.w_1.weight"] : nullptr;
+                if (dw) ly.kh = fp8_scale_exponent(device_row_l1_bound(L.s, (const float*)dw->data, ly.w1.bias, units, D * k, xmax, L.absmax_scratch));
+                else ly.w2.wm = nullptr;
+            }
         }
+        else ly.w2.wm = nullptr;
         ly.ln2g = L.copy(p + ".norm2.weight", {D}); ly.ln2b = L.copy(p + ".norm2.bias", {D});
     }
     auto it = L.m.find(pe_pre + ".pe");
@@ -2089,7 +2136,7 @@ int fs2_set_option(const char* name, int32_t value) {
     else if (n == "FS2_ATTN_W32") o.w32 = value;
     else if (n == "FS2_ROW4") o.row4 = value;
     else if (n == "FS2_MT4") o.mt4 = value;
-    else if (n == "FS2_SCHED4") o.sched4 = value;
+    else if (n == "FS2_FFN2_MX") o.ffn2_mx = value != 0;
     else return fail(nullptr, FS2_ERR_ARG, "fs2_set_option: unknown option %s", name);
     return FS2_OK;
 }

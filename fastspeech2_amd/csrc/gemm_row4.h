@@ -66,6 +66,21 @@ __device__ __forceinline__ void acc_mfma(const bf16x8_t& fa, const bf16x8_t& fb)
     FS2_ACC_TUPLES(X)
 #undef X
 }
+// the same on fp16 fragments (an mx unit of 64 fp16 channels: gemm_mx.h)
+template <int T>
+__device__ __forceinline__ void acc_mfma_f16(const bf16x8_t& fa, const bf16x8_t& fb) {
+#define X(t, r0, r1, r2, r3) if constexpr (T == t) asm volatile("v_mfma_f32_16x16x32_f16 a[" #r0 ":" #r3 "], %0, %1, a[" #r0 ":" #r3 "]" : : "v"(fa), "v"(fb) : "a" #r0, "a" #r1, "a" #r2, "a" #r3);
+    FS2_ACC_TUPLES(X)
+#undef X
+}
+// acc[T] += A.B on an mx unit of 128 e4m3 channels: ONE block-scaled K = 128 MFMA (32 cycles); operands = both 16-byte pieces of the row, the
+// E8M0 scale bytes (one constant per tensor, x 0x01010101) in architectural registers
+template <int T>
+__device__ __forceinline__ void acc_mfma_mx(const v8i_t& fa, const v8i_t& fb, int sa, int sb) {
+#define X(t, r0, r1, r2, r3) if constexpr (T == t) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 a[" #r0 ":" #r3 "], %0, %1, a[" #r0 ":" #r3 "], %2, %3 op_sel_hi:[0,0,0]" : : "v"(fa), "v"(fb), "v"(sa), "v"(sb) : "a" #r0, "a" #r1, "a" #r2, "a" #r3);
+    FS2_ACC_TUPLES(X)
+#undef X
+}
 // acc[T] = v
 template <int T>
 __device__ __forceinline__ void acc_set(const f32x4& v) {
@@ -100,8 +115,13 @@ __device__ long long g_row_phase[8][8];
 // split-bf16 planes (FFN2 + LN2; out-proj + LN1 in bf16x3 mode), 1 = LayerNorm -> fp32 rows + mx planes (out-proj + LN1 in mix_mx mode),
 // 2 = LayerNorm -> ReLU -> x_scale v + alpha pe -> fp32 rows + split-bf16 planes (the decoder input layer).  Everything else stays on gemm_row8_bf16
 // (fs2_runtime.hip: use_row4).
-template <int NSPLIT, int NB, int MT, int EPI = 0, int SCHED = 2>
+// ARITH = 2 (FFN2 + LN2 in mix_mx mode): the "mx" arithmetic of gemm_mx.h on this GEMM -- the A planes are mx planes (the hidden
+// layer leaves FFN1's epilogue that way, with the static scale 2^kh of its a-priori bound), the weight image is the mx image of w_2: the first half of
+// the 128-byte units are 64 fp16 channels (two fp16 MFMAs per fragment pair), the second half 128 e4m3 channels (ONE block-scaled MFMA): 32 matrix-pipe
+// cycles per accumulator and unit instead of 48.  Same DMA pieces, ring, barriers and fragment reads; simulated first (tools/arith_sim_ffn2.py).
+template <int NSPLIT, int NB, int MT, int EPI = 0, int SCHED = 2, int ARITH = 0>
 __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
+    static_assert(ARITH == 0 || (ARITH == 2 && NSPLIT == 3), "split-bf16 (0) or mx (2) operands");
     constexpr int NT = 4 * NB, NP = NT / 2, BM = 32 * MT, BN = 128 * NB, RW = 16 * MT;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int PIECES = MT + 4 * NB;                       // one-KB LDS-DMA pieces per wave and stage: A pieces first (they come from HBM), then B
@@ -216,15 +236,24 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
             if (NSPLIT == 3) f.l[u] = *reinterpret_cast<const bf16x8_t*>(bp1 + buf * STAGE + (n2 + u) * 2048);
         }
     };
-    // the MFMAs of one group (n-tiles n2, n2 + 1), flat index m = 0 .. in gemm_row8_bf16's order (per accumulator: lo.hi, hi.lo, hi.hi);
-    // after MFMA number m the callback `between(m)` may issue something else (a DMA piece).  asm volatile: issued in program order.
-    auto mfma_group = [&](const AFrag& fa, const BPair& fb, auto n2_tag, auto&& between) __attribute__((always_inline)) {
-        constexpr int n2 = decltype(n2_tag)::value;
-        for_seq_i<0, (NSPLIT == 3 ? 6 : 2) * MT>([&](auto m_tag) __attribute__((always_inline)) {
+    // the MFMAs of one group (n-tiles n2, n2 + 1), flat index m = 0 .. in gemm_row8_bf16's order (per accumulator: lo.hi, hi.lo, hi.hi); KIND 1 / 2: an mx
+    // unit of fp16 / of e4m3 channels (per accumulator: piece 0 then piece 1 / one scaled MFMA).  After MFMA number m the callback `between(m)` may issue
+    // something else (a DMA piece).  asm volatile: issued in program order.
+    auto group_mfmas = [](int kind) constexpr { return kind == 0 ? (NSPLIT == 3 ? 6 : 2) * MT : (kind == 1 ? 4 * MT : 2 * MT); };
+    const int mx_sa = a.mx_scale, mx_sb = a.mx_scale_b;
+    auto mfma_group = [&](auto kind_tag, const AFrag& fa, const BPair& fb, auto n2_tag, auto&& between) __attribute__((always_inline)) {
+        constexpr int n2 = decltype(n2_tag)::value, KIND = decltype(kind_tag)::value;
+        for_seq_i<0, group_mfmas(KIND)>([&](auto m_tag) __attribute__((always_inline)) {
             constexpr int m = decltype(m_tag)::value;
             constexpr int blk = m / (2 * MT), u = (m % (2 * MT)) / MT, mt = m % MT;
             constexpr int T = mt * NT + n2 + u;
-            if constexpr (NSPLIT == 3) {
+            if constexpr (KIND == 2) {
+                acc_mfma_mx<T>(__builtin_shufflevector(__builtin_bit_cast(v4i_t, fa.h[mt]), __builtin_bit_cast(v4i_t, fa.l[mt]), 0, 1, 2, 3, 4, 5, 6, 7),
+                               __builtin_shufflevector(__builtin_bit_cast(v4i_t, fb.h[u]), __builtin_bit_cast(v4i_t, fb.l[u]), 0, 1, 2, 3, 4, 5, 6, 7), mx_sa, mx_sb);
+            } else if constexpr (KIND == 1) {
+                if constexpr (blk == 0) acc_mfma_f16<T>(fa.h[mt], fb.h[u]);
+                else acc_mfma_f16<T>(fa.l[mt], fb.l[u]);
+            } else if constexpr (NSPLIT == 3) {
                 if constexpr (blk == 0) acc_mfma<T>(fa.l[mt], fb.h[u]);
                 else if constexpr (blk == 1) acc_mfma<T>(fa.h[mt], fb.l[u]);
                 else acc_mfma<T>(fa.h[mt], fb.h[u]);
@@ -236,9 +265,9 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     };
     // deal the pieces [first, first + cnt) of stage `it` (ring slot buf) out evenly over a group's MFMAs: piece j goes behind MFMA number
     // floor((j + 1) gm / (cnt + 1)) - 1.  `between` callback of mfma_group.
-    auto deal = [&](auto m_tag, auto first_tag, auto cnt_tag, int it, int buf) __attribute__((always_inline)) {
+    auto deal = [&](auto kind_tag, auto m_tag, auto first_tag, auto cnt_tag, int it, int buf) __attribute__((always_inline)) {
         constexpr int first = decltype(first_tag)::value, cnt = decltype(cnt_tag)::value, m = decltype(m_tag)::value;
-        constexpr int gm = (NSPLIT == 3 ? 6 : 2) * MT;
+        constexpr int gm = group_mfmas(decltype(kind_tag)::value);
         for_seq_i<0, cnt>([&](auto j_tag) __attribute__((always_inline)) {
             constexpr int j = decltype(j_tag)::value;
             constexpr int raw = ((j + 1) * gm) / (cnt + 1) - 1, slot = raw < 0 ? 0 : (raw > gm - 1 ? gm - 1 : raw);
@@ -263,8 +292,9 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
 
     // one k-step: fragments of step `it` in (fc: A, fb0: first B pair); leaves those of step it + 1 in (fn, fb0).  MORE1 / MORE2 (compile
     // time): stages it + 1 / it + 2 exist -- the loop's last two steps are instantiations of their own, so no DMA piece sits behind a branch.
-    auto k_step = [&](AFrag& fc, AFrag& fn, int it, auto more1_tag, auto more2_tag) __attribute__((always_inline)) {
+    auto k_step = [&](auto kind_tag, AFrag& fc, AFrag& fn, int it, auto more1_tag, auto more2_tag) __attribute__((always_inline)) {
         constexpr bool MORE1 = decltype(more1_tag)::value, MORE2 = decltype(more2_tag)::value;
+        using KT = decltype(kind_tag);
         const int cur = it & 1;
         for_seq_i<0, NP>([&](auto p_tag) __attribute__((always_inline)) {
             constexpr int p = decltype(p_tag)::value;
@@ -275,9 +305,9 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
                 load_B(fnext, cur, 2 * (p + 1));
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (p < SCHED && MORE1 && (cut(p + 2) > cut(p + 1)))
-                    mfma_group(fc, fthis, N2{}, [&](auto m_tag) __attribute__((always_inline)) {
-                        deal(m_tag, std::integral_constant<int, cut(p + 1)>{}, std::integral_constant<int, cut(p + 2) - cut(p + 1)>{}, it + 1, cur ^ 1); });
-                else mfma_group(fc, fthis, N2{}, nothing);
+                    mfma_group(KT{}, fc, fthis, N2{}, [&](auto m_tag) __attribute__((always_inline)) {
+                        deal(KT{}, m_tag, std::integral_constant<int, cut(p + 1)>{}, std::integral_constant<int, cut(p + 2) - cut(p + 1)>{}, it + 1, cur ^ 1); });
+                else mfma_group(KT{}, fc, fthis, N2{}, nothing);
             } else {
                 // every fragment of stage `it` is in registers (the last pair was requested a group ago); stage it + 1 must have landed everywhere
                 if constexpr (MORE1) {
@@ -286,20 +316,31 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
                     load_B(fnext, cur ^ 1, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (MORE2) mfma_group(fc, fthis, N2{}, [&](auto m_tag) __attribute__((always_inline)) { deal(m_tag, I0{}, IPL{}, it + 2, cur); });
-                else mfma_group(fc, fthis, N2{}, nothing);
+                if constexpr (MORE2) mfma_group(KT{}, fc, fthis, N2{}, [&](auto m_tag) __attribute__((always_inline)) { deal(KT{}, m_tag, I0{}, IPL{}, it + 2, cur); });
+                else mfma_group(KT{}, fc, fthis, N2{}, nothing);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    // (niter is even and >= 2: the launcher checks)
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    using KL = std::integral_constant<int, ARITH == 2 ? 2 : 0>;      // the kind of the last steps
     int it = 0;
-    for (; it + 2 < niter; it += 2) {
-        k_step(fa0, fa1, it, std::true_type{}, std::true_type{});
-        k_step(fa1, fa0, it + 1, std::true_type{}, std::true_type{});
+    if constexpr (ARITH == 2) {
+        // (niter is a multiple of 4, >= 4: the launcher checks; units [0, niter / 2) hold fp16 channels, the rest e4m3 channels)
+        for (; it < niter / 2; it += 2) {
+            k_step(K1{}, fa0, fa1, it, std::true_type{}, std::true_type{});
+            k_step(K1{}, fa1, fa0, it + 1, std::true_type{}, std::true_type{});
+        }
     }
-    k_step(fa0, fa1, it, std::true_type{}, std::false_type{});
-    k_step(fa1, fa0, it + 1, std::false_type{}, std::false_type{});
+    // (niter is even and >= 2: the launcher checks)
+    for (; it + 2 < niter; it += 2) {
+        k_step(KL{}, fa0, fa1, it, std::true_type{}, std::true_type{});
+        k_step(KL{}, fa1, fa0, it + 1, std::true_type{}, std::true_type{});
+    }
+    k_step(KL{}, fa0, fa1, it, std::true_type{}, std::false_type{});
+    k_step(KL{}, fa1, fa0, it + 1, std::false_type{}, std::false_type{});
     FS2_RT(2)
 
     // ---- epilogue (gemm_row8_bf16's arithmetic): the rows stay in the accumulator file and are read three times -- row sums, centred sums of

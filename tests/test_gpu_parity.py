@@ -680,8 +680,8 @@ def test_c5_all_1024_utterances_through_the_eight_shards(env, monkeypatch):
     after another on this box's one GPU through `ShardedSynthesizer` -- the sync-free single-GPU path into the very send buffers of the
     collective -- with `torch.distributed` replaced by a stand-in that plays the eight ranks in turn and hands the last one the eight send
     buffers as its all-gather result; `gather_shards` then does what it does on a node (frame counts out of the tail rows, device-side offsets,
-    `fs2_op_unpack_rows_dev`).  Every one of the 1,024 utterances (613 k frames) is compared with the oracle, and the assembled result is
-    bit-identical to the unsharded 1,024-utterance call.  mix_mx (what bench.py runs).  The real 8-rank collective is covered over gloo
+    `fs2_op_unpack_rows_dev`).  Every one of the 1,024 utterances (613 k frames) is compared with the oracle; the assembled result is bit-identical
+    to every shard run alone and within 2e-5 of the unsharded 1,024-utterance call (variants by batch size).  mix_mx (what bench.py runs).  The real 8-rank collective is covered over gloo
     (tests/test_parallel_gloo.py) and over nccl in tests/test_gpu_multi.py."""
     model, sd, cfg, O = env
     import fastspeech2_amd.parallel as P
@@ -734,13 +734,32 @@ def test_c5_all_1024_utterances_through_the_eight_shards(env, monkeypatch):
         model.precision = "fp32"
     mels, ol_dev = out
     assert torch.equal(ol_dev.cpu(), b["olens"])
-    # assembled == unsharded, bit for bit, and zero beyond every utterance
-    st = (torch.cumsum(ref_ol, 0) - ref_ol).tolist()
+    # What the collective path must be is EXACT: every utterance of the assembled result is, bit for bit, what its shard computes when that
+    # shard runs alone through the plain batched entry point (host-driven layout), and zero beyond its frames.  Against the unsharded
+    # 1,024-utterance call the last bits may differ -- an utterance's values never depend on its batch-mates' values, but kernel variants are
+    # chosen by the batch's size (a 9.6 k-token shard runs the encoder's LayerNorms as separate row passes, the 77 k-token
+    # batch fused into the GEMM epilogue; sums associate differently, ~1e-6) -- so that comparison is a tolerance, recorded below.
     mels_h, ref_h = mels.cpu(), ref_pk.cpu()
-    for i in range(B):
-        L = int(ref_ol[i])
-        assert torch.equal(mels_h[i, :L], ref_h[st[i]:st[i] + L]), i
-        assert float(mels_h[i, L:].abs().sum()) == 0.0, i
+    st = (torch.cumsum(ref_ol, 0) - ref_ol).tolist()
+    model.precision = "mix_mx"
+    try:
+        with torch.no_grad():
+            for r, p_ in enumerate(parts):
+                sel = torch.as_tensor(p_)
+                il_s = il[sel]
+                Tm = int(il_s.max())
+                pk, ol_s = model.inference_batch(xs[sel.cuda()][:, :Tm], il_s, d_override=ds[sel.cuda()][:, :Tm], packed=True)
+                assert torch.equal(ol_s, b["olens"][sel])
+                pk_h, off = pk.cpu(), 0
+                for j, g in enumerate(p_):
+                    L = int(ol_s[j])
+                    assert torch.equal(mels_h[g, :L], pk_h[off:off + L]), (r, g)
+                    assert float(mels_h[g, L:].abs().sum()) == 0.0, g
+                    off += L
+    finally:
+        model.precision = "fp32"
+    vs_unsharded = max(float((mels_h[i, :int(ref_ol[i])] - ref_h[st[i]:st[i] + int(ref_ol[i])]).abs().max()) for i in range(B))
+    assert vs_unsharded <= 2e-5, vs_unsharded
     # every utterance against the oracle
     i0 = int(torch.argmax(il))
     prev_threads = _tune_oracle_threads(O, sd, cfg, b["xs"][i0:i0 + 1, :int(il[i0])], il[i0:i0 + 1], b["ds"][i0:i0 + 1, :int(il[i0])])
@@ -759,9 +778,10 @@ def test_c5_all_1024_utterances_through_the_eight_shards(env, monkeypatch):
             worst = max(worst, d)
     finally:
         torch.set_num_threads(prev_threads)
-    print("c5, all %d utterances / %d frames through the 8 LPT shards (%s utterances each): assembled == unsharded bit for bit; worst mel max-abs vs the oracle "
-          "%.2e; %d bucket decision(s) in %d utterance(s) on the other side of a bin edge (verified teacher-forced)"
-          % (B, int(ref_ol.sum()), [len(p_) for p_ in parts], worst, flipped_frames, flipped_utts))
+    print("c5, all %d utterances / %d frames through the 8 LPT shards (%s utterances each): assembled == each shard run alone, bit for bit; vs the unsharded "
+          "1,024-utterance call %.1e (kernel variants by batch size); worst mel max-abs vs the oracle %.2e; %d bucket decision(s) in %d utterance(s) on the other "
+          "side of a bin edge (verified teacher-forced)" % (B, int(ref_ol.sum()), [len(p_) for p_ in parts], vs_unsharded, worst, flipped_frames, flipped_utts))
+    record_measurement("c5_all1024_sharded_vs_unsharded_maxabs_mix_mx", vs_unsharded)
     record_measurement("c5_all1024_mel_maxabs_mix_mx", worst)
     record_measurement("c5_all1024_flipped_bucket_decisions_mix_mx", flipped_frames)
 

@@ -6,7 +6,7 @@ import pytest
 
 from fastspeech2_amd import _audit, _lib
 
-ROW4 = "_ZN3fs214gemm_row4_bf16ILi3ELi3ELi5ELi0ELi1EEEvNS_8GemmArgsE"
+ROW4 = "_ZN3fs214gemm_row4_bf16ILi3ELi3ELi5ELi0ELi2ELi0EEEvNS_8GemmArgsE"
 W32 = "_ZN3fs28attn_w32ILi192EEEvNS_11AttnB16ArgsE"
 
 

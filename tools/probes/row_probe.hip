@@ -9,6 +9,7 @@
 #include <cmath>
 #include <vector>
 #include "gemm_row4.h"
+#include "gemm_mx.h"
 using namespace fs2;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -35,6 +36,13 @@ static void launch_row8(const GemmArgs& a) {
     static bool done = false;
     if (!done) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_row8_bf16<3, 3, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
     hipLaunchKernelGGL((gemm_row8_bf16<3, 3, MT>), dim3((a.R + 64 * MT - 1) / (64 * MT)), dim3(512), lds, 0, a);
+}
+template <int MT>
+static void launch_row4_mx(const GemmArgs& a) {
+    constexpr size_t lds = row4_lds_bytes<3, MT>();
+    static bool done = false;
+    if (!done) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_row4_bf16<3, 3, MT, 0, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    hipLaunchKernelGGL((gemm_row4_bf16<3, 3, MT, 0, 2, 2>), dim3((a.R + 32 * MT - 1) / (32 * MT)), dim3(256), lds, 0, a);
 }
 template <int MT, int EPI, int SCHED>
 static void launch_row4(const GemmArgs& a) {
@@ -143,6 +151,54 @@ int main(int argc, char** argv) {
         if (epi == 1) { T("row4<128,s2>", [&](const GemmArgs& a) { launch_row4<4, 1, 2>(a); }); T("row4<160,s2>", [&](const GemmArgs& a) { launch_row4<5, 1, 2>(a); }); }
         if (epi == 2) { T("row4<128,s2>", [&](const GemmArgs& a) { launch_row4<4, 2, 2>(a); }); T("row4<160,s2>", [&](const GemmArgs& a) { launch_row4<5, 2, 2>(a); }); }
     }
+    // ---- the mx arithmetic (ARITH = 2) against split-bf16 on CONSISTENT operands: one fp32 matrix (non-negative, like a ReLU output) and one fp32 weight,
+    // turned into both plane / image formats by the library's own kernels; static scales from a deliberately loose bound (x 200, as in the model)
+    if (C % 128 == 0 && (size_t)R * C * 4 < (size_t)3 << 30) {
+        std::vector<float> hxf((size_t)Rpad * C), hwf((size_t)N * C);
+        for (auto& v : hxf) v = 3.f * (rand() & 0xffff) / 65536.f * ((rand() & 3) ? 1.f : 0.f);
+        for (auto& v : hwf) v = 0.06f * ((rand() & 0xffff) - 32768) / 32768.f;
+        float *xf, *wf; void *xb, *xm, *wbf, *wmx;
+        CK(hipMalloc(&xf, hxf.size() * 4)); CK(hipMemcpy(xf, hxf.data(), hxf.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMalloc(&wf, hwf.size() * 4)); CK(hipMemcpy(wf, hwf.data(), hwf.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMalloc(&xb, hxf.size() * 4)); CK(hipMalloc(&xm, hxf.size() * 4)); CK(hipMalloc(&wbf, hwf.size() * 4)); CK(hipMalloc(&wmx, hwf.size() * 4));
+        const int kh = (int)floorf(log2f(448.f / (3.f * 200.f))), kw = (int)floorf(log2f(448.f / 0.06f));
+        const int64_t nx = (int64_t)Rpad * (C / 4);
+        hipLaunchKernelGGL(to_planes, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, 0, xf, C, C, Rpad, nchunks, xb, 0, 1.f);
+        hipLaunchKernelGGL(to_planes, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, 0, xf, C, C, Rpad, nchunks, xm, 2, exp2f((float)kh));
+        const int64_t tb = (int64_t)N * nchunks * 32;
+        hipLaunchKernelGGL(repack_weight_bf16, dim3((unsigned)((tb + 255) / 256)), dim3(256), 0, 0, wf, N, C, 1, N, nchunks, (const float*)nullptr, (const float*)nullptr, 0.f, (__bf16*)wbf, 0, 0);
+        const size_t mxb = mx_image_bytes(N, C, 1);
+        hipLaunchKernelGGL(repack_weight_mx, dim3((unsigned)((mxb / 2 + 255) / 256)), dim3(256), 0, 0, wf, N, C, 1, N, kw, (unsigned short*)wmx);
+        CK(hipDeviceSynchronize());
+        auto b4 = [](int e) { const int b = e < 1 ? 1 : (e > 254 ? 254 : e); return b * 0x01010101; };
+        GemmArgs ab = args(0, 0, ref);
+        ab.Xp = xb; ab.W = (const float*)wbf; ab.Wb = wbf;
+        GemmArgs am = args(0, 0, out[0]);
+        am.Xp = xm; am.W = (const float*)wmx; am.Wb = wmx; am.mx = 1; am.mx_scale = b4(127 - kh - 11); am.mx_scale_b = b4(127 - kw);
+        launch_row8<2>(ab);
+        CK(hipDeviceSynchronize());
+        std::vector<float> yr((size_t)R * N), ym((size_t)R * N);
+        CK(hipMemcpy(yr.data(), ref.y, yr.size() * 4, hipMemcpyDeviceToHost));
+        for (int mtv = 4; mtv <= 5; ++mtv) {
+            CK(hipMemset(out[0].y, 0xff, ybytes));
+            if (mtv == 4) launch_row4_mx<4>(am); else launch_row4_mx<5>(am);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(ym.data(), out[0].y, ym.size() * 4, hipMemcpyDeviceToHost));
+            double worst = 0, mag = 0; size_t nanc = 0;
+            for (size_t i = 0; i < yr.size(); ++i) { if (!(ym[i] == ym[i])) ++nanc; worst = fmax(worst, fabs((double)ym[i] - yr[i])); mag = fmax(mag, fabs((double)yr[i])); }
+            printf("  mx (fp16 + e4m3 cross terms, scales 2^%d / 2^%d) row4<%d rows> vs split-bf16 row8: max |diff| %.3e at max |y| %.2f, %zu NaN%s\n", kh, kw, 32 * mtv, worst, mag, nanc,
+                   (worst > 1e-3 || nanc) ? "  FAILED" : "");
+            if (worst > 1e-3 || nanc) ++bad;
+        }
+        auto Tm = [&](const char* nm, auto launch) {
+            const float us = time_kernel([&](int) { launch(); }, reps);
+            printf("  FFN2-like  %-18s %8.1f us   %7.1f TFLOP/s\n", nm, us, flop / us * 1e-6);
+        };
+        Tm("row8<128> bf16x3", [&] { launch_row8<2>(ab); });
+        Tm("row4<160> bf16x3", [&] { launch_row4<5, 0, 2>(ab); });
+        Tm("row4<128> mx", [&] { launch_row4_mx<4>(am); });
+        Tm("row4<160> mx", [&] { launch_row4_mx<5>(am); });
+    }
 #ifdef FS2_ROW_TIMING
     for (int mtv = 4; mtv <= 5; ++mtv) {
         long long z[8][8]; memset(z, 0, sizeof z);
@@ -154,5 +210,6 @@ int main(int argc, char** argv) {
         for (int w = 0; w < 8; ++w) if (z[w][4]) printf("    wg %3d: %7lld | %7lld | %7lld | %7lld\n", 32 * w, z[w][1] - z[w][0], z[w][2] - z[w][0], z[w][3] - z[w][0], z[w][4] - z[w][0]);
     }
 #endif
+    printf("probe: %s\n", bad ? "FAILED" : "ok");
     return bad ? 1 : 0;
 }
