@@ -57,7 +57,7 @@ def test_the_shipped_library_carries_a_clean_audit_record_of_its_own_binary():
     assert rec is not None, "no audit record for this binary: build it with __graft_entry__.build()"
     assert rec["clean"] and rec["violations"] == 0, rec
     kinds = [v["kind"] for v in rec["kernels"].values()]
-    assert kinds.count("attn_w32") >= 2 and kinds.count("gemm_row4_bf16") >= 12, kinds
+    assert kinds.count("attn_w32") >= 2 and kinds.count("gemm_row4_bf16") >= 8, kinds
     assert all(v["asm_mfma"] > 0 for v in rec["kernels"].values())
 
 
