@@ -353,7 +353,6 @@ inline int row4_mt(long rows) {
 inline int row4_epi(const GemmArgs& a) {
     if (a.ktaps != 1 || a.N != 384 || !a.ln_g || !a.Y || !a.Yp || a.relu_pre || a.dot_w || a.k_groups > 1 || a.ln_groups > 1 || a.qk_hi || a.yp_col_off) return -1;
     if (a.Cpad % 64 != 0 || a.yp_chunks * 32 != a.N) return -1;      // an even number of k-steps; planes exactly N wide
-    if ((unsigned long long)a.R * (unsigned)a.Cpad * 4ull >= (1ull << 32)) return -1;      // the LDS-DMA pieces address the A planes as base + 32-bit byte offset
     if (a.pe) return (a.act_post == 1 && a.yp_f16 == 0) ? 2 : -1;
     if (a.act_post != 0) return -1;
     return a.yp_f16 == 0 ? 0 : (a.yp_f16 == 2 ? 1 : -1);

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     const int arow0 = m0 + wave * 8 + jrow;
     unsigned a_off[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a_off[i] = (unsigned)min(arow0 + 32 * i, a.R - 1) * (unsigned)(niter * 128) + (unsigned)(sA * 16);
+    for (int i = 0; i < MT; ++i) a_off[i] = (unsigned)(min(arow0 + 32 * i, a.R - 1) - m0) * (unsigned)(niter * 128) + (unsigned)(sA * 16);
     // B: piece u of wave w (q = w + 4 u) fills LDS rows 32 u + 8 w + jrow = n-tile 2 u + (w >> 1), tile row jB; that row belongs to
     // weight row 64 (u >> 1) + 4 rperm_inv(jB) + 2 (u & 1) + (w >> 1) (gemm_planes.h: four consecutive channels per lane)
     const int jB = (wave & 1) * 8 + jrow;
@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     unsigned b_off[4 * NB];
 #pragma unroll
     for (int u = 0; u < 4 * NB; ++u) b_off[u] = (unsigned)(64 * (u >> 1) + 4 * rperm_inv(jB) + 2 * (u & 1) + (wave >> 1)) * (unsigned)(niter * 128) + (unsigned)(sB * 16);
-    gchar_t* abase0 = uniform_ptr(Xp);
+    // (offsets relative to the TILE's first row, < 1 MB: as offsets from the start of the planes they passed 2^31 on a 630 k-row launch -- c5 unsharded,
+    //  4 KB rows -- and the results of the rows beyond were wrong: the 32-bit VGPR offset of the SGPR-base addressing form is not safe to use as unsigned)
+    gchar_t* abase0 = uniform_ptr(reinterpret_cast<const char*>(Xp) + (size_t)m0 * niter * 128);
     gchar_t* bbase0 = uniform_ptr(Wb);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t*)smem_q);
     const unsigned ldsw = lds0 + wave * 1024;

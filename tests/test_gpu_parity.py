@@ -206,6 +206,44 @@ def test_c2_row_complete_tile_heights_are_bit_identical(env, fs2_option):
         model.precision = "fp32"
 
 
+def test_c2_one_wave_per_simd_row_kernel_is_bit_identical_to_the_8_wave_one(env, fs2_option):
+    """gemm_row4_bf16 (one wave per SIMD, accumulators in literal AGPRs; the decoder's out-proj + LN1, FFN2 + LN2 and input layer) keeps
+    gemm_row8_bf16's operands, layouts and per-accumulator MFMA order: with the row-complete kernels forced at c2, the forward with FS2_ROW4 = 0 and
+    with FS2_ROW4 = 1 at both tile heights (FS2_MT4 = 4 | 5: 128 / 160 rows) must not differ in a single bit -- in split-bf16 and, with FFN2 kept
+    on split-bf16 (FS2_FFN2_MX = 0), in mix_mx (whose out-proj epilogue writes mx planes: EPI 1).  With FFN2 + LN2 in the mx arithmetic
+    (gemm_row4.h ARITH = 2, the default of mix_mx where that kernel runs) the result is another rounding of the same sums: within 2e-5 of the
+    split-bf16 FFN2, the same at both tile heights bit for bit, and within the mode's tolerance of the oracle."""
+    model, sd, cfg, O = env
+    from fastspeech2_amd.synthetic import make_batch
+    b = make_batch("c2")
+    fs2_option("FS2_ROW8", 1)
+    fs2_option("FS2_QKV8", 1)
+    run = lambda: model.inference_batch(b["xs"].cuda(), b["ilens"], d_override=b["ds"].cuda())[0]
+    try:
+        for precision in ("bf16x3", "mix_mx"):
+            model.precision = precision
+            fs2_option("FS2_FFN2_MX", 0)
+            outs = {}
+            for row4, mt in ((0, -1), (1, 4), (1, 5)):
+                fs2_option("FS2_ROW4", row4)
+                fs2_option("FS2_MT4", mt)
+                with torch.no_grad():
+                    outs[(row4, mt)] = run()
+            assert torch.equal(outs[(0, -1)], outs[(1, 4)]) and torch.equal(outs[(0, -1)], outs[(1, 5)]), precision
+        fs2_option("FS2_FFN2_MX", 1)                                   # (mix_mx still selected)
+        mx = {}
+        for mt in (4, 5):
+            fs2_option("FS2_MT4", mt)
+            with torch.no_grad():
+                mx[mt] = run()
+        assert torch.equal(mx[4], mx[5])
+        d = float((mx[5] - outs[(1, 5)]).abs().max())
+        assert 0.0 < d <= 2e-5, d                                      # another rounding of the same sums (and really another kernel: d > 0)
+        _c2_body(model, sd, cfg, O, b, "mix_mx")
+    finally:
+        model.precision = "fp32"
+
+
 @pytest.mark.parametrize("row8", [0, 1])
 def test_c2_fused_pitch_and_energy_predictors(env, row8, fs2_option):
     """The two variance predictors read the same input (reference fastspeech.py:194-196,214-217): in the bf16 modes they run as one launch per
