@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     unsigned b_off[4 * NB];
 #pragma unroll
     for (int u = 0; u < 4 * NB; ++u) b_off[u] = (unsigned)(64 * (u >> 1) + 4 * rperm_inv(jB) + 2 * (u & 1) + (wave >> 1)) * (unsigned)(niter * 128) + (unsigned)(sB * 16);
-    // (offsets relative to the TILE's first row, < 1 MB: as offsets from the start of the planes they passed 2^31 on a 630 k-row launch -- c5 unsharded,
-    //  4 KB rows -- and the results of the rows beyond were wrong: the 32-bit VGPR offset of the SGPR-base addressing form is not safe to use as unsigned)
+    // (offsets relative to the TILE's first row, < 1 MB, so that nothing depends on how the SGPR-base addressing form extends its 32-bit VGPR offset:
+    //  as offsets from the start of the planes they pass 2^31 on a 630 k-row launch with 4-KB rows -- c5 unsharded)
     gchar_t* abase0 = uniform_ptr(reinterpret_cast<const char*>(Xp) + (size_t)m0 * niter * 128);
     gchar_t* bbase0 = uniform_ptr(Wb);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t*)smem_q);
