@@ -51,7 +51,7 @@ WORKLOAD_TEXT = {
 
 
 def csrc_sha16():
-    """Fingerprint of the kernel sources (what profiles/r04_traffic.json was measured on)."""
+    """Fingerprint of the kernel sources (what profiles/r05_traffic.json was measured on)."""
     import hashlib
     hsh = hashlib.sha256()
     d = os.path.join(ROOT, "fastspeech2_amd", "csrc")
@@ -537,11 +537,11 @@ def main():
     try:    # HBM-side bytes per launch + the matrix-pipe occupancy of the same kernel: rocprofv3 PMC passes of this same command (tools/profile_round.sh
         # -> tools/pmc_summary.py -> profiles/).  The record names the kernel sources it was measured on: after any change to them it is stale and
         # the fields stay null instead of quoting an old kernel
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r05_traffic.json")))
         if (tr["workload"] == workload and tr["precision"] == args.precision and tr["kernel_site"] == dom_name and world == 1
                 and tr.get("csrc_sha16") == csrc_sha16()):
             roofline["traffic"] = tr["traffic_bytes"]
-            roofline["traffic_note"] = ("rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r04_traffic.json (separate --pmc passes of this "
+            roofline["traffic_note"] = ("rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r05_traffic.json (separate --pmc passes of this "
                                         "command on these kernel sources)")
             if roofline.get("algorithmic_bytes"):
                 roofline["traffic_over_algorithmic"] = round(tr["traffic_bytes"] / roofline["algorithmic_bytes"], 2)

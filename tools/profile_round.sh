@@ -4,7 +4,7 @@
 # tools/pmc_summary.py on the build host and commit the summaries under profiles/.
 #   tools/profile_round.sh <tag> [workload] [precision] [pmc: 0|1]
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 WL=${2:-c3}
 PREC=${3:-mix_mx}
 PMC=${4:-1}
@@ -12,7 +12,7 @@ OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python /root/repo/bench.py --workload $WL --precision $PREC --steps 4 --warmup 2 --no-cpu-baseline"
+CMD="python /root/repo/bench.py --workload $WL --precision $PREC --steps 4 --warmup 2 --no-cpu-baseline --sustain 0"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $CMD > "$OUT/trace.log" 2>&1
 if [ "$PMC" = "1" ]; then
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o p -- $CMD > "$OUT/fetch.log" 2>&1
