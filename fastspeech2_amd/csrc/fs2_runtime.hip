@@ -96,6 +96,7 @@ struct Options {
     int w32 = -1;        // FS2_ATTN_W32 split-bf16 attention with 32 queries per wave (attn_w32.h): 0 never, 1 whenever the head dim allows, -1 by regime
     int row4 = -1;       // FS2_ROW4     the one-wave-per-SIMD row-complete kernel (gemm_row4.h) wherever gemm_row8_bf16 would run and it has the epilogue: 0 never, else yes
     int mt4 = -1;        // FS2_MT4      its m-tiles per wave (4 | 5: 128 / 160-row workgroups; -1: by the round count)
+    int qkv4 = -1;       // FS2_QKV4     the fused QKV projection's passes on gemm_row4_bf16 (EPI 3) wherever gemm_qkv8_bf16 would run at D = 384: 0 never, else yes
     int ffn2_mx = 1;     // FS2_FFN2_MX  mix_mx mode: the second FFN GEMM in the mx arithmetic too, wherever gemm_row4_bf16 runs it (0: split-bf16 as in round 4)
 };
 int env_int(const char* name, int dflt) {
@@ -107,7 +108,7 @@ Options& opts() {
         Options x;
         x.bm = env_int("FS2_BM", -1); x.row8 = env_int("FS2_ROW8", -1); x.qkv8 = env_int("FS2_QKV8", -1);
         x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.qkv_split = env_int("FS2_QKV_SPLIT", -1); x.op_att_planes = env_int("FS2_OP_ATT_PLANES", 0); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 0); x.w32 = env_int("FS2_ATTN_W32", -1);
-        x.row4 = env_int("FS2_ROW4", -1); x.mt4 = env_int("FS2_MT4", -1); x.ffn2_mx = env_int("FS2_FFN2_MX", 1);
+        x.row4 = env_int("FS2_ROW4", -1); x.mt4 = env_int("FS2_MT4", -1); x.ffn2_mx = env_int("FS2_FFN2_MX", 1); x.qkv4 = env_int("FS2_QKV4", -1);
         return x;
     }();
     return o;
@@ -423,6 +424,26 @@ hipError_t launch_qkv8(hipStream_t s, const GemmArgs& a) {
     return apart ? launch_qkv8_t<NSPLIT, NB, 2, true>(s, a) : launch_qkv8_t<NSPLIT, NB, 2, false>(s, a);
 }
 
+// The fused QKV projection's passes on the one-wave-per-SIMD structure (gemm_row4.h, EPI 3): always one workgroup per (row tile, pass); the tile height that
+// minimises rounds x height of the 3 T pass-workgroups (c3: 160 rows = 687 units = 2.7 rounds against 858 = 3.4 rounds of 128 rows).  Bit-identical to gemm_qkv8_bf16.
+inline int qkv4_mt(long rows) {
+    const long r4 = (3 * ((rows + 127) / 128) + kCus - 1) / kCus * 128, r5 = (3 * ((rows + 159) / 160) + kCus - 1) / kCus * 160;
+    return r5 <= r4 ? 5 : 4;
+}
+template <int MT>
+hipError_t launch_qkv4_t(hipStream_t s, const GemmArgs& a) {
+    static LdsAttr attr;
+    constexpr size_t lds = row4_lds_bytes<3, MT>();
+    static_assert((size_t)32 * MT * kQkvLd * 4 <= row4_lds_bytes<3, MT>(), "the V pass transposes its tile through the operand ring's memory");
+    allow_lds(reinterpret_cast<const void*>(&gemm_row4_bf16<3, 3, MT, 3, 2, 0>), lds, attr);
+    hipLaunchKernelGGL((gemm_row4_bf16<3, 3, MT, 3, 2, 0>), dim3((a.Rvt + 32 * MT - 1) / (32 * MT), 3), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_qkv4(hipStream_t s, const GemmArgs& a) {
+    const int mt = (opts().mt4 == 4 || opts().mt4 == 5) ? opts().mt4 : qkv4_mt(rows_in_use(a, a.Rvt));
+    return mt == 5 ? launch_qkv4_t<5>(s, a) : launch_qkv4_t<4>(s, a);
+}
+
 // Fused QKV projection on the 8-wave structure when there is about a CU's worth of 128-row tiles (FS2_QKV8=0|1 forces the choice)
 bool use_qkv8(const GemmArgs& a) {
     if (!a.qk_hi || a.ktaps != 1 || (a.att_D != 256 && a.att_D != 384) || a.N != 3 * a.att_D) return false;
@@ -580,6 +601,8 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
                 e = launch_mx(s, t);
             } else if (a.f16_terms) {
                 e = a.f16_terms == 3 ? launch_pl_f16<3>(s, t) : (a.f16_terms == 2 ? launch_pl_f16<2>(s, t) : launch_pl_f16<1>(s, t));
+            } else if (use_qkv8(t) && precision == FS2_PREC_BF16X3 && opts().qkv4 != 0 && opts().row4 != 0 && a.att_D == 384 && a.Cpad % 64 == 0) {
+                e = launch_qkv4(s, t);
             } else if (use_qkv8(t)) {
                 if (a.att_D == 384) e = (precision == FS2_PREC_BF16X3) ? launch_qkv8<3, 3>(s, t) : launch_qkv8<1, 3>(s, t);
                 else e = (precision == FS2_PREC_BF16X3) ? launch_qkv8<3, 2>(s, t) : launch_qkv8<1, 2>(s, t);
@@ -2136,6 +2159,7 @@ int fs2_set_option(const char* name, int32_t value) {
     else if (n == "FS2_ROW4") o.row4 = value;
     else if (n == "FS2_MT4") o.mt4 = value;
     else if (n == "FS2_FFN2_MX") o.ffn2_mx = value != 0;
+    else if (n == "FS2_QKV4") o.qkv4 = value;
     else return fail(nullptr, FS2_ERR_ARG, "fs2_set_option: unknown option %s", name);
     return FS2_OK;
 }

@@ -114,7 +114,9 @@ __device__ long long g_row_phase[8][8];
 // instruction stream 12 MT times -- the first build, with gemm_row8_bf16's run-time switches, was 400 KB of code): 0 = LayerNorm -> fp32 rows +
 // split-bf16 planes (FFN2 + LN2; out-proj + LN1 in bf16x3 mode), 1 = LayerNorm -> fp32 rows + mx planes (out-proj + LN1 in mix_mx mode),
 // 2 = LayerNorm -> ReLU -> x_scale v + alpha pe -> fp32 rows + split-bf16 planes (the decoder input layer).  Everything else stays on gemm_row8_bf16
-// (fs2_runtime.hip: use_row4).
+// (fs2_runtime.hip: use_row4).  EPI = 3: one pass (blockIdx.y: Q, K or V) of the fused QKV projection -- no LayerNorm, no residual; Q (x log2e / sqrt(d_k)) and K leave
+// as row-major split-bf16 planes [Rvt][2 D], V through a [BM][132] fp32 tile in LDS as V^T planes [D][Rvt] (8 consecutive keys per 16-byte store): gemm_qkv8_bf16's
+// outputs, bit for bit, in 160-row tiles (687 pass-workgroups at c3 instead of 858 of 128 rows).
 // ARITH = 2 (FFN2 + LN2 in mix_mx mode): the "mx" arithmetic of gemm_mx.h on this GEMM -- the A planes are mx planes (the hidden
 // layer leaves FFN1's epilogue that way, with the static scale 2^kh of its a-priori bound), the weight image is the mx image of w_2: the first half of
 // the 128-byte units are 64 fp16 channels (two fp16 MFMAs per fragment pair), the second half 128 e4m3 channels (ONE block-scaled MFMA): 32 matrix-pipe
@@ -141,6 +143,12 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     const __bf16* Xp = reinterpret_cast<const __bf16*>(a.Xp);
     const int niter = a.Cpad / 32;
     const int jrow = lane >> 3, jslot = lane & 7;
+    const int nbp = EPI == 3 ? (int)blockIdx.y : 0;           // QKV pass of this workgroup: its 128 NB weight rows / bias entries
+    if constexpr (EPI == 3) {
+        Wb += (size_t)nbp * BN * niter * 64;
+        a.bias = a.bias ? a.bias + nbp * BN : nullptr;
+        a.resid = nullptr;
+    }
 
     // A: piece i of wave w fills tile rows 32 i + 8 w + jrow (piece index q = w + 4 i, q & 1 == w & 1: the swizzle term is a per-lane constant).
     // Rows beyond R (the last tile) repeat row R - 1: their results are never stored, and rows of a GEMM do not interact.
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     const int arow0 = m0 + wave * 8 + jrow;
     unsigned a_off[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a_off[i] = (unsigned)(min(arow0 + 32 * i, a.R - 1) - m0) * (unsigned)(niter * 128) + (unsigned)(sA * 16);
+    for (int i = 0; i < MT; ++i) a_off[i] = (unsigned)(min(arow0 + 32 * i, max(a.R - 1, m0)) - m0) * (unsigned)(niter * 128) + (unsigned)(sA * 16);      // (m0 >= R: a QKV tile of padding rows)
     // B: piece u of wave w (q = w + 4 u) fills LDS rows 32 u + 8 w + jrow = n-tile 2 u + (w >> 1), tile row jB; that row belongs to
     // weight row 64 (u >> 1) + 4 rperm_inv(jB) + 2 (u & 1) + (w >> 1) (gemm_planes.h: four consecutive channels per lane)
     const int jB = (wave & 1) * 8 + jrow;
@@ -199,16 +207,16 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     f32x4 bv[NB];
 #pragma unroll
     for (int g = 0; g < NB; ++g) bv[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + col0 + 64 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-    load_resid(I0{});
+    if constexpr (EPI != 3) load_resid(I0{});
     for_seq_i<0, MT>([&](auto mt_tag) __attribute__((always_inline)) {
         constexpr int mt = decltype(mt_tag)::value;
-        if constexpr (mt + 1 < MT) load_resid(std::integral_constant<int, mt + 1>{});
+        if constexpr (mt + 1 < MT && EPI != 3) load_resid(std::integral_constant<int, mt + 1>{});
         __builtin_amdgcn_sched_barrier(0);
         for_seq_i<0, NB>([&](auto g_tag) __attribute__((always_inline)) {
             constexpr int g = decltype(g_tag)::value;
             f32x4 v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = bv[g] + rv[mt & 1][g][r];
+            for (int r = 0; r < 4; ++r) v[r] = EPI == 3 ? bv[g] : bv[g] + rv[mt & 1][g][r];
             for_seq_i<0, 4>([&](auto j_tag) __attribute__((always_inline)) {      // tuple (mt, 4 g + j): register r = row r, channel col0 + 64 g + j
                 constexpr int j = decltype(j_tag)::value;
                 acc_set<mt * NT + 4 * g + j>(f32x4{v[0][j], v[1][j], v[2][j], v[3][j]});
@@ -349,6 +357,83 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     // squares (completed across the two N-waves through LDS), then normalise + affine (+ ReLU + positional encoding) on the way out
     acc_drain();
     const int* __restrict__ rpos = a.row_pos;
+    if constexpr (EPI == 3) {
+        // this lane's rows: row(mt, r) = rowb + 16 mt + rp[r]; their validity as ONE bit mask (bit 4 mt + r); gaps and rows beyond R leave as zeros
+        unsigned vmask = 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rowb + mt * 16 + rp[r];
+                const bool ok = row < a.R && loadi_or_zero(rpos + row, rpos != nullptr && row < a.R) >= 0;
+                vmask |= ok ? (1u << (mt * 4 + r)) : 0u;
+            }
+        if (nbp < 2) {                   // Q | K: 8 + 8 bytes of hi / lo per 4 channels, 128 contiguous bytes per row and plane
+            __bf16* qkh = reinterpret_cast<__bf16*>(a.qk_hi);
+            __bf16* qkl = reinterpret_cast<__bf16*>(a.qk_lo);
+            const float sc = (nbp == 0) ? a.q_scale : 1.f;
+            for_seq_i<0, NB>([&](auto g_tag) __attribute__((always_inline)) {
+                constexpr int g = decltype(g_tag)::value;
+                for_seq_i<0, MT>([&](auto mt_tag) __attribute__((always_inline)) {
+                    constexpr int mt = decltype(mt_tag)::value;
+                    f32x4 x[4];
+                    for_seq_i<0, 4>([&](auto j_tag) __attribute__((always_inline)) { x[decltype(j_tag)::value] = acc_get<mt * NT + 4 * g + decltype(j_tag)::value>(); });
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rowb + mt * 16 + rp[r];
+                        if (row >= a.Rvt) continue;
+                        const float f = ((vmask >> (mt * 4 + r)) & 1u) ? sc : 0.f;
+                        uint2 hi, lo;
+                        split4(f32x4{x[0][r], x[1][r], x[2][r], x[3][r]} * f, hi, lo);
+                        const size_t off = (size_t)row * 2 * BN + nbp * BN + col0 + 64 * g;
+                        *reinterpret_cast<uint2*>(qkh + off) = hi;
+                        *reinterpret_cast<uint2*>(qkl + off) = lo;
+                    }
+                });
+            });
+        } else {                         // V: NB 128-column passes through a [BM][132] fp32 tile in LDS -> V^T planes (as gemm_qkv8_bf16)
+            float* tile = reinterpret_cast<float*>(smem_q);
+            __bf16* vth = reinterpret_cast<__bf16*>(a.vt_hi);
+            __bf16* vtl = reinterpret_cast<__bf16*>(a.vt_lo);
+            for_seq_i<0, NB>([&](auto pass_tag) __attribute__((always_inline)) {
+                constexpr int pass = decltype(pass_tag)::value;
+                __syncthreads();         // operand buffers / previous pass's tile are dead
+                for_seq_i<0, NB>([&](auto g_tag) __attribute__((always_inline)) {
+                    constexpr int g = decltype(g_tag)::value;
+                    const int G = wn * NB + g;           // 64-column group of the block (wave-uniform)
+                    if ((G >> 1) == pass) {
+                        for_seq_i<0, MT>([&](auto mt_tag) __attribute__((always_inline)) {
+                            constexpr int mt = decltype(mt_tag)::value;
+                            f32x4 x[4];
+                            for_seq_i<0, 4>([&](auto j_tag) __attribute__((always_inline)) { x[decltype(j_tag)::value] = acc_get<mt * NT + 4 * g + decltype(j_tag)::value>(); });
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int trow = wm * RW + mt * 16 + rp[r];
+                                *reinterpret_cast<f32x4*>(tile + trow * kQkvLd + (((G & 1) * 64 + 4 * lr) ^ qkv_tile_swz(trow))) =
+                                    ((vmask >> (mt * 4 + r)) & 1u) ? f32x4{x[0][r], x[1][r], x[2][r], x[3][r]} : f32x4{0.f, 0.f, 0.f, 0.f};
+                            }
+                        });
+                    }
+                });
+                __syncthreads();
+                // column c of the pass, rows 8 j .. 8 j + 7: 4 consecutive lanes share a column (64-byte V^T segments)
+#pragma unroll
+                for (int u = 0; u < BM / 16; ++u) {
+                    const int idx = tid + u * 256;
+                    const int c = (idx >> 2) & 127, j = ((idx >> 9) << 2) | (idx & 3);
+                    const int row = m0 + 8 * j;
+                    if (row >= a.Rvt) continue;
+                    const float* t = tile + (8 * j) * kQkvLd + (c ^ qkv_tile_swz(8 * j));      // (rows 8 j .. 8 j + 7 share one swizzle term)
+                    const SplitPair sp = split8(make_float4(t[0], t[kQkvLd], t[2 * kQkvLd], t[3 * kQkvLd]),
+                                                make_float4(t[4 * kQkvLd], t[5 * kQkvLd], t[6 * kQkvLd], t[7 * kQkvLd]));
+                    const size_t off = (size_t)(pass * 128 + c) * a.Rvt + row;
+                    *reinterpret_cast<uint4*>(vth + off) = sp.hi;
+                    *reinterpret_cast<uint4*>(vtl + off) = sp.lo;
+                }
+            });
+        }
+        return;
+    }
     float* __restrict__ Y = a.Y;
     void* __restrict__ Yp = a.Yp;
     float* red = reinterpret_cast<float*>(smem_q);      // [2 passes][4 waves][RW rows]
