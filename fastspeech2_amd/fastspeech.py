@@ -250,6 +250,12 @@ class FeedForwardTransformer(nn.Module):
         # encoding as the only decoder input layer, feat_out Linear(adim, odim)); see fastspeech2_script.py here
         ddim = m.adim if _script_twin else m.ddim
         self.idim, self.odim = idim, odim
+        # throughput mode of the sync-free entry points (inference_batch(sync=False), ShardedSynthesizer): run each call's token-level half on a side
+        # stream so that it overlaps the previous call's frame-level kernels.  The caller then guarantees that the input ids (and d_override) of a call
+        # are COMPLETE when the call is made -- not the product of work still queued on the current stream.  Off by default; results are unchanged.
+        self.overlap_encoder = False
+        self._enc_streams = {}
+        self._enc_gen_seen = -1
         self.use_scaled_pos_enc = bool(m.use_scaled_pos_enc)
         self.use_masking = bool(m.use_masking)
         self.use_weighted_masking = bool(m.use_weighted_masking)
@@ -421,7 +427,11 @@ class FeedForwardTransformer(nn.Module):
                 "training (autograd / dropout / BatchNorm batch statistics) is outside the scope of this MI355X "
                 "inference path: call model.eval() and wrap calls in torch.no_grad()")
         dev = xs.device
-        xs = xs.contiguous().long()
+        # (overlap_encoder: whatever copy these conversions need -- a column-sliced shard of a batch is not contiguous -- must run on the stream the
+        #  encoder runs on; on the current stream it would queue behind the previous call's kernels while the side stream reads the result at once)
+        in_stream = self.input_stream(dev) if capacity is not None else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(in_stream):
+            xs = xs.contiguous().long()
         B, Tmax = xs.shape
         il = torch.as_tensor(ilens).detach().to("cpu", torch.int64).contiguous()   # host lengths (reference: .tolist())
         if il.numel() != B:
@@ -439,21 +449,45 @@ class FeedForwardTransformer(nn.Module):
                 raise ValueError("teacher-forced _forward needs ds, es and ps")
             ds_dev = ds.to(dev).long().contiguous()
         elif d_override is not None:
-            ds_dev = d_override.to(dev).long().contiguous()
+            with torch.cuda.stream(in_stream):
+                ds_dev = d_override.to(dev).long().contiguous()
         if ds_dev is not None and tuple(ds_dev.shape) != (B, Tmax):
             raise ValueError("ds must be [B, Tmax] = [%d, %d], got %s" % (B, Tmax, tuple(ds_dev.shape)))
         with torch.cuda.device(dev):
             st = _stream(dev)
-            tok_ws = torch.empty(L.fs2_token_workspace_bytes(h, C.byref(batch)), dtype=torch.uint8, device=dev)
-            d_log = torch.empty(B, Tmax, dtype=torch.float32, device=dev) if teacher else None
-            d_int = torch.empty(B, Tmax, dtype=torch.int64, device=dev) if is_inference else None
-            olens_dev = torch.empty(B, dtype=torch.int64, device=dev)
-            enc_out = torch.empty(B, Tmax, self._cfg["adim"], device=dev) if "encoder_out" in want else None
-            eio = _lib.EncodeIO(batch, xs.data_ptr(), ds_dev.data_ptr() if ds_dev is not None else None,
-                                d_log.data_ptr() if d_log is not None else None,
-                                d_int.data_ptr() if d_int is not None else None, olens_dev.data_ptr(),
-                                enc_out.data_ptr() if enc_out is not None else None, tok_ws.data_ptr(), tok_ws.numel(), float(alpha))
-            _lib.check(L.fs2_encode(h, st, C.byref(eio)), h)
+            # Throughput mode (``overlap_encoder``, sync-free calls only): the token-level half of the forward -- encoder, duration predictor:
+            # ~30 launches that leave most of the chip idle -- runs on a side stream, so that call i + 1's encoder executes while call i's
+            # frame-level kernels still run on the caller's stream; an event hands the encoder's results to this call's fs2_decode.  The side
+            # stream does NOT wait for the caller's stream: the caller promises that xs (and d_override) are complete (see ``overlap_encoder``).
+            cur = torch.cuda.current_stream(dev)
+            side = None
+            if capacity is not None and self.overlap_encoder and not torch.cuda.is_current_stream_capturing():
+                side = self._enc_streams.get(dev)
+                if side is None:
+                    side = self._enc_streams[dev] = torch.cuda.Stream(device=dev)
+                if self._enc_gen_seen != self._weights_generation:      # the weights were (re-)uploaded on the caller's stream since the side stream last looked
+                    side.wait_stream(cur)
+                    self._enc_gen_seen = self._weights_generation
+            with torch.cuda.stream(side if side is not None else cur):
+                st_e = _stream(dev)
+                tok_ws = torch.empty(L.fs2_token_workspace_bytes(h, C.byref(batch)), dtype=torch.uint8, device=dev)
+                d_log = torch.empty(B, Tmax, dtype=torch.float32, device=dev) if teacher else None
+                d_int = torch.empty(B, Tmax, dtype=torch.int64, device=dev) if is_inference else None
+                olens_dev = torch.empty(B, dtype=torch.int64, device=dev)
+                enc_out = torch.empty(B, Tmax, self._cfg["adim"], device=dev) if "encoder_out" in want else None
+                eio = _lib.EncodeIO(batch, xs.data_ptr(), ds_dev.data_ptr() if ds_dev is not None else None,
+                                    d_log.data_ptr() if d_log is not None else None,
+                                    d_int.data_ptr() if d_int is not None else None, olens_dev.data_ptr(),
+                                    enc_out.data_ptr() if enc_out is not None else None, tok_ws.data_ptr(), tok_ws.numel(), float(alpha))
+                _lib.check(L.fs2_encode(h, st_e, C.byref(eio)), h)
+            if side is not None:
+                cur.wait_stream(side)                      # (this call's fs2_decode and everything behind it on the caller's stream)
+                for t_ in (tok_ws, d_log, d_int, olens_dev, enc_out):      # allocated on the side stream, used on the caller's
+                    if t_ is not None:
+                        t_.record_stream(cur)
+                xs.record_stream(side)                                      # ... and the other way round
+                if ds_dev is not None:
+                    ds_dev.record_stream(side)
             if capacity is not None:
                 total_cap, Lcap = int(capacity[0]), int(capacity[1])
                 self.decoder.embed[-1].ensure(Lcap)      # (a grown table is picked up by the next call's fingerprint check)
@@ -785,6 +819,16 @@ class FeedForwardTransformer(nn.Module):
         for rec in list(self._pending):
             if self._fold(rec, block) is None:
                 break
+
+    def input_stream(self, device):
+        """The stream a sync-free call's inputs should be prepared on: the encoder's side stream in ``overlap_encoder`` mode (so that slicing /
+        gathering the ids of call i + 1 does not queue behind call i's frame-level kernels), else the current stream."""
+        if not self.overlap_encoder or torch.cuda.is_current_stream_capturing():
+            return torch.cuda.current_stream(device)
+        side = self._enc_streams.get(device)
+        if side is None:
+            side = self._enc_streams[device] = torch.cuda.Stream(device=device)
+        return side
 
     def async_ok(self):
         """Waits for every ``inference_batch(sync=False)`` call still in flight; True if the capacities of ALL asynchronous

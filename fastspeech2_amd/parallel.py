@@ -7,6 +7,8 @@ single-GPU path on it, and the only exchange is an all-gather of the final mels 
 "nccl" on ROCm; "gloo" in the CPU tests).  The gather and the order restoration are exact; an utterance's values do not
 depend on its batch-mates (only, in the last bits, on the size-dependent kernel variants: DESIGN.md section 1).
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -329,8 +331,12 @@ class ShardedSynthesizer:
         mine = parts[rank]
         sel = torch.as_tensor(mine, dtype=torch.int64)
         il_loc = il[sel]
-        xs_loc = xs[sel.to(xs.device)][:, : int(il_loc.max())] if len(mine) else xs[:0]
-        kw_loc = {k: (v[sel.to(v.device)][:, : xs_loc.shape[1]] if torch.is_tensor(v) else v) for k, v in kw.items()}
+        # (with model.overlap_encoder the shard's ids are cut out on the encoder's side stream: on the current stream that gather would queue behind
+        #  the previous call's frame-level kernels, and the side stream does not wait for the current one)
+        in_stream = self.model.input_stream(xs.device) if (self.model is not None and xs.is_cuda and self._ratio is not None and not sync) else None
+        with (torch.cuda.stream(in_stream) if in_stream is not None else contextlib.nullcontext()):
+            xs_loc = xs[sel.to(xs.device)][:, : int(il_loc.max())] if len(mine) else xs[:0]
+            kw_loc = {k: (v[sel.to(v.device)][:, : xs_loc.shape[1]] if torch.is_tensor(v) else v) for k, v in kw.items()}
         if self.model is None:
             if len(mine):
                 mel, olens = self.run_local(xs_loc, il_loc, **kw_loc)

@@ -878,6 +878,16 @@ def test_sharded_synthesizer_over_nccl_world_size_1(env):
             assert over.ok()
             for m, o in outs:
                 assert torch.equal(o.cpu(), ol) and torch.equal(m[:, :L], ref)
+            torch.cuda.synchronize()
+            model.overlap_encoder = True                           # ... and each call's encoder on its own side stream as well (bench.py's N > 1 mode)
+            try:
+                outs = [over(xs, il, d_override=ds) for _ in range(4)]
+                over.wait()
+                assert over.ok()
+                for m, o in outs:
+                    assert torch.equal(o.cpu(), ol) and torch.equal(m[:, :L], ref)
+            finally:
+                model.overlap_encoder = False
             synth._ratio = (0.05, 0.05)                            # absurd capacities -> overflow must be visible, not silent
             m3, _ = synth(xs, il, d_override=ds)
             assert not synth.ok()
@@ -922,6 +932,59 @@ def test_async_overflow_is_never_silent(env):
         assert torch.equal(mel[:, : ref.shape[1]], ref) and torch.equal(ol_dev.cpu(), ol)
         empty, eo = model.inference_batch(xs[:0], il[:0])
         assert empty.shape[0] == 0 and eo.numel() == 0
+
+
+def test_overlap_encoder_mode_changes_nothing_but_the_schedule(env):
+    """`model.overlap_encoder` (throughput mode of the sync-free entry points): each call's token-level half runs on a side stream, so that it executes
+    while the previous call's frame-level kernels still run.  Two different batches alternate, eight calls in flight, none waited for: every result
+    is bit-identical to the synchronous call of its batch, frame counts included, and the validity records stay per call."""
+    from fastspeech2_amd.synthetic import make_batch
+    model = env[0]
+    b1, b2 = make_batch("c3", B=24), make_batch("c2", B=12)
+    ins = [(b["xs"].cuda(), b["ilens"], b["ds"].cuda()) for b in (b1, b2)]
+    model.precision = "mix_mx"
+    try:
+        with torch.no_grad():
+            refs = [model.inference_batch(x, il, d_override=d) for x, il, d in ins]
+            free = [model.inference_batch(x, il) for x, il, d in ins]                    # free-running durations: the frame counts are the device's own
+            assert model.async_ok()
+            torch.cuda.synchronize()
+            model.overlap_encoder = True
+            outs = [model.inference_batch(*ins[i & 1][:2], d_override=ins[i & 1][2], sync=False) for i in range(8)]
+            outs_free = [model.inference_batch(*ins[i & 1][:2], sync=False, packed=bool(i & 2)) for i in range(8)]
+            # a shard cut out of a batch by rows AND columns is not contiguous: the copy that makes it so must run on the encoder's stream too
+            sel = torch.argsort(ins[0][1])[:8]
+            m = int(ins[0][1][sel].max())
+            assert m < ins[0][0].shape[1]
+            model.overlap_encoder = False
+            sub_ref = model.inference_batch(ins[0][0][sel.cuda()][:, :m], ins[0][1][sel], d_override=ins[0][2][sel.cuda()][:, :m])
+            torch.cuda.synchronize()
+            model.overlap_encoder = True
+            subs = []
+            for _ in range(4):
+                with torch.cuda.stream(model.input_stream(ins[0][0].device)):
+                    xs_s, ds_s = ins[0][0][sel.cuda()][:, :m], ins[0][2][sel.cuda()][:, :m]
+                subs.append(model.inference_batch(xs_s, ins[0][1][sel], d_override=ds_s, sync=False))
+                outs.append(model.inference_batch(*ins[1][:2], d_override=ins[1][2], sync=False))       # (keeps the caller's stream busy in between)
+                outs.append(model.inference_batch(*ins[0][:2], d_override=ins[0][2], sync=False))
+            assert all(o.ok() for o in outs + outs_free + subs) and model.async_ok()
+            for mel, ol in subs:
+                assert torch.equal(ol.cpu(), sub_ref[1]) and torch.equal(mel[:, : sub_ref[0].shape[1]], sub_ref[0])
+            for i, (mel, ol) in enumerate(outs):
+                ref, rol = refs[i & 1] if i < 8 else refs[1 - (i & 1)]          # (the eight alternating calls, then the b2 / b1 pairs queued between the shard calls)
+                assert torch.equal(ol.cpu(), rol) and torch.equal(mel[:, : ref.shape[1]], ref) and float(mel[:, ref.shape[1]:].abs().sum()) == 0.0
+            for i, (mel, ol) in enumerate(outs_free):
+                ref, rol = free[i & 1]
+                assert torch.equal(ol.cpu(), rol)
+                if i & 2:
+                    st = (torch.cumsum(rol, 0) - rol).tolist()
+                    for j in range(len(rol)):
+                        assert torch.equal(mel[st[j]:st[j] + int(rol[j])], ref[j, : int(rol[j])])
+                else:
+                    assert torch.equal(mel[:, : ref.shape[1]], ref)
+    finally:
+        model.overlap_encoder = False
+        model.precision = "fp32"
 
 
 @pytest.mark.parametrize("alpha", [0.7, 1.5])
