@@ -241,6 +241,9 @@ class FeedForwardTransformer(nn.Module):
         were alone -- what ``inference()`` produces; batch invariant, shardable) or "padded_compat"
         (bit-for-bit the reference's padded-batch behaviour where convolutions and unmasked attention
         see pad rows).  ``forward()`` (the loss path) always uses "padded_compat".
+      * ``overlap_encoder`` (default False): throughput mode of the sync-free entry points -- each call's token-level half (encoder +
+        duration predictor) runs on a side stream and overlaps the previous call's frame-level kernels; results are unchanged; the
+        caller prepares the ids of a call under ``input_stream(device)`` or guarantees they are complete.
     """
 
     def __init__(self, idim: int, odim: int, hp, _script_twin: bool = False):
