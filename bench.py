@@ -300,6 +300,10 @@ def main():
     ap.add_argument("--profile-kernels", action="store_true", help="print the per-kernel hipEvent table to stderr")
     ap.add_argument("--graph", action="store_true", help="replay the forward as one captured HIP graph (single GPU; the launch-bound small configs)")
     ap.add_argument("--no-overlap-encoder", action="store_true", help="keep every launch of a step on one stream (rounds 1-4; the A/B of `overlap_encoder`)")
+    ap.add_argument("--streams", type=int, default=None, help="streams the steps are issued on in turn (default: 3 per GPU -- that many whole "
+                    "steps in flight, the dispatcher fills one step's tail rounds and HBM bursts with another's workgroups; 1 = the schedule of rounds 1-4, "
+                    "and the only one with --graph / --profile-kernels)")
+    ap.add_argument("--overlap-encoder", action="store_true", help="model.overlap_encoder also with --streams > 1 (default: only with one stream)")
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds the step keeps running after the timed region for `sustained_ms_per_step` (0: off)")
     ap.add_argument("--padded", action="store_true", help="N > 1: every rank also unpacks the gathered mels into the padded [B, Lcap, odim] tensor "
                                                            "(default: the packed form, gathered packs + offsets, no unpack launch)")
@@ -331,7 +335,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     workload = args.workload or ("c5" if use_dist else "c3")
 
-    from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
+    from fastspeech2_amd import FeedForwardTransformer, StepStreams, default_hparams, N_PHONEME_SYMBOLS
     from fastspeech2_amd.parallel import ShardedSynthesizer, shard_indices, path_flops
     from fastspeech2_amd.synthetic import portable_state_dict, ljspeech_durations, make_batch
 
@@ -344,7 +348,13 @@ def main():
     model.precision = args.precision
     # throughput mode: every step's token-level half (encoder + duration predictor, ~30 launches that leave most of the chip idle) runs on a side
     # stream and overlaps the previous step's frame-level kernels; the batch is resident and complete, which is what the mode asks of its caller
-    model.overlap_encoder = not (args.no_overlap_encoder or args.profile_kernels or args.graph)
+    # (with several steps in flight -- see --streams below -- the other steps' kernels fill the same holes and the extra streams only compete for
+    #  the hardware queues: profiles/r05_ab_stream_schedules.txt)
+    eager = not (args.profile_kernels or args.graph)
+    n_streams = args.streams if args.streams else (3 if eager else 1)
+    if n_streams > 1 and not eager:
+        raise SystemExit("--streams > 1 serves the eager path")
+    model.overlap_encoder = eager and not args.no_overlap_encoder and (n_streams == 1 or args.overlap_encoder)
 
     # ONE global batch, identical on every rank (numpy RandomState, seed = config number).  c5 is cut to 128 utterances per
     # GPU when fewer than 8 GPUs run it, so the work per GPU does not depend on N (weak scaling); 8 GPUs run all 1024.
@@ -360,8 +370,30 @@ def main():
     synth = ShardedSynthesizer(model, overlap=os.environ.get("FS2_DIST_SERIAL") != "1") if use_dist else None
 
     graph_run = None
+    # throughput mode: consecutive steps go to `n_streams` streams in turn, so that many whole steps are in flight and every kernel's tail round,
+    # HBM burst and launch gap is filled by another step's workgroups (profiles/r05_ab_stream_schedules.txt).  Nothing in the library knows
+    # about it: a call runs on the caller's current stream.  Every step still does all its work; the timed region still covers exactly K steps
+    # between two full-device synchronisations.  (N > 1: the all-gathers stay on the synthesizer's one side stream, in program order on every rank.)
+    step_streams = StepStreams(n_streams, device=dev) if n_streams > 1 else None
+    step_no = [0]
+    one_stream = [False]        # (the A/B region behind the timed one)
 
-    def step():
+    def step(done=None):
+        """one pass of the hot path over the batch; `done` (an event) is recorded behind it on the stream it was issued on"""
+        if step_streams is not None and step_no[0] > 0 and not one_stream[0]:
+            step_no[0] += 1
+            with step_streams.next():
+                r = step_here()
+                if done is not None:
+                    done.record()
+            return r
+        step_no[0] += 1
+        r = step_here()
+        if done is not None:
+            done.record()
+        return r
+
+    def step_here():
         if graph_run is not None:
             mel_, ol_, _ = graph_run(xs)
             return mel_, ol_
@@ -419,8 +451,7 @@ def main():
         t0 = time.perf_counter()
         ev[0].record()
         for i in range(args.steps):
-            mel, olens_all = step()
-            ev[i + 1].record()
+            mel, olens_all = step(ev[i + 1])
         if synth is not None:
             synth.wait()
         torch.cuda.synchronize()
@@ -428,7 +459,8 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         assert all_ok(), "capacities of the asynchronous path were exceeded in the timed region"
-        step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+        # spacing of the steps' completions (with S streams: over windows of S steps, the steps of one stream)
+        step_ms = [ev[i + 1 - n_streams].elapsed_time(ev[i + 1]) / n_streams for i in range(n_streams - 1, args.steps)]
         prof = model.get_profile() if graph_run is None else scout_prof      # (graph mode: the roofline comes from the eager scouting step)
         model.set_profiling(False)
         # ---- steady state: the timed region above is K steps (0.1 s at c3) after ~0.05 s of warm-up, and sustained MFMA load
@@ -463,6 +495,38 @@ def main():
             sustained = dict(steps=n_sus, seconds=round(dts, 3), ms_per_step=round(1e3 * dts / n_sus, 3),
                              sclk_mhz=(dict(min=min(clk), median=statistics.median(clk), max=max(clk), samples=len(clk),
                                             source="amdgpu sysfs pp_dpm_sclk, sampled by the host while the queue is full") if clk else None))
+        # ---- the same steps on ONE stream (not part of `value`): the A/B of the schedule, and the dominant kernel alone on the chip -- in the
+        # timed region above its launches share the CUs with the other step's kernels, so their bracketed duration there is not the kernel's own
+        alone = None
+        if step_streams is not None:
+            n_al = max(4, min(args.steps, 10))
+            one_stream[0] = True
+            for _ in range(2):
+                step()
+            if synth is not None:
+                synth.wait()
+            torch.cuda.synchronize()
+            model.set_profiling(True, only=dom_site)
+            if use_dist:
+                dist.barrier()
+            ta = time.perf_counter()
+            for _ in range(n_al):
+                mel, olens_all = step()
+            if synth is not None:
+                synth.wait()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            dta = time.perf_counter() - ta
+            if use_dist:
+                t = torch.tensor([dta], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dta = float(t.item())
+            pa = [ms for name, ms, fl, by in model.get_profile() if name == dom_site]
+            model.set_profiling(False)
+            one_stream[0] = False
+            assert all_ok(), "capacities of the asynchronous path were exceeded in the one-stream region"
+            alone = dict(steps=n_al, ms_per_step=round(1e3 * dta / n_al, 3), avg_launch_ms=sum(pa) / max(len(pa), 1))
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -505,6 +569,13 @@ def main():
                     launches_per_step=dom_n // max(args.steps, 1),
                     # this site's launches (events around it alone, inside the timed region) as a share of the step's wall time: cannot exceed 1
                     share_of_step_time=round(dom_ms / (1e3 * dt), 3))
+    if alone is not None and alone["avg_launch_ms"] > 0:
+        # `achieved` / `frac` above are what the contract asks for -- this site's launches inside the timed region, where (two steps in flight) they
+        # share the chip with the other step's kernels.  The same launches with one step in flight (a short region behind the timed one):
+        a1 = algo / (alone["avg_launch_ms"] * 1e-3) / 1e12
+        roofline["one_step_in_flight"] = dict(avg_launch_ms=round(alone["avg_launch_ms"], 4), achieved=round(a1, 2), frac=round(a1 / peak, 4),
+                                              note="the same launch site bracketed while the steps run on ONE stream (the kernel alone on the chip); "
+                                                   "`frac` is measured with %d steps in flight" % n_streams)
     if args.precision != "fp32":
         # what the chip sustains on random bf16 operands with nothing but MFMAs in flight (tools/probes/mfma_shape_probe.hip,
         # profiles/r02_mfma_shape_power_probe.txt: 1.8-2.1 PFLOP/s at 1.8-2.1 GHz, power-limited); `peak` stays the nominal figure
@@ -616,7 +687,7 @@ def main():
                        "parallelism": ("LPT utterance-sharded x%d (unequal shards), one all-gather(packed mels + frame counts) over RCCL%s"
                                        % (world, ", overlapped with the next step's forward (side stream)" if synth.overlap else ""))
                                       if use_dist else "single GPU",
-                       "launch": launch, "overlap_encoder": bool(model.overlap_encoder)},
+                       "launch": launch, "overlap_encoder": bool(model.overlap_encoder), "streams": n_streams},
             "roofline": roofline,
             "roofline_worst": roofline_worst,
             "roofline_hbm": roofline_hbm,
@@ -625,6 +696,10 @@ def main():
             line["sustained_ms_per_step"] = sustained["ms_per_step"]
             line["sustained"] = dict(sustained, ratio_to_timed=round(sustained["ms_per_step"] / (1e3 * dt / args.steps), 4),
                                      value=round(total_frames * 1e3 / sustained["ms_per_step"], 1))
+        if alone is not None:
+            line["one_stream"] = dict(steps=alone["steps"], ms_per_step=alone["ms_per_step"], value=round(total_frames * 1e3 / alone["ms_per_step"], 1),
+                                      note="the same steps issued on one stream (rounds 1-4's schedule%s), measured behind the timed region"
+                                           % (" + overlap_encoder" if model.overlap_encoder else ""))
         if use_dist:
             line["config"]["gather"] = "padded" if (args.padded or args.profile_kernels) else "packed"
             line["config"]["collective_world_size"] = dist.get_world_size()

@@ -4,5 +4,5 @@
 (reference fastspeech.py:28); its arithmetic runs in ``libfs2_hip.so`` (C ABI: include/fs2.h).
 """
 from .hparams import default_hparams, load_hparams, N_PHONEME_SYMBOLS  # noqa: F401
-from .fastspeech import FeedForwardTransformer  # noqa: F401
+from .fastspeech import FeedForwardTransformer, StepStreams  # noqa: F401
 from .io import load_checkpoint, vocoder_input, hparams_from_str  # noqa: F401

@@ -21,7 +21,7 @@ from torch import nn
 
 from . import _lib
 
-__all__ = ["FeedForwardTransformer", "AsyncMels", "Fs2CapacityError"]
+__all__ = ["FeedForwardTransformer", "AsyncMels", "Fs2CapacityError", "StepStreams"]
 
 
 class Fs2CapacityError(RuntimeError):
@@ -88,6 +88,36 @@ class _AsyncRecord:
 # ----------------------------------------------------------------------------------------------
 # parameter containers (names fixed by the reference's state-dict layout)
 # ----------------------------------------------------------------------------------------------
+class StepStreams:
+    """Throughput mode for a caller with independent batches queued: ``n`` streams handed out in turn, so that ``n`` whole forwards are in flight and
+    the tail round, HBM burst and launch gap of one forward's kernels are filled by another's workgroups (c3: 7.28 -> 8.84 M mel frames/s with
+    n = 3, profiles/r05_ab_stream_schedules.txt; more streams than the runtime has hardware queues -- 4 by default, the null stream included -- lose
+    again).  Nothing in the library knows about it -- a sync-free call runs on its caller's current stream::
+
+        rot = StepStreams(3)
+        for xs, ilens in batches:
+            with rot.next():
+                results.append(model.inference_batch(xs, ilens, sync=False))
+        rot.join()                    # the current stream waits for all of them; then model.async_ok()
+
+    ``next()`` makes the stream it hands out wait for what the current stream has queued so far (the batch's inputs); results belong to the stream
+    they were computed on until ``join()`` (keep them alive, or ``record_stream`` them, while another stream reads them)."""
+
+    def __init__(self, n=3, device=None):
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(int(n), 1))]
+        self._i = 0
+
+    def next(self):
+        s = self.streams[self._i % len(self.streams)]
+        self._i += 1
+        s.wait_stream(torch.cuda.current_stream(s.device))
+        return torch.cuda.stream(s)
+
+    def join(self):
+        for s in self.streams:
+            torch.cuda.current_stream(s.device).wait_stream(s)
+
+
 def sinusoid_table(n, d):
     """pe[t,2i]=sin(t*exp(-2i*ln(1e4)/d)), pe[t,2i+1]=cos(.)  (reference core/embedding.py:57-66).
     Built on the host once (trig tables belong on the host, not in the streaming kernel)."""
@@ -257,8 +287,8 @@ class FeedForwardTransformer(nn.Module):
         # stream so that it overlaps the previous call's frame-level kernels.  The caller then guarantees that the input ids (and d_override) of a call
         # are COMPLETE when the call is made -- not the product of work still queued on the current stream.  Off by default; results are unchanged.
         self.overlap_encoder = False
-        self._enc_streams = {}
-        self._enc_gen_seen = -1
+        self._enc_streams = {}          # (device, caller's stream) -> the side stream of the calls made on that stream
+        self._enc_gen_seen = {}
         self.use_scaled_pos_enc = bool(m.use_scaled_pos_enc)
         self.use_masking = bool(m.use_masking)
         self.use_weighted_masking = bool(m.use_weighted_masking)
@@ -465,12 +495,10 @@ class FeedForwardTransformer(nn.Module):
             cur = torch.cuda.current_stream(dev)
             side = None
             if capacity is not None and self.overlap_encoder and not torch.cuda.is_current_stream_capturing():
-                side = self._enc_streams.get(dev)
-                if side is None:
-                    side = self._enc_streams[dev] = torch.cuda.Stream(device=dev)
-                if self._enc_gen_seen != self._weights_generation:      # the weights were (re-)uploaded on the caller's stream since the side stream last looked
-                    side.wait_stream(cur)
-                    self._enc_gen_seen = self._weights_generation
+                side = self.input_stream(dev)
+                if self._enc_gen_seen.get(side.cuda_stream) != self._weights_generation:      # the weights were (re-)uploaded on some stream since this side stream last looked
+                    torch.cuda.synchronize(dev)
+                    self._enc_gen_seen[side.cuda_stream] = self._weights_generation
             with torch.cuda.stream(side if side is not None else cur):
                 st_e = _stream(dev)
                 tok_ws = torch.empty(L.fs2_token_workspace_bytes(h, C.byref(batch)), dtype=torch.uint8, device=dev)
@@ -826,11 +854,13 @@ class FeedForwardTransformer(nn.Module):
     def input_stream(self, device):
         """The stream a sync-free call's inputs should be prepared on: the encoder's side stream in ``overlap_encoder`` mode (so that slicing /
         gathering the ids of call i + 1 does not queue behind call i's frame-level kernels), else the current stream."""
+        cur = torch.cuda.current_stream(device)
         if not self.overlap_encoder or torch.cuda.is_current_stream_capturing():
-            return torch.cuda.current_stream(device)
-        side = self._enc_streams.get(device)
+            return cur
+        key = (device, cur.cuda_stream)          # one side stream per stream the caller works on: steps issued on alternating streams overlap their encoders too
+        side = self._enc_streams.get(key)
         if side is None:
-            side = self._enc_streams[device] = torch.cuda.Stream(device=device)
+            side = self._enc_streams[key] = torch.cuda.Stream(device=device)
         return side
 
     def async_ok(self):

@@ -994,6 +994,47 @@ def test_overlap_encoder_mode_changes_nothing_but_the_schedule(env):
         model.precision = "fp32"
 
 
+@pytest.mark.parametrize("overlap_encoder", [False, True])
+def test_two_steps_in_flight_on_two_streams_change_nothing_but_the_schedule(env, overlap_encoder):
+    """bench.py's one-GPU schedule: consecutive sync-free calls are issued on alternating streams, so two whole forwards are in flight on the chip
+    (with `overlap_encoder` each stream has its own side stream for the token-level half).  Two different batches, twelve calls on two streams (so
+    both batches run on both streams and against each other), padded and packed results: bit-identical to the synchronous calls, frame counts and
+    validity records included."""
+    from fastspeech2_amd.synthetic import make_batch
+    model = env[0]
+    b1, b2 = make_batch("c3", B=24), make_batch("c2", B=12)
+    ins = [(b["xs"].cuda(), b["ilens"]) for b in (b1, b2)]
+    model.precision = "mix_mx"
+    try:
+        with torch.no_grad():
+            refs = [model.inference_batch(x, il) for x, il in ins]
+            caps = [(int(r[1].sum()) + 64 * len(r[1]), int(r[1].max()) + 32) for r in refs]
+            torch.cuda.synchronize()
+            model.overlap_encoder = overlap_encoder
+            from fastspeech2_amd import StepStreams
+            rot = StepStreams(2)
+            order = [0, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 1]         # batch of call i; call i runs on stream i & 1
+            outs = []
+            for i, k in enumerate(order):
+                with rot.next():
+                    outs.append(model.inference_batch(*ins[k], sync=False, packed=(i % 3 == 2), capacity=caps[k]))
+            rot.join()                                           # (no host synchronisation: the comparisons below run on the current stream)
+            assert all(o.ok() for o in outs) and model.async_ok()
+            for i, k in enumerate(order):
+                mel, ol = outs[i]
+                ref, rol = refs[k]
+                assert torch.equal(ol.cpu(), rol)
+                if i % 3 == 2:
+                    st = (torch.cumsum(rol, 0) - rol).tolist()
+                    for j in range(len(rol)):
+                        assert torch.equal(mel[st[j]:st[j] + int(rol[j])], ref[j, : int(rol[j])])
+                else:
+                    assert torch.equal(mel[:, : ref.shape[1]], ref) and float(mel[:, ref.shape[1]:].abs().sum()) == 0.0
+    finally:
+        model.overlap_encoder = False
+        model.precision = "fp32"
+
+
 @pytest.mark.parametrize("alpha", [0.7, 1.5])
 def test_duration_alpha_speed_control(env, alpha):
     """Length-regulator speed control (reference length_regulator.py:57-59) through the batched entry point: the mels equal

@@ -19,6 +19,10 @@ bench)
   for spec in "c3 bf16x3" "c3 fp32" "c2 mix_mx" "c2 fp32" "c1 mix_mx" "c4 mix_mx" "c4 bf16x3" "c5 mix_mx"; do set -- $spec
     python bench.py --workload $1 --precision $2 --no-cpu-baseline > $D/bench_r05_$1_$2.json 2>/dev/null
   done
+  for wl in c3 c2 c4 c5; do      # the schedule's A/B: one stream (+ overlap_encoder), and c3 with every launch of a step on one stream (rounds 1-4)
+    python bench.py --workload $wl --no-cpu-baseline --streams 1 > $D/bench_r05_${wl}_mix_mx_one_stream.json 2>/dev/null
+  done
+  python bench.py --no-cpu-baseline --streams 1 --no-overlap-encoder > $D/bench_r05_c3_mix_mx_one_stream_no_overlap.json 2>/dev/null
   python bench.py --workload c1 --no-cpu-baseline --graph > $D/bench_r05_c1_mix_mx_graph.json 2>/dev/null
   FS2_FORCE_DIST=1 python bench.py --workload c5 --no-cpu-baseline > $D/bench_r05_c5_rccl_single_rank.json 2>/dev/null
   FS2_ROW4=0 FS2_FFN2_MX=0 python bench.py --no-cpu-baseline > $D/bench_r05_c3_mix_mx_row8.json 2>/dev/null
