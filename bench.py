@@ -535,6 +535,9 @@ def main():
     if use_dist and synth is not None and graph_run is None:
         with torch.no_grad():
             multi_gpu = dist_diagnostics(model, synth, xs, il, parts, rank, world, dev, max(2, min(args.steps, 5)), 1e3 * dt / args.steps)
+            if multi_gpu is not None and n_streams > 1:
+                multi_gpu["schedule_note"] = ("the diagnostic legs (forward alone, serial collective) run one step at a time on one stream; the timed steps are issued on "
+                                              "%d streams per rank, so `collective_ms_exposed_overlapped` (timed step - busiest rank's forward alone) can be negative" % n_streams)
 
     # ---- per-kernel table (hipEvents on the launch stream, accumulated over the timed steps) ----
     agg = {}
@@ -562,6 +565,14 @@ def main():
     else:   # fall back to the launch's own count (includes the ~1.5 % gap rows)
         algo = sum(fl for n_, ms, fl, by in prof if n_ == dom_name) / dom_n
     avg_ms = dom_ms / dom_n
+    bracket_in_flight = None
+    if alone is not None and alone["avg_launch_ms"] > 0:
+        # With several steps in flight a hipEvent bracket is not the kernel's duration: the second event waits for the kernel, the kernel waits in its
+        # hardware queue for CUs that other streams' kernels hold (c3, 3 streams: bracket 0.57 ms, rocprofv3 dispatch timestamps of the same region
+        # 0.46 ms, the kernel alone 0.42 ms: profiles/r05_kernel_trace_by_region.txt).  The roofline of the kernel is therefore taken where the
+        # bracket IS the duration: the same launch site in the one-stream region behind the timed one (it agrees with rocprofv3 to 1 %).
+        bracket_in_flight = avg_ms
+        avg_ms = alone["avg_launch_ms"]
     achieved = algo / (avg_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.precision]
     roofline = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
@@ -569,13 +580,14 @@ def main():
                     launches_per_step=dom_n // max(args.steps, 1),
                     # this site's launches (events around it alone, inside the timed region) as a share of the step's wall time: cannot exceed 1
                     share_of_step_time=round(dom_ms / (1e3 * dt), 3))
-    if alone is not None and alone["avg_launch_ms"] > 0:
-        # `achieved` / `frac` above are what the contract asks for -- this site's launches inside the timed region, where (two steps in flight) they
-        # share the chip with the other step's kernels.  The same launches with one step in flight (a short region behind the timed one):
-        a1 = algo / (alone["avg_launch_ms"] * 1e-3) / 1e12
-        roofline["one_step_in_flight"] = dict(avg_launch_ms=round(alone["avg_launch_ms"], 4), achieved=round(a1, 2), frac=round(a1 / peak, 4),
-                                              note="the same launch site bracketed while the steps run on ONE stream (the kernel alone on the chip); "
-                                                   "`frac` is measured with %d steps in flight" % n_streams)
+    if bracket_in_flight is not None:
+        lps = dom_n // max(args.steps, 1)
+        roofline["share_of_step_time"] = round(lps * avg_ms / (1e3 * dt / args.steps), 3)      # (kernel time / step interval: steps overlap)
+        roofline["measured_in"] = ("the one-stream region behind the timed one (%d steps, hipEvents around this site on the launch stream): with %d steps "
+                                   "in flight an event bracket also holds the launch's wait in its hardware queue" % (alone["steps"], n_streams))
+        roofline["timed_region_bracket"] = dict(steps_in_flight=n_streams, avg_bracket_ms=round(bracket_in_flight, 4),
+                                                frac_if_read_as_duration=round(algo / (bracket_in_flight * 1e-3) / 1e12 / peak, 4),
+                                                note="rocprofv3 dispatch timestamps of this region: profiles/r05_kernel_trace_by_region.txt")
     if args.precision != "fp32":
         # what the chip sustains on random bf16 operands with nothing but MFMAs in flight (tools/probes/mfma_shape_probe.hip,
         # profiles/r02_mfma_shape_power_probe.txt: 1.8-2.1 PFLOP/s at 1.8-2.1 GHz, power-limited); `peak` stays the nominal figure
