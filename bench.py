@@ -706,6 +706,8 @@ def main():
         }
         if sustained is not None:
             line["sustained_ms_per_step"] = sustained["ms_per_step"]
+            if sustained.get("sclk_mhz"):
+                line["sclk_mhz_median"] = sustained["sclk_mhz"]["median"]      # (boxes of one pool differ: 1.4 .. 2.4 GHz under this load)
             line["sustained"] = dict(sustained, ratio_to_timed=round(sustained["ms_per_step"] / (1e3 * dt / args.steps), 4),
                                      value=round(total_frames * 1e3 / sustained["ms_per_step"], 1))
         if alone is not None:
