@@ -3,8 +3,9 @@ accumulators in a[0 : 4 MT NT)).  hipcc does not know that these registers are l
 lists only say "destroyed" -- and pads no hazards around inline asm (cdna guide section 5.7), so a different compiler version could place a
 temporary or an AGPR spill there, or drop a pad, and corrupt results silently.  `_lib.build()` therefore compiles with -save-temps, runs this
 audit on the device assembly of the very library it ships and records the outcome next to the .so (libfs2_hip.audit.json, tied to the
-binary's hash); `_lib.lib()` switches both kernels off (FS2_ATTN_W32 = 0, FS2_ROW4 = 0: the compiler-scheduled kernels run instead) when the
-record is missing, stale or not clean.  Round-4 advisor finding (medium).
+binary's hash); the LIBRARY itself looks for that record of its own hash when it is first used (fs2_runtime.hip: audit_clean) and starts with
+both kernels off (FS2_ATTN_W32 = 0, FS2_ROW4 = 0: the compiler-scheduled kernels run instead) when the record is missing, stale or not clean --
+for every consumer of the C ABI, not only the ctypes binding.  Round-4 / round-5 advisor findings.
 
 Checks per attn_w32<DK> kernel (tools/probes/audit_w32.py, rounds 4-5):
   1. no compiler-generated v_accvgpr_* touches a0 .. a(16 NT - 1) outside ASMSTART / ASMEND;
@@ -19,6 +20,11 @@ Checks per gemm_row4_bf16<.., NB, MT, ..> kernel:
 Both: 6. the SGPR base of an asm LDS-DMA instruction was not written by a VALU instruction (v_readfirstlane) within the 5 preceding issue states.
 """
 import re
+
+# What a clean record must hold (round-5 advisor finding: "clean" used to require one attn_w32 record only, so a symbol regex that stopped
+# matching would have let the row kernels through unaudited): the library instantiates attn_w32 for two head dims and gemm_row4_bf16 for
+# {MT 4, 5} x {EPI 0, 1, 2, 3 in split-bf16} + {MT 4, 5} x {EPI 0 in the mx arithmetic}.  fs2_runtime.hip: launch_attn_w32_t / launch_row4_t / launch_qkv4_t.
+EXPECTED_KERNELS = {"attn_w32": 2, "gemm_row4_bf16": 10}
 
 _REG = re.compile(r'([va])\[(\d+):(\d+)\]|([va])(\d+)$')
 

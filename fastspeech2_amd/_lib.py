@@ -48,8 +48,10 @@ class TensorDesc(C.Structure):
 
 
 class Batch(C.Structure):
+    """fs2_batch.  ``regime_tokens`` / ``regime_utterances`` (0 / 0 = this batch's own): the batch the kernel variants are chosen for --
+    a shard of a larger batch names the whole batch and is then computed bit-identically to the one-call run of the whole batch."""
     _fields_ = [("B", C.c_int32), ("Tmax", C.c_int32), ("ilens", C.POINTER(C.c_int64)),
-                ("compat_padded", C.c_int32), ("precision", C.c_int32)]
+                ("compat_padded", C.c_int32), ("precision", C.c_int32), ("regime_tokens", C.c_int64), ("regime_utterances", C.c_int32)]
 
 
 class EncodeIO(_Sized):
@@ -76,11 +78,11 @@ class OpGemmArgs(_Sized):
 
 
 # every symbol include/fs2.h declares (tests check the library exports all of them)
-ABI_VERSION = 3      # FS2_ABI_VERSION of the include/fs2.h these mirrors were written against (checked in lib())
+ABI_VERSION = 4      # FS2_ABI_VERSION of the include/fs2.h these mirrors were written against (checked in lib())
 
 EXPORTS = ["fs2_abi_version", "fs2_create", "fs2_destroy", "fs2_last_error", "fs2_load_weights", "fs2_token_workspace_bytes",
            "fs2_encode", "fs2_frame_workspace_bytes", "fs2_row_capacity", "fs2_frame_workspace_bytes_cap", "fs2_decode", "fs2_set_profiling", "fs2_set_profile_filter", "fs2_get_profile",
-           "fs2_op_conv_gemm", "fs2_op_attention", "fs2_op_length_regulate", "fs2_op_unpack_rows", "fs2_op_unpack_rows_dev", "fs2_op_transpose", "fs2_op_bucketize", "fs2_op_duration", "fs2_set_option"]
+           "fs2_op_conv_gemm", "fs2_op_attention", "fs2_op_length_regulate", "fs2_op_unpack_rows", "fs2_op_unpack_rows_dev", "fs2_op_transpose", "fs2_op_bucketize", "fs2_op_duration", "fs2_set_option", "fs2_get_option", "fs2_get_counter"]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
 
@@ -124,7 +126,8 @@ def build(force=False, verbose=False):
     bad = {k: v["violations"] for k, v in kernels.items() if v["violations"]}
     rec = dict(so_sha16=_sha16(LIB_PATH), hipcc=subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().split("\n")[0],
                kernels={k: {a: b for a, b in v.items() if a != "violations"} for k, v in kernels.items()},
-               violations=sum(len(v) for v in bad.values()), clean=not bad and any(v["kind"] == "attn_w32" for v in kernels.values()))
+               violations=sum(len(v) for v in bad.values()),
+               clean=not bad and all(sum(1 for v in kernels.values() if v["kind"] == k) >= n for k, n in _audit.EXPECTED_KERNELS.items()))
     with open(AUDIT_PATH, "w") as f:
         json.dump(rec, f, indent=1)
     if bad:
@@ -242,17 +245,36 @@ def lib():
     L.fs2_op_duration.restype = C.c_int
     L.fs2_set_option.argtypes = [C.c_char_p, i32]
     L.fs2_set_option.restype = C.c_int
-    # the kernels with literal-register accumulators run only in a library whose ISA was audited (build()): otherwise the compiler-scheduled
-    # kernels take their place (attn_bf16, gemm_row8_bf16) -- slower, never silently wrong
-    rec = audit_record()
-    if rec is None or not rec.get("clean"):
+    L.fs2_get_option.argtypes = [C.c_char_p, C.POINTER(i32)]
+    L.fs2_get_option.restype = C.c_int
+    L.fs2_get_counter.argtypes = [vp, vp, C.c_char_p, C.POINTER(C.c_int64), i32]
+    L.fs2_get_counter.restype = C.c_int
+    # The kernels with literal-register accumulators run only in a library whose ISA was audited (build()): the LIBRARY looks for the record of
+    # its own hash when it is first used (fs2_runtime.hip: audit_clean) and otherwise starts with attn_w32 / gemm_row4_bf16 switched off -- for
+    # every consumer, not only this binding; the compiler-scheduled kernels take their place (slower, never silently wrong).  Here: say so.
+    v = i32(0)
+    L.fs2_get_option(b"FS2_AUDIT_CLEAN", C.byref(v))
+    if not v.value:
         import warnings
+        rec = audit_record()
         warnings.warn("%s has no clean ISA audit record (%s): attn_w32 and gemm_row4_bf16 are switched off; rebuild with "
                       "`python -c 'import __graft_entry__ as g; g.build()'`" % (LIB_PATH, "missing or stale" if rec is None else "violations"))
-        L.fs2_set_option(b"FS2_ATTN_W32", 0)
-        L.fs2_set_option(b"FS2_ROW4", 0)
     _lib = L
     return L
+
+
+def get_option(name):
+    """Value of a kernel-choice switch, or of a read-only fact about this binary: "FS2_AUDIT_CLEAN", "attn_w32_active", "row4_active",
+    "qkv4_active" (include/fs2.h: fs2_get_option)."""
+    v = C.c_int32(0)
+    check(lib().fs2_get_option(name.encode(), C.byref(v)))
+    return int(v.value)
+
+
+def kernel_state():
+    """What a benchmark line should say about the binary that produced it: the audit state and which hand-scheduled kernels may run."""
+    return {k: bool(get_option(n)) for k, n in (("audit_clean", "FS2_AUDIT_CLEAN"), ("attn_w32_active", "attn_w32_active"),
+                                                ("row4_active", "row4_active"), ("qkv4_active", "qkv4_active"))}
 
 
 def set_option(name, value):

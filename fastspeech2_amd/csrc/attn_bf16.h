@@ -91,6 +91,7 @@ struct AttnB16Args {
     int nitems;                                // host-driven layout: number of work items
     int D; int mask_q;
     unsigned qk_lo_bytes, vt_lo_bytes;         // attn_w32.h: byte distance of the lo planes behind the hi planes (both < 2^31)
+    int *slow_count, *slow_count2;             // attn_w32.h: device counters of the waves that left the fast path (the handle's cumulative one, the call's status word), or nullptr
 };
 
 // max / sum over the four lanes {l, l^16, l^32, l^48} (the four 8-key groups of one query column) with the gfx950 row swaps:

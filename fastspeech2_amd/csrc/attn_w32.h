@@ -159,6 +159,10 @@ template <int DK>
 __device__ __noinline__ void attn_w32_rows_slow(const AttnB16Args a, int s0, int len, int klen, int q0, int h, int lane) {      // (a by value: a reference would move the kernel's own copy of the arguments into scratch memory)
     const int l31 = lane & 31, hi = lane >> 5;
     const int qrow = q0 + l31;
+    if (lane == 0) {      // one count per wave (fs2_get_counter "attn_slow_path_waves"; fs2_decode_io.status[5])
+        if (a.slow_count) atomicAdd(a.slow_count, 1);
+        if (a.slow_count2) atomicAdd(a.slow_count2, 1);
+    }
     if (qrow >= len) return;
     const __bf16* qh = a.qk_hi + (size_t)(s0 + qrow) * a.ldqk + (size_t)h * DK;
     const __bf16* ql = a.qk_lo + (size_t)(s0 + qrow) * a.ldqk + (size_t)h * DK;

@@ -4,12 +4,15 @@
 // time, workspace carving (no allocation inside a forward), host- or device-driven frame layout, per-launch hipEvent profiling.
 // Replaces the tensor work of reference fastspeech.py:169-243 (`FeedForwardTransformer._forward`).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
+#include <iterator>
 #include <map>
 #include <string>
 #include <type_traits>
@@ -103,12 +106,101 @@ int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
+
+// ---- the ISA-audit gate (round-5 advisor finding: the gate used to live in the ctypes binding only).  attn_w32 and gemm_row4_bf16 keep their
+// accumulators in literal registers the compiler does not know to be live; fastspeech2_amd/_lib.py::build() audits the device
+// assembly of the binary it ships and records the outcome in libfs2_hip.audit.json next to it, tied to the file's SHA-256.  The library looks for
+// that record of ITSELF when it is first used: without a clean one the three switches below start at 0 for every consumer (ctypes, the TorchScript
+// op, a C program linked against the ABI) and only an explicit fs2_set_option turns them on (probes).
+struct Sha256 {
+    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    unsigned char buf[64]; size_t fill = 0; uint64_t total = 0;
+    static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+    void block(const unsigned char* p) {
+        static const uint32_t K[64] = {
+            0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u,
+            0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau,
+            0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u,
+            0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
+            0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u,
+            0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+        uint32_t w[64];
+        for (int i = 0; i < 16; ++i) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+        for (int i = 16; i < 64; ++i) {
+            const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; ++i) {
+            const uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+            const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    void update(const unsigned char* p, size_t n) {
+        total += n;
+        while (n) {
+            const size_t k = std::min(n, 64 - fill);
+            memcpy(buf + fill, p, k); fill += k; p += k; n -= k;
+            if (fill == 64) { block(buf); fill = 0; }
+        }
+    }
+    std::string hex16() {      // first 16 hex digits of the digest (what _lib.py records as so_sha16)
+        const uint64_t bits = total * 8;
+        unsigned char pad[72] = {0x80};
+        const size_t padn = (fill < 56 ? 56 - fill : 120 - fill);
+        unsigned char len[8];
+        for (int i = 0; i < 8; ++i) len[i] = (unsigned char)(bits >> (56 - 8 * i));
+        update(pad, padn); update(len, 8);
+        char out[17];
+        snprintf(out, sizeof out, "%08x%08x", h[0], h[1]);
+        return out;
+    }
+};
+bool audit_clean_of_this_binary() {
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<const void*>(&fs2_abi_version), &info) || !info.dli_fname) return false;
+    const std::string so = info.dli_fname;
+    const size_t slash = so.rfind('/');
+    const std::string rec_path = (slash == std::string::npos ? std::string() : so.substr(0, slash + 1)) + "libfs2_hip.audit.json";
+    std::ifstream rf(rec_path);
+    if (!rf) return false;
+    const std::string rec((std::istreambuf_iterator<char>(rf)), std::istreambuf_iterator<char>());
+    const size_t k = rec.find("\"so_sha16\"");
+    if (k == std::string::npos) return false;
+    const size_t q0 = rec.find('"', rec.find(':', k) + 1), q1 = q0 == std::string::npos ? q0 : rec.find('"', q0 + 1);
+    if (q1 == std::string::npos) return false;
+    const std::string want = rec.substr(q0 + 1, q1 - q0 - 1);
+    const size_t c = rec.find("\"clean\"");
+    const size_t v = c == std::string::npos ? c : rec.find_first_not_of(" :", c + 7);
+    if (v == std::string::npos || rec.compare(v, 4, "true") != 0) return false;
+    std::ifstream sf(so, std::ios::binary);
+    if (!sf) return false;
+    Sha256 sh;
+    std::vector<unsigned char> blk(1 << 20);
+    while (sf) {
+        sf.read(reinterpret_cast<char*>(blk.data()), (std::streamsize)blk.size());
+        if (sf.gcount() > 0) sh.update(blk.data(), (size_t)sf.gcount());
+    }
+    return sh.hex16() == want;
+}
+bool audit_clean() {
+    static const bool ok = audit_clean_of_this_binary();
+    return ok;
+}
+
 Options& opts() {
     static Options o = [] {
         Options x;
         x.bm = env_int("FS2_BM", -1); x.row8 = env_int("FS2_ROW8", -1); x.qkv8 = env_int("FS2_QKV8", -1);
         x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.qkv_split = env_int("FS2_QKV_SPLIT", -1); x.op_att_planes = env_int("FS2_OP_ATT_PLANES", 0); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 0); x.w32 = env_int("FS2_ATTN_W32", -1);
         x.row4 = env_int("FS2_ROW4", -1); x.mt4 = env_int("FS2_MT4", -1); x.ffn2_mx = env_int("FS2_FFN2_MX", 1); x.qkv4 = env_int("FS2_QKV4", -1);
+        if (!audit_clean()) {
+            x.w32 = 0; x.row4 = 0; x.qkv4 = 0;
+            fprintf(stderr, "libfs2_hip: no clean ISA-audit record of this binary (libfs2_hip.audit.json next to it): attn_w32 and gemm_row4_bf16 are switched "
+                            "off, attn_bf16 / gemm_row8_bf16 run instead; rebuild with `python -c 'import __graft_entry__ as g; g.build()'`\n");
+        }
         return x;
     }();
     return o;
@@ -220,6 +312,8 @@ struct fs2_handle {
     long enc_ntok = 0;         // phonemes of the encoded batch (basis of the frame-level kernel-variant choice)
     float* kp = nullptr; size_t kp_cap = 0;   // split-K scratch of the call in progress (carved from its workspace)
     int cur_regime = 0;        // regime_rows of the call in progress (0: the launch's own row count)
+    int* counters = nullptr;   // device int[16], zeroed at creation: [0] = waves of attn_w32 that left the fast path (fs2_get_counter)
+    int* cur_status = nullptr; // device-driven layout: the status words of the call in progress ([5] counts the same event for that call alone)
     int gap = kGap;            // zero rows between packed utterances: max(kMinGap, largest conv halo of this model)
     void* enc_ws = nullptr;
     std::vector<void*> graph_pinned;   // host staging owned by captured graphs (see upload_layout)
@@ -759,6 +853,7 @@ int launch_attention_b16(fs2_handle* h, hipStream_t s, const char* name, const f
     a.start = dl.start; a.len = dl.len; a.klen = dl.klen; a.work = dl.work; a.nwork = dl.dims ? dl.dims + 1 : nullptr; a.nitems = nwork; a.D = D; a.mask_q = mask_q;
     const ptrdiff_t qk_d = reinterpret_cast<const char*>(qkl) - reinterpret_cast<const char*>(qkh), vt_d = reinterpret_cast<const char*>(vtl) - reinterpret_cast<const char*>(vth);
     a.qk_lo_bytes = (unsigned)qk_d; a.vt_lo_bytes = (unsigned)vt_d;
+    a.slow_count = h ? h->counters : nullptr; a.slow_count2 = (h && h->cur_status) ? h->cur_status + 5 : nullptr;
     Scope sc(h, s, name, flops, 0.0);
     hipError_t e;
     // (the regime row count of the call in progress when there is one: derived from the phoneme count, it is the same number in the host-
@@ -1366,7 +1461,25 @@ int check_batch(fs2_handle* h, const fs2_batch& b) {
     for (int i = 0; i < b.B; ++i)
         if (b.ilens[i] <= 0 || b.ilens[i] > b.Tmax) return fail(h, FS2_ERR_ARG, "ilens[%d]=%lld outside [1,%d]", i, (long long)b.ilens[i], b.Tmax);
     if (b.precision < FS2_PREC_FP32 || b.precision > FS2_PREC_MIX_MX) return fail(h, FS2_ERR_ARG, "unknown precision mode %d", b.precision);
+    if (b.regime_tokens < 0 || b.regime_utterances < 0 || (b.regime_tokens > 0) != (b.regime_utterances > 0))
+        return fail(h, FS2_ERR_ARG, "batch: regime_tokens=%lld / regime_utterances=%d must be given together (0 / 0 = this call's own batch)", (long long)b.regime_tokens, b.regime_utterances);
     return FS2_OK;
+}
+
+// The row counts the kernel-variant choices are functions of (fs2.h: fs2_batch.regime_*): ESTIMATES of the packed rows of the batch the variants
+// are chosen for -- this call's own, or the larger one the caller names -- at token level (one row per phoneme) and at frame level (8 frames per
+// phoneme; LJSpeech: 7.9), plus the alignment and gap rows of every utterance.  Functions of (phonemes, utterances) only: the host knows both in
+// the host- and in the device-driven layout, and a shard that names the whole batch gets the whole batch's numbers.  Any value gives correct
+// results; the same value gives the same kernels, hence the same bits.
+inline long regime_tokens_of(const fs2_batch& b, bool token_level) {
+    if (b.regime_tokens > 0) return (long)b.regime_tokens;
+    long n = 0;
+    for (int i = 0; i < b.B; ++i) n += (token_level && b.compat_padded) ? (long)b.Tmax : (long)b.ilens[i];      // (padded-batch semantics: the encoder runs on Tmax rows per utterance)
+    return n;
+}
+inline int regime_rows_of(const fs2_batch& b, bool token_level) {
+    const long utts = b.regime_utterances > 0 ? b.regime_utterances : b.B;
+    return (int)std::min<long>((token_level ? 1 : 8) * regime_tokens_of(b, token_level) + utts * (kGap + kAttAlign) + kGap, INT32_MAX - 256);
 }
 
 void token_layout(const fs2_batch& b, HostLayout& L, int gap) {
@@ -1544,6 +1657,13 @@ int fs2_create(const fs2_config* cfg, fs2_handle** out) {
     }
     fs2_handle* h = new fs2_handle();
     h->cfg = *cfg;
+    {
+        DeviceGuard g(cfg->device);
+        if (hipMalloc((void**)&h->counters, 16 * sizeof(int)) != hipSuccess || hipMemset(h->counters, 0, 16 * sizeof(int)) != hipSuccess) {
+            delete h;
+            return fail(nullptr, FS2_ERR_HIP, "hipMalloc of the handle's counters failed");
+        }
+    }
     {   // zero rows between packed utterances: the largest conv halo of this model (launch_gemm refuses kernels > kMaxHalo + 1 taps)
         int p = std::max(std::max(cfg->ffn_kernel, cfg->dur_kernel), cfg->var_kernel);
         if (cfg->postnet_layers > 0) p = std::max(p, cfg->postnet_filts);
@@ -1557,6 +1677,7 @@ void fs2_destroy(fs2_handle* h) {
     if (!h) return;
     DeviceGuard g(h->cfg.device);
     free_weights(h);
+    if (h->counters) hipFree(h->counters);
     for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (void* p : h->graph_pinned) hipHostFree(p);
     delete h;
@@ -1691,7 +1812,8 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
     int* meta; StackBufs sb; float *p0, *p1, *dlog_rows; int64_t* dint; int* cum; int* o32; bool ok;
     carve_tokens(c, b, L, io->workspace, io->workspace_bytes, &meta, &sb, &p0, &p1, &dlog_rows, &dint, &cum, &o32, &ok, &h->kp, &h->kp_cap);
     if (!ok) return fail(h, FS2_ERR_WORKSPACE, "fs2_encode: workspace too small");
-    h->cur_regime = 0;
+    const int tok_regime = regime_rows_of(b, /*token_level=*/true);
+    h->cur_regime = tok_regime; h->cur_status = nullptr;
     if ((rc = upload_layout(h, s, L, meta, h->dtok))) return rc;
     const DevLayout& dl = h->dtok;
     const bool enc_pl = prec != FS2_PREC_FP32;   // activations also travel as planes (x0p holds those of x0 before and after the stack)
@@ -1702,7 +1824,7 @@ int fs2_encode(fs2_handle* h, void* stream, const fs2_encode_io* io) {
                            enc_pl && c.adim % 32 == 0 ? sb.x0p : nullptr);
         HIP_TRY(h, hipGetLastError());
     }
-    if ((rc = run_stack(h, s, "enc", h->enc, c.adim, c.aheads, L.R, L, dl, /*mask_q=*/1, sb, prec, /*x0p_ready=*/enc_pl && c.adim % 32 == 0, /*allow_splitk=*/true, /*regime_rows=*/0, ffn_terms))) return rc;
+    if ((rc = run_stack(h, s, "enc", h->enc, c.adim, c.aheads, L.R, L, dl, /*mask_q=*/1, sb, prec, /*x0p_ready=*/enc_pl && c.adim % 32 == 0, /*allow_splitk=*/true, /*regime_rows=*/tok_regime, ffn_terms))) return rc;
     if ((rc = run_predictor(h, s, "dur", h->dur, sb.x0, c.adim, L.R, dl.row_pos, p0, p1, dlog_rows, prec, enc_pl ? sb.x0p : nullptr, sb.xps))) return rc;
     {
         Scope sc(h, s, "dur.post", 0, 0);
@@ -1795,10 +1917,10 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     const int R = L.R;
     // Kernel variants with different summation orders (LayerNorm fused into the row-complete GEMM or not) are chosen from a row
     // count.  The exact one is unknown to the host in the device-driven mode, and the capacity differs from it, so both modes use
-    // the same ESTIMATE instead: 8 frames per phoneme (LJSpeech: 7.9) plus the per-utterance alignment rows.  Any value gives
-    // correct results; using the same one in both modes makes them bit-identical.
-    const int regime_rows = (int)std::min<long>(8 * h->enc_ntok + (long)b.B * (kGap + kAttAlign) + kGap, INT32_MAX - 256);
-    h->cur_regime = regime_rows;
+    // the same ESTIMATE instead (regime_rows_of): 8 frames per phoneme plus the per-utterance alignment rows -- of this batch, or of
+    // the larger batch the caller says this one is a shard of (fs2_batch.regime_*).
+    const int regime_rows = regime_rows_of(b, /*token_level=*/false);
+    h->cur_regime = regime_rows; h->cur_status = devlay ? io->status : nullptr;
     // bf16 modes: the length-regulator output (and later its sum with the pitch / energy embeddings) is also written as planes,
     // in x1p (free until the decoder stack's first LayerNorm): the A operand of both variance predictors and of the decoder input layer
     void* hfr_planes = (prec != FS2_PREC_FP32 && c.adim % 32 == 0) ? f.sb.x1p : nullptr;
@@ -2161,6 +2283,47 @@ int fs2_set_option(const char* name, int32_t value) {
     else if (n == "FS2_FFN2_MX") o.ffn2_mx = value != 0;
     else if (n == "FS2_QKV4") o.qkv4 = value;
     else return fail(nullptr, FS2_ERR_ARG, "fs2_set_option: unknown option %s", name);
+    return FS2_OK;
+}
+
+int fs2_get_option(const char* name, int32_t* value) {
+    if (!name || !value) return fail(nullptr, FS2_ERR_ARG, "fs2_get_option: null argument");
+    const Options& o = opts();
+    const std::string n = name;
+    if (n == "FS2_AUDIT_CLEAN") *value = audit_clean() ? 1 : 0;
+    else if (n == "attn_w32_active") *value = o.w32 != 0;
+    else if (n == "row4_active") *value = o.row4 != 0;
+    else if (n == "qkv4_active") *value = o.qkv4 != 0 && o.row4 != 0;
+    else if (n == "FS2_BM") *value = o.bm;
+    else if (n == "FS2_ROW8") *value = o.row8;
+    else if (n == "FS2_QKV8") *value = o.qkv8;
+    else if (n == "FS2_NOSPLITK") *value = o.nosplitk;
+    else if (n == "FS2_F32_ROWS") *value = o.f32_rows;
+    else if (n == "FS2_MT8") *value = o.mt8;
+    else if (n == "FS2_QKV_SPLIT") *value = o.qkv_split;
+    else if (n == "FS2_OP_ATT_PLANES") *value = o.op_att_planes;
+    else if (n == "FS2_FUSE_VAR") *value = o.fuse_var;
+    else if (n == "FS2_BAL") *value = o.bal;
+    else if (n == "FS2_ATTN_W32") *value = o.w32;
+    else if (n == "FS2_ROW4") *value = o.row4;
+    else if (n == "FS2_MT4") *value = o.mt4;
+    else if (n == "FS2_FFN2_MX") *value = o.ffn2_mx;
+    else if (n == "FS2_QKV4") *value = o.qkv4;
+    else return fail(nullptr, FS2_ERR_ARG, "fs2_get_option: unknown option %s", name);
+    return FS2_OK;
+}
+
+int fs2_get_counter(fs2_handle* h, void* stream, const char* name, int64_t* value, int32_t reset) {
+    if (!h || !name || !value) return fail(h, FS2_ERR_ARG, "fs2_get_counter: null argument");
+    if (std::string(name) != "attn_slow_path_waves") return fail(h, FS2_ERR_ARG, "fs2_get_counter: unknown counter %s", name);
+    DeviceGuard g(h->cfg.device);
+    HIP_TRY(h, g.err);
+    hipStream_t s = (hipStream_t)stream;
+    int v = 0;
+    HIP_TRY(h, hipMemcpyAsync(&v, h->counters, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (reset) HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(int), s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    *value = v;
     return FS2_OK;
 }
 

@@ -444,7 +444,7 @@ class FeedForwardTransformer(nn.Module):
 
     # ------------------------------------------------------------------ the path
     def _run(self, xs, ilens, olens=None, ds=None, es=None, ps=None, is_inference=False, compat=False,
-             want=("before", "after"), d_override=None, capacity=None, alpha=1.0, packed_out=None):
+             want=("before", "after"), d_override=None, capacity=None, alpha=1.0, packed_out=None, regime=None):
         """Runs fs2_encode -> (olens readback) -> fs2_decode.  Returns a dict of device tensors.
 
         ``capacity=(total_frames_bound, per_utterance_bound)`` selects the device-driven frame layout instead: no host
@@ -453,7 +453,10 @@ class FeedForwardTransformer(nn.Module):
         int32[8] = {rows used, attention work items, overflow flags, longest utterance, valid frames, ...}: the results are
         valid only if ``status[2] == 0`` (see ``inference_batch(sync=False)``); ``after_packed`` then has
         ``fs2_row_capacity(total_frames_bound)`` x reduction_factor rows, of which the first ``status[4]`` x reduction_factor are filled; ``packed_out`` (a contiguous
-        float32 [>= that many rows, odim] tensor) receives them in place instead of a new allocation."""
+        float32 [>= that many rows, odim] tensor) receives them in place instead of a new allocation.
+
+        ``regime=(phonemes, utterances)`` of the batch the kernel variants are to be chosen for (include/fs2.h: fs2_batch.regime_*):
+        a shard of a larger batch names the whole batch and is computed bit-identically to the one-call run of the whole batch."""
         _require_device(xs)
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
@@ -473,7 +476,15 @@ class FeedForwardTransformer(nn.Module):
         L = self._ensure_ready(dev, Tmax)
         h = self._handle
         il_arr = (C.c_int64 * B)(*il.tolist())
-        batch = _lib.Batch(B, Tmax, il_arr, int(compat), prec)
+        if regime is not None:
+            rt, ru = int(regime[0]), int(regime[1])
+            if rt <= 0 or ru <= 0:
+                raise ValueError("regime=(phonemes, utterances) must both be positive, got %r" % (regime,))
+            if compat:
+                raise ValueError("regime applies to per-utterance semantics: a padded_compat batch depends on its batch-mates anyway")
+            batch = _lib.Batch(B, Tmax, il_arr, int(compat), prec, rt, ru)
+        else:
+            batch = _lib.Batch(B, Tmax, il_arr, int(compat), prec)
         out = {}
         teacher = not is_inference
         ds_dev = None
@@ -572,7 +583,7 @@ class FeedForwardTransformer(nn.Module):
                     raise ValueError("olens %s do not match the sums of the durations %s" % (given.tolist(), ol.tolist()))
             Lmax = int(ol.max())
             if self.decoder.embed[-1].ensure(Lmax):                # pe table grew: reload and redo the encoder
-                return self._run(xs, ilens, olens, ds, es, ps, is_inference, compat, want, d_override, alpha=alpha)
+                return self._run(xs, ilens, olens, ds, es, ps, is_inference, compat, want, d_override, alpha=alpha, regime=regime)
             ol_arr = (C.c_int64 * B)(*ol.tolist())
             frm_ws = torch.empty(L.fs2_frame_workspace_bytes(h, C.byref(batch), ol_arr), dtype=torch.uint8, device=dev)
             odim = self.odim
@@ -694,7 +705,7 @@ class FeedForwardTransformer(nn.Module):
         self._learn_ratio(il, r["olens"], alpha)
         return r["after"][0]
 
-    def inference_batch(self, xs, ilens, d_override=None, packed=False, sync=True, capacity=None, alpha=1.0, packed_out=None):
+    def inference_batch(self, xs, ilens, d_override=None, packed=False, sync=True, capacity=None, alpha=1.0, packed_out=None, regime=None):
         """Batched free-running synthesis (not in the reference, which only has single-utterance
         ``inference``): per-utterance semantics; returns (mels [B, Lmax, odim], olens [B] on the host = MEL frames per utterance,
         i.e. decoder frames x reduction_factor), or with
@@ -710,7 +721,11 @@ class FeedForwardTransformer(nn.Module):
         ``ok()`` is then False: repeat the batch with ``sync=True`` (which learns the exact sizes).  ``packed_out``: a
         caller-owned [>= row capacity, odim] buffer that receives the pack in place (the multi-GPU send buffer).  Any number of
         asynchronous calls may be in flight; ``async_ok()`` waits for all of them and tells whether every one since the last
-        ``async_ok()`` was valid.  The first call of a model is always synchronous.  ``alpha``: duration scale."""
+        ``async_ok()`` was valid.  The first call of a model is always synchronous.  ``alpha``: duration scale.
+
+        ``regime=(phonemes, utterances)``: this batch is a SHARD of a batch of that size -- choose the kernel variants (which differ in
+        summation order, i.e. in the last bits) as the one-call run of the whole batch would, so that every utterance comes out bit-identical
+        to that run (what ``ShardedSynthesizer`` passes on every rank; include/fs2.h: fs2_batch.regime_tokens / regime_utterances)."""
         il = torch.as_tensor(ilens).detach().to("cpu", torch.int64).reshape(-1)
         if not float(alpha) > 0.0:
             raise ValueError("alpha must be > 0 (reference length_regulator.py:57), got %r" % (alpha,))
@@ -723,13 +738,13 @@ class FeedForwardTransformer(nn.Module):
             total, Lcap = capacity if capacity is not None else self.predict_capacity(il, alpha)
             key = "after_packed" if packed else "after"         # (packed: the padded mels are neither built nor written)
             r = self._run(xs, il, is_inference=True, compat=False, want=(key,), d_override=d_override, capacity=(total, Lcap), alpha=alpha,
-                          packed_out=packed_out if packed else None)
+                          packed_out=packed_out if packed else None, regime=regime)
             mel_lens = r["olens"] if self.reduction_factor == 1 else r["olens"] * self.reduction_factor     # mel frames per utterance
             if torch.cuda.is_current_stream_capturing():     # graph capture: no host-side bookkeeping inside the graph
                 return AsyncMels(r[key], mel_lens, r["status"], None)
             return AsyncMels(r[key], mel_lens, r["status"], self._record_async(il, r, xs.device, alpha))
         want = ("after", "after_packed") if packed else ("after",)
-        r = self._run(xs, il, is_inference=True, compat=False, want=want, d_override=d_override, alpha=alpha)
+        r = self._run(xs, il, is_inference=True, compat=False, want=want, d_override=d_override, alpha=alpha, regime=regime)
         if d_override is None:
             self._learn_ratio(il, r["olens"], alpha)
         else:

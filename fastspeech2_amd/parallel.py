@@ -5,7 +5,8 @@ The reference has no distributed code at all.  Utterance
 units: every rank holds the (tiny) id batch, takes a cost-balanced subset of the utterances, runs the
 single-GPU path on it, and the only exchange is an all-gather of the final mels over RCCL/xGMI (backend
 "nccl" on ROCm; "gloo" in the CPU tests).  The gather and the order restoration are exact; an utterance's values do not
-depend on its batch-mates (only, in the last bits, on the size-dependent kernel variants: DESIGN.md section 1).
+depend on its batch-mates, and -- every rank naming the whole batch as the basis of its kernel-variant choice (``regime``) -- not on
+how the batch was split either: sharded == unsharded bit for bit (DESIGN.md sections 1 and 5).
 """
 import contextlib
 
@@ -286,14 +287,20 @@ class ShardedSynthesizer:
     * ``ShardedSynthesizer(run_local)`` with a callable ``run_local(xs_shard, ilens_shard) -> (mels, olens)``: generic form
       (host-driven gather of ragged padded batches, :func:`gather_mels`)."""
 
-    def __init__(self, model_or_fn, group=None, overlap=False):
+    def __init__(self, model_or_fn, group=None, overlap=False, global_regime=True):
         """``overlap=True`` (throughput mode): the collective and the unpack of a sync-free call run on a side stream, so the
         all-gather of batch i over xGMI overlaps the forward of batch i+1; the returned tensors then belong to that stream:
-        call ``wait()`` (or synchronize the device) before touching them on the current stream."""
+        call ``wait()`` (or synchronize the device) before touching them on the current stream.
+
+        ``global_regime=True`` (default): every rank names the WHOLE batch's size as the basis of its kernel-variant choice
+        (``inference_batch(regime=(phonemes, utterances))``), so each shard is computed by exactly the kernels the one-GPU run of
+        the whole batch uses and the gathered result is bit-identical to that run (SURVEY.md section 8e's criterion).  ``False``:
+        each shard picks the variants of its own size -- results then agree with the one-GPU run to ~2e-5, not bit for bit."""
         self.model = model_or_fn if hasattr(model_or_fn, "inference_batch") else None
         self.run_local = None if self.model is not None else model_or_fn
         self.group = group
         self.overlap = bool(overlap)
+        self.global_regime = bool(global_regime)
         self._comm = None
         self._ratio = None          # (mean, max) frames per phoneme agreed between the ranks
         self._last = None           # the most recent sync-free call's AsyncMels (introspection; ok() is cumulative)
@@ -351,6 +358,8 @@ class ShardedSynthesizer:
                 mel = mel.new_zeros(0, 1, int(odim))
             return gather_mels(mel, olens, mine, xs.shape[0], self.group)
         model = self.model
+        if self.global_regime:
+            kw_loc = dict(kw_loc, regime=(int(il.sum()), int(il.numel())))
         if self._ratio is None or sync:
             # synchronous pass: exact sizes on every rank (host-driven layout), learn and agree on the ratio
             if len(mine):

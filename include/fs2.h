@@ -62,7 +62,7 @@ typedef struct fs2_handle fs2_handle;
  * fs2_load_weights.  Their layout is frozen within a revision: any change to them bumps FS2_ABI_VERSION, and a binding
  * compares its own FS2_ABI_VERSION with fs2_abi_version() before the first call (fastspeech2_amd/_lib.py: lib();
  * csrc/fs2_torch_op.cpp: check_abi()). */
-#define FS2_ABI_VERSION 3
+#define FS2_ABI_VERSION 4
 int32_t fs2_abi_version(void);
 
 /* Model hyper-parameters: the hp.model / hp.data fields FeedForwardTransformer.__init__ reads
@@ -109,6 +109,15 @@ typedef struct fs2_batch {
                                computes).  1: reproduce the reference's padded-batch numerics
                                (conv / unmasked attention see the pad rows)      */
     int32_t precision;      /* FS2_PREC_*                                                      */
+    /* Kernel-variant regime (ABI 4).  Some launches exist in variants that sum in different orders (LayerNorm fused into the
+     * row-complete GEMM or not, deterministic split-K, the 32- or the 64-query attention kernel); which one runs is a function
+     * of the SIZE of the batch only -- of these two numbers, never of a capacity or of the data.  0 / 0 = this call's own batch
+     * (sum of ilens, B).  A caller that runs a SHARD of a larger batch (one rank of the multi-GPU split, a batch cut into
+     * pieces) passes the WHOLE batch's numbers on every piece: every utterance is then computed by exactly the kernels the
+     * one-call run of the whole batch uses, and its result is bit-identical to that run's (SURVEY.md section 8e's criterion;
+     * the per-utterance semantics of reference fastspeech.py:169-243).  Both numbers must be given together. */
+    int64_t regime_tokens;      /* phonemes of the batch the variants are chosen for (0: sum of ilens)  */
+    int32_t regime_utterances;  /* utterances of that batch (0: B)                                      */
 } fs2_batch;
 
 typedef struct fs2_encode_io {
@@ -162,7 +171,8 @@ typedef struct fs2_decode_io {
      * left in the token workspace, the packed-row layout and the attention work list are built by a kernel, grids
      * are sized for the capacities and the surplus tiles exit at once.  Lmax is then the per-utterance capacity of
      * the padded outputs.  status (device int32[8], required in this mode) receives
-     * {total rows used, attention work items, overflow flags, longest utterance, valid frames, 0, 0, 0}; overflow
+     * {total rows used, attention work items, overflow flags, longest utterance, valid frames, waves of this call's decoder
+     * attention that left attn_w32's fast path (see fs2_get_counter), 0, 0}; overflow
      * flags != 0 (FS2_OVF_*) means a capacity was too small and the outputs are invalid -- before / after /
      * after_packed are then filled with NaN: rerun with larger capacities or with host olens.  after_packed,
      * if given, must hold r * row_capacity rows in this mode. */
@@ -266,6 +276,25 @@ int fs2_op_duration(void *stream, const float *d_log, int64_t n, int64_t *d);
  * "FS2_F32_ROWS", "FS2_MT8", "FS2_FUSE_VAR", "FS2_BAL"; -1 = automatic).  Their initial values come from the environment variables of the same
  * names, read once when the library is first used; the launch path never reads the environment. */
 int fs2_set_option(const char *name, int32_t value);
+
+/* Reads a switch back (the value fs2_set_option / the environment left: -1 = automatic), or one of the read-only facts about
+ * THIS binary a benchmark line should carry:
+ *   "FS2_AUDIT_CLEAN"   1 if a clean ISA-audit record of exactly this binary (libfs2_hip.audit.json next to it, tied to the
+ *                       file's SHA-256) was found when the library was first used, else 0.  The kernels whose accumulators
+ *                       are literal registers (attn_w32, gemm_row4_bf16) run only in an audited binary: without the record
+ *                       FS2_ATTN_W32 / FS2_ROW4 / FS2_QKV4 start at 0 for EVERY consumer of the library (ctypes, the
+ *                       TorchScript op, a C program) and can only be switched on by an explicit fs2_set_option;
+ *   "attn_w32_active" / "row4_active" / "qkv4_active"   1 if that kernel is allowed to run (its switch is not 0).
+ * Unknown name: FS2_ERR_ARG. */
+int fs2_get_option(const char *name, int32_t *value);
+
+/* Cumulative event counters of a handle (device memory, read back with one blocking 8-byte copy behind `stream`):
+ *   "attn_slow_path_waves"  waves of attn_w32 that left the fast path because a row's probabilities, relative to its FIRST key
+ *                           tile's maximum, summed beyond 2^60 (peaked attention of a trained model: reference
+ *                           core/attention.py:55-62 has no such notion, its softmax is one formula) and were recomputed by the
+ *                           plain fp32 two-pass loop: correct, but ~30 x slower per wave.  0 on flat (random-init) attention.
+ * reset != 0 zeroes the counter after reading it. */
+int fs2_get_counter(fs2_handle *h, void *stream, const char *name, int64_t *value, int32_t reset);
 
 #ifdef __cplusplus
 }

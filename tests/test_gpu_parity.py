@@ -718,131 +718,142 @@ def _explain_by_bucket_flips(model, precision, b, i, oracle, sd, cfg, O, decisio
 
 
 def test_c5_all_1024_utterances_through_the_eight_shards(env, monkeypatch):
-    """BASELINE config c5 (batch = 1024 sharded over 8 MI355X), ALL of it: the eight LPT shards (`shard_indices`) run one
-    after another on this box's one GPU through `ShardedSynthesizer` -- the sync-free single-GPU path into the very send buffers of the
-    collective -- with `torch.distributed` replaced by a stand-in that plays the eight ranks in turn and hands the last one the eight send
-    buffers as its all-gather result; `gather_shards` then does what it does on a node (frame counts out of the tail rows, device-side offsets,
+    """BASELINE config c5 (batch = 1024 sharded over 8 MI355X), ALL of it: the eight LPT shards (`shard_indices`) run one after another on this
+    box's one GPU through `ShardedSynthesizer` -- the sync-free single-GPU path into the very send buffers of the collective -- with
+    `torch.distributed` replaced by a stand-in that plays the eight ranks in turn and hands the last one the eight send buffers as its all-gather
+    result (tests/fake_dist.py); `gather_shards` then does what it does on a node (frame counts out of the tail rows, device-side offsets,
     `fs2_op_unpack_rows_dev`).  Checked, in mix_mx (what bench.py runs):
-      * the assembled result is bit-identical to every shard run alone through the plain entry point (host-driven layout), zero beyond every utterance;
-      * every one of the 1,024 utterances (613 k frames) of the assembled result AND of the unsharded 1,024-utterance call matches the oracle -- within
-        the tolerance, or, the pass being free-running in pitch and energy (1.2 M bucket decisions), with its differences explained by decisions that
-        fell on the other side of a bin edge the oracle's own predictor output touches (then re-verified teacher-forced), as at c4;
-      * assembled vs unsharded: not bit-identical by design -- an utterance's values never depend on its batch-mates' values, but kernel variants are
-        chosen by the batch's size (a 9.6 k-token shard runs the encoder's LayerNorms as separate row passes, the 77 k-token batch
-        fused into the GEMM epilogue), ~1e-5 on the predictor outputs, so the two runs may also DECIDE differently at a bin edge (first seen on
-        utterance 130: 0.044 on the mel, both sides right by the criterion above).  Recorded, with the number of such utterances.
-    The real 8-rank collective is covered over gloo (tests/test_parallel_gloo.py) and over nccl in tests/test_gpu_multi.py."""
+      * SURVEY.md section 8e's criterion: the assembled result is BIT-IDENTICAL to the one-GPU call of all 1,024 utterances -- every rank names the
+        whole batch as the basis of its kernel-variant choice (`regime`, include/fs2.h: fs2_batch.regime_*; round 6), so a 9.6 k-token shard runs
+        the very kernels the 77 k-token batch runs (round 5: variants by the shard's own size, ~2e-5 apart, one utterance 0.044 apart through a bucket
+        decision at a bin edge);
+      * so is every shard run alone through the plain entry point with the same `regime` (host-driven layout): mels AND the 1.2 M bucket decisions;
+      * every one of the 1,024 utterances (613 k frames) matches the oracle -- within the tolerance, or, the pass being free-running in pitch and
+        energy, with its differences explained by decisions that fell on the other side of a bin edge the oracle's own predictor output touches
+        (then re-verified teacher-forced), as at c4;
+      * without the override (`global_regime=False`) the shards agree with the one-GPU call to 5e-5 wherever the decisions agree (recorded).
+    The real 8-rank collective is covered over gloo (tests/test_parallel_gloo.py) and over nccl in tests/test_gpu_zmulti.py."""
     model, sd, cfg, O = env
     import fastspeech2_amd.parallel as P
     from fastspeech2_amd.synthetic import make_batch
+    from tests import fake_dist
     from tests.conftest import record_measurement
     b = make_batch("c5")
     B, W = 1024, 8
     parts = P.shard_indices(b["ilens"].tolist(), W)
     assert sorted(sum(parts, [])) == list(range(B)) and all(100 <= len(p_) <= 160 for p_ in parts)
     xs, il, ds = b["xs"].cuda(), b["ilens"], b["ds"].cuda()
-    state = {"rank": 0, "sends": {}}
-
-    class FakeDist:
-        """the eight ranks of one node, played in turn by this process"""
-        ReduceOp = P.dist.ReduceOp
-        is_available = staticmethod(lambda: True)
-        is_initialized = staticmethod(lambda: True)
-        get_world_size = staticmethod(lambda group=None: W)
-        get_rank = staticmethod(lambda group=None: state["rank"])
-
-        @staticmethod
-        def all_reduce(t, op=None, group=None):
-            return None
-
-        @staticmethod
-        def all_gather_into_tensor(recv, send, group=None):
-            state["sends"][state["rank"]] = send.clone()
-            recv.zero_()
-            if len(state["sends"]) == W:
-                rv = recv.view(W, send.shape[0], send.shape[1])
-                for q in range(W):
-                    rv[q].copy_(state["sends"][q])
-
+    whole = (int(il.sum()), B)
     model.precision = "mix_mx"
     try:
         with torch.no_grad():
-            un = model._run(xs, il, is_inference=True, d_override=ds, want=("after", "qe", "qp"))          # the unsharded call (host-driven layout)
+            un = model._run(xs, il, is_inference=True, d_override=ds, want=("after", "qe", "qp"))          # the one-GPU call (host-driven layout)
             assert torch.equal(un["olens"], b["olens"]) and torch.isfinite(un["after"]).all()
             un_after, un_qe, un_qp = un["after"].cpu(), un["qe"].cpu().long(), un["qp"].cpu().long()
             del un
             model.inference_batch(xs[:64], il[:64], d_override=ds[:64])                                      # (teaches the capacity predictor a ratio)
             ratio = model._frames_per_token
-            monkeypatch.setattr(P, "dist", FakeDist)
-            synth = P.ShardedSynthesizer(model)
-            synth._ratio = (float(ratio[0]) * 1.05, float(ratio[1]) * 1.2)
-            out = None
-            for r in range(W):
-                state["rank"] = r
-                out = synth(xs, il, d_override=ds, packed=(r < W - 1))      # the last "rank" also scatters into the padded result
-            monkeypatch.undo()
+            mels, ol_dev = fake_dist.run_all_ranks(P, monkeypatch, model, W, xs, il, (float(ratio[0]) * 1.05, float(ratio[1]) * 1.2), d_override=ds)
             assert model.async_ok()
-            mels, ol_dev = out
             assert torch.equal(ol_dev.cpu(), b["olens"])
             mels_h = mels.cpu()
-            del mels, out
-            # every shard alone: bit-identical to its part of the assembled result; its own bucket decisions are kept for the oracle comparison
-            sh_qe, sh_qp = [None] * B, [None] * B
+            del mels
+            Lm = un_after.shape[1]
+            assert torch.equal(mels_h[:, :Lm], un_after) and float(mels_h[:, Lm:].abs().sum()) == 0.0, "sharded (8 ranks) != the one-GPU call of the whole batch"
+            # every shard alone, naming the whole batch: bit-identical too, bucket decisions included; and once without the override
+            worst_local, apart_local = 0.0, 0
             for r, p_ in enumerate(parts):
                 sel = torch.as_tensor(p_)
                 il_s = il[sel]
                 Tm = int(il_s.max())
-                rs = model._run(xs[sel.cuda()][:, :Tm], il_s, is_inference=True, d_override=ds[sel.cuda()][:, :Tm], want=("after", "qe", "qp"))
+                rs = model._run(xs[sel.cuda()][:, :Tm], il_s, is_inference=True, d_override=ds[sel.cuda()][:, :Tm], want=("after", "qe", "qp"), regime=whole)
                 assert torch.equal(rs["olens"], b["olens"][sel])
                 a_h, qe_h, qp_h = rs["after"].cpu(), rs["qe"].cpu().long(), rs["qp"].cpu().long()
+                rl = model._run(xs[sel.cuda()][:, :Tm], il_s, is_inference=True, d_override=ds[sel.cuda()][:, :Tm], want=("after", "qe", "qp"))
+                l_h, lqe_h, lqp_h = rl["after"].cpu(), rl["qe"].cpu().long(), rl["qp"].cpu().long()
                 for j, g in enumerate(p_):
                     L = int(rs["olens"][j])
-                    assert torch.equal(mels_h[g, :L], a_h[j, :L]), (r, g)
-                    assert float(mels_h[g, L:].abs().sum()) == 0.0, g
-                    sh_qe[g], sh_qp[g] = qe_h[j, :L], qp_h[j, :L]
+                    assert torch.equal(un_after[g, :L], a_h[j, :L]), (r, g)
+                    assert torch.equal(un_qe[g, :L], qe_h[j, :L]) and torch.equal(un_qp[g, :L], qp_h[j, :L]), (r, g)
+                    if torch.equal(un_qe[g, :L], lqe_h[j, :L]) and torch.equal(un_qp[g, :L], lqp_h[j, :L]):
+                        worst_local = max(worst_local, _maxabs(un_after[g, :L], l_h[j, :L]))
+                    else:
+                        apart_local += 1
     finally:
         model.precision = "fp32"
-    # every utterance of both results against the oracle
+    assert worst_local <= 5e-5, worst_local
+    # every utterance against the oracle
     i0 = int(torch.argmax(il))
     prev_threads = _tune_oracle_threads(O, sd, cfg, b["xs"][i0:i0 + 1, :int(il[i0])], il[i0:i0 + 1], b["ds"][i0:i0 + 1, :int(il[i0])])
-    worst, worst_un, flipped_utts, flipped_frames, apart, worst_apart_same = 0.0, 0.0, 0, 0, 0, 0.0
+    worst, flipped_utts, flipped_frames = 0.0, 0, 0
     try:
         for i in range(B):
             T, L = int(il[i]), int(b["olens"][i])
             o = O.padded_forward(sd, cfg, b["xs"][i:i + 1, :T], il[i:i + 1], is_inference=True, d_override=b["ds"][i:i + 1, :T])
             orc = (o["after"][0], o["qe"][0, :L].long(), o["qp"][0, :L].long(), o["e_outs"][0, :L].float(), o["p_outs"][0, :L].float())
-            explained = False
-            for tag, mel, dec in (("sharded", mels_h[i, :L], (sh_qe[i], sh_qp[i])), ("unsharded", un_after[i, :L], (un_qe[i, :L], un_qp[i, :L]))):
-                d = _maxabs(mel, orc[0])
-                if d > MEL_TOL:
-                    d, flips = _explain_by_bucket_flips(model, "mix_mx", b, i, orc, sd, cfg, O, decisions=dec)
-                    explained = True
-                    if tag == "sharded":
-                        flipped_utts += 1
-                        flipped_frames += flips
-                assert d <= MEL_TOL, (tag, i, L, d)
-                if tag == "sharded":
-                    worst = max(worst, d)
-                else:
-                    worst_un = max(worst_un, d)
-            dd = _maxabs(mels_h[i, :L], un_after[i, :L])
-            if dd > 1e-4:
-                apart += 1
-                assert explained, (i, dd)          # the two runs differ visibly only where one of them decided differently from the oracle at a bin edge
-            else:
-                worst_apart_same = max(worst_apart_same, dd)
+            d = _maxabs(mels_h[i, :L], orc[0])
+            if d > MEL_TOL:
+                d, flips = _explain_by_bucket_flips(model, "mix_mx", b, i, orc, sd, cfg, O, decisions=(un_qe[i, :L], un_qp[i, :L]))
+                flipped_utts += 1
+                flipped_frames += flips
+            assert d <= MEL_TOL, (i, L, d)
+            worst = max(worst, d)
     finally:
         torch.set_num_threads(prev_threads)
-    assert worst_apart_same <= 5e-5, worst_apart_same
-    print("c5, all %d utterances / %d frames through the 8 LPT shards (%s utterances each): assembled == each shard run alone, bit for bit; worst mel max-abs vs the "
-          "oracle %.2e (unsharded call: %.2e); %d bucket decision(s) in %d utterance(s) of the sharded run on the other side of a bin edge (verified teacher-forced); "
-          "sharded vs unsharded: %d utterance(s) apart through such a decision, the others within %.1e (kernel variants by batch size)"
-          % (B, int(b["olens"].sum()), [len(p_) for p_ in parts], worst, worst_un, flipped_frames, flipped_utts, apart, worst_apart_same))
+    print("c5, all %d utterances / %d frames through the 8 LPT shards (%s utterances each): assembled == the one-GPU call of the whole batch == each shard run "
+          "alone with regime = the whole batch, bit for bit (mels and bucket decisions); worst mel max-abs vs the oracle %.2e; %d bucket decision(s) in %d "
+          "utterance(s) on the other side of a bin edge (verified teacher-forced, mel error of those utterances beside an agreed decision); shards with their OWN "
+          "regime vs the whole batch: within %.1e on the utterances with the same decisions, %d utterance(s) apart through a decision"
+          % (B, int(b["olens"].sum()), [len(p_) for p_ in parts], worst, flipped_frames, flipped_utts, worst_local, apart_local))
     record_measurement("c5_all1024_mel_maxabs_mix_mx", worst)
-    record_measurement("c5_all1024_unsharded_mel_maxabs_mix_mx", worst_un)
     record_measurement("c5_all1024_flipped_bucket_decisions_mix_mx", flipped_frames)
-    record_measurement("c5_all1024_sharded_vs_unsharded_same_decisions_maxabs_mix_mx", worst_apart_same)
-    record_measurement("c5_all1024_sharded_vs_unsharded_utterances_apart_by_a_decision", apart)
+    record_measurement("c5_all1024_own_regime_vs_whole_batch_same_decisions_maxabs_mix_mx", worst_local)
+    record_measurement("c5_all1024_own_regime_vs_whole_batch_utterances_apart_by_a_decision", apart_local)
+
+
+@pytest.mark.parametrize("B,world", [(19, 2), (67, 8)])
+def test_shards_named_after_the_whole_batch_equal_the_one_gpu_call(env, monkeypatch, B, world):
+    """tests/test_gpu_zmulti.py's exact shapes (its batches of 8 W + 3 utterances, bf16x3, teacher-forced durations) on ONE GPU: B = 19 over 2 ranks
+    puts the whole batch (regime 11.8 k rows: attn_w32) and its shards (6 k: attn_bf16) on different sides of the attention-kernel threshold,
+    B = 67 over 8 ranks on different sides of every threshold (row-complete LayerNorm-fused kernels, split-K, attn_w32).  With every rank naming
+    the whole batch (`regime`), both the sync-free sharded path (device-driven layout, packs -> `gather_shards`) and each shard's synchronous call
+    are bit-identical to the one-GPU call -- mels and bucket decisions -- which is what that file asserts over RCCL on a multi-GPU node."""
+    model = env[0]
+    import fastspeech2_amd.parallel as P
+    from fastspeech2_amd.synthetic import make_batch
+    from tests import fake_dist
+    b = make_batch("c5", B=B)
+    xs, il, ds = b["xs"].cuda(), b["ilens"], b["ds"].cuda()
+    parts = P.shard_indices(il.tolist(), world)
+    whole = (int(il.sum()), B)
+    model.precision = "bf16x3"
+    try:
+        with torch.no_grad():
+            un = model._run(xs, il, is_inference=True, d_override=ds, want=("after", "qe", "qp"))
+            ref, ol = model.inference_batch(xs, il, d_override=ds)
+            assert torch.equal(ref, un["after"])
+            ratio = model._frames_per_token
+            mels, ol_dev = fake_dist.run_all_ranks(P, monkeypatch, model, world, xs, il, (float(ratio[0]) * 1.05, float(ratio[1]) * 1.2), d_override=ds)
+            assert model.async_ok() and torch.equal(ol_dev.cpu(), ol)
+            L = ref.shape[1]
+            assert torch.equal(mels[:, :L], ref) and float(mels[:, L:].abs().sum()) == 0.0, "sync-free sharded != the one-GPU call"
+            differs = 0
+            for p_ in parts:
+                sel = torch.as_tensor(p_)
+                Tm = int(il[sel].max())
+                rs = model._run(xs[sel.cuda()][:, :Tm], il[sel], is_inference=True, d_override=ds[sel.cuda()][:, :Tm], want=("after", "qe", "qp"), regime=whole)
+                rl = model._run(xs[sel.cuda()][:, :Tm], il[sel], is_inference=True, d_override=ds[sel.cuda()][:, :Tm], want=("after",))
+                for j, g in enumerate(p_):
+                    n = int(ol[g])
+                    assert torch.equal(rs["after"][j, :n], ref[g, :n]), g
+                    assert torch.equal(rs["qe"][j, :n], un["qe"][g, :n]) and torch.equal(rs["qp"][j, :n], un["qp"][g, :n]), g
+                    differs += int(not torch.equal(rl["after"][j, :n], ref[g, :n]))
+                    assert _maxabs(rl["after"][j, :n], ref[g, :n].cpu()) <= 1e-3
+            # (the premise of the test: without the override these shapes do pick other kernels -- if this ever reads 0 the thresholds have moved
+            #  and the shapes no longer straddle them)
+            assert differs > 0, "the shards' own regimes picked the whole batch's kernels: the test no longer straddles a threshold"
+    finally:
+        model.precision = "fp32"
 
 
 def test_sharded_synthesizer_over_nccl_world_size_1(env):

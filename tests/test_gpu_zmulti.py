@@ -3,7 +3,12 @@
 world_size 1 runs on the one-GPU box (it exercises exactly this worker code and the collective at world size 1); world_size 2 and
 8 skip unless that many GPUs are visible, so the first `pytest -m gpu` on a multi-GPU node also is the first time `gather_shards`
 sees RCCL with more than one rank.  Criterion: the gathered result is bit-identical to the 1-GPU result in the same
-precision mode -- every rank also runs the whole batch unsharded and compares."""
+precision mode -- every rank also runs the whole batch unsharded and compares.  That holds because every rank names the WHOLE batch as the
+basis of its kernel-variant choice (`ShardedSynthesizer(global_regime=True)`, include/fs2.h: fs2_batch.regime_*): these very shapes (B = 19
+over 2 ranks, B = 67 over 8) put the batch and its shards on different sides of the kernel thresholds, and
+tests/test_gpu_parity.py::test_shards_named_after_the_whole_batch_equal_the_one_gpu_call proves the identity for them on ONE GPU (ranks played in
+turn), so that a red result here can only come from the collective.  (The file sorts behind the operator and parity tests on purpose: under
+`pytest -x` nothing multi-GPU can hide them.)"""
 import os
 import socket
 

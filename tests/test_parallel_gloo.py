@@ -37,15 +37,17 @@ class FakeModel:
     _frames_per_token = None
     _overflow_seen = False
     overflow_next = False        # test hook: the next sync-free call behaves like a capacity overflow (NaN pack, flagged)
+    regimes = None               # every `regime` a call was given (ShardedSynthesizer names the WHOLE batch on every rank)
 
     def async_ok(self):
         ok = not self._overflow_seen
         self._overflow_seen = False
         return ok
 
-    def inference_batch(self, xs, ilens, packed=False, sync=True, capacity=None, alpha=1.0):
+    def inference_batch(self, xs, ilens, packed=False, sync=True, capacity=None, alpha=1.0, regime=None):
         from fastspeech2_amd.parallel import row_capacity
         assert packed and xs.shape[0] == len(ilens) > 0, "the synthesizer must not call the model with an empty shard"
+        self.regimes = (self.regimes or []) + [regime]
         mel, ol = _fake_run_local(xs, ilens)
         if alpha != 1.0:         # duration scale: every utterance gets round(L * alpha) frames (its first frame repeated behind)
             ol2 = torch.round(ol.float() * alpha).long()
@@ -75,9 +77,9 @@ class FakeModelR2(FakeModel):
     MEL frames, the capacities handed in by ShardedSynthesizer and the learned frames-per-phoneme ratio count DECODER frames."""
     reduction_factor = 2
 
-    def inference_batch(self, xs, ilens, packed=False, sync=True, capacity=None, alpha=1.0):
+    def inference_batch(self, xs, ilens, packed=False, sync=True, capacity=None, alpha=1.0, regime=None):
         from fastspeech2_amd.parallel import row_capacity
-        assert packed and alpha == 1.0
+        assert packed and alpha == 1.0 and regime is not None and regime[1] >= len(ilens) and regime[0] >= int(torch.as_tensor(ilens).sum())
         mel, ol = _fake_run_local(xs, ilens)
         valid = torch.cat([mel[i, : int(ol[i])].repeat_interleave(2, dim=0) for i in range(len(ol))])
         il = torch.as_tensor(ilens)
@@ -129,6 +131,12 @@ def _worker(rank, world, port, q):
     assert synth.ok()
     assert torch.equal(ol4, want_ol) and torch.equal(mel4[:, :L], want_mel) and float(mel4[:, L:].abs().sum()) == 0.0
     assert not torch.isnan(mel4).any()
+    # every call named the WHOLE batch as the basis of the kernel-variant choice (sharded == unsharded bit for bit on the real model)
+    if mine:
+        assert synth.model.regimes == [(int(il.sum()), int(il.numel()))] * 2, synth.model.regimes
+    local = ShardedSynthesizer(FakeModel(), global_regime=False)
+    local(xs, il)
+    assert not mine or local.model.regimes == [None]
     # (3b) packed return form: no padded [B, Lcap, odim] tensor, frames are read in place from the gathered packs
     recv, starts, ol5 = synth(xs, il, packed=True)
     assert torch.equal(ol5, want_ol)

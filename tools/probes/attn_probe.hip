@@ -27,6 +27,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dstart, start.data(), B * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dlen, len.data(), B * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dklen, klen.data(), B * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dwork, work.data(), work.size() * 8, hipMemcpyHostToDevice));
     AttnB16Args a;
+    memset(&a, 0, sizeof a);
     a.qk_hi = qkh; a.qk_lo = qkl; a.ldqk = 2 * D; a.vt_hi = vth; a.vt_lo = vtl; a.Rvt = Rvt; a.ctx = ctx; a.ldc = D; a.ctxp = nullptr; a.ctxp_chunks = D / 32;
     a.start = dstart; a.len = dlen; a.klen = dklen; a.work = dwork; a.nwork = nullptr; a.D = D; a.mask_q = 0;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16<192, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_b16_lds_bytes<192>()));
