@@ -72,15 +72,23 @@ def cpu_baseline(sd, cfg, batch, gpu, budget_s=14.0):
     B = xs.shape[0]
     # Pick the thread count that is fastest for this op mix (small GEMM/conv calls: all logical cores of a
     # 2-socket host oversubscribe badly), so that the CPU side is not handicapped.
-    one = lambda: O.padded_forward(sd, cfg, xs[:1, : int(il[0])], il[:1], is_inference=True, d_override=ds[:1, : int(il[0])])
+    # (picked from the MEDIAN of three repeats on the batch's MEDIAN-length utterance -- one timing of the first, short utterance
+    #  gave 32 threads on one box and 16 on the next, 11.7 k against 21.5 k frames/s)
+    im = int(torch.argsort(il)[B // 2])
+    Tm_ = int(il[im])
+    one = lambda: O.padded_forward(sd, cfg, xs[im:im + 1, :Tm_], il[im:im + 1], is_inference=True, d_override=ds[im:im + 1, :Tm_])
     ncpu = os.cpu_count() or 1
-    best_t, best_dt = 1, float("inf")
+    best_t, best_dt, tuning = 1, float("inf"), {}
     for nt in sorted({t for t in (4, 8, 16, 32, 64, ncpu // 2, ncpu) if 1 <= t <= ncpu}):
         torch.set_num_threads(nt)
         one()
-        t0 = time.perf_counter()
-        one()
-        dt_ = time.perf_counter() - t0
+        reps = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            one()
+            reps.append(time.perf_counter() - t0)
+        dt_ = statistics.median(reps)
+        tuning[nt] = round(1e3 * dt_, 1)
         if dt_ < best_dt:
             best_t, best_dt = nt, dt_
         if dt_ > 4 * best_dt:
@@ -127,7 +135,9 @@ def cpu_baseline(sd, cfg, batch, gpu, budget_s=14.0):
     cpu_model, phys, logical = host_cpu()
     return dict(value=round(best, 1), unit="mel-frames/s", cores=torch.get_num_threads(), threads=torch.get_num_threads(), host_physical_cores=phys,
                 host_logical_cores=logical, cpu_model=cpu_model, kind="port",
-                cores_note="cores = threads the oracle ran on (the fastest of 4 .. all logical cores for this op mix), not the host's core count",
+                thread_tuning_ms=dict(utterance_phonemes=Tm_, median_of=3, ms_by_threads=tuning),
+                cores_note="cores = threads the oracle ran on (the fastest of 4 .. all logical cores for this op mix: median of 3 repeats on the "
+                           "median-length utterance), not the host's core count",
                 sample="oracle (validated fp32 PyTorch port of the reference path; measured equal to the real reference within noise, "
                        "BASELINE.md section 3) on the c3 batch: per-utterance loop over the first %d utterances (%d frames) = %.0f fr/s; "
                        "one padded batch of %d = %.0f fr/s; faster quoted" % (n, frames, per_utt, nb, padded)), worst, flips
@@ -175,6 +185,44 @@ def sclk_reader(local):
             pass
         return None
     return read if read() is not None else None
+
+
+def smi_sclk_start():
+    """When the sysfs node reads an implausible shader clock (< 500 MHz at normal step times: the node's, not the chip's -- the driver's box in
+    round 5 read 95 MHz), ask the SMI tool once WHILE the queue is full: returns a started subprocess (or None) for smi_sclk_finish()."""
+    import shutil
+    import subprocess
+    for tool, argv in (("amd-smi", ["metric", "--clock"]), ("rocm-smi", ["--showclocks"])):
+        exe = shutil.which(tool) or (os.path.join("/opt/rocm/bin", tool) if os.path.exists(os.path.join("/opt/rocm/bin", tool)) else None)
+        if exe:
+            try:
+                return tool, subprocess.Popen([exe] + argv, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+            except OSError:
+                continue
+    return None
+
+
+def smi_sclk_finish(started, local):
+    """-> (MHz of GPU `local`'s shader clock as the SMI tool printed it, tool name) or (None, None)."""
+    import re
+    if started is None:
+        return None, None
+    tool, proc = started
+    try:
+        out, _ = proc.communicate(timeout=20)
+    except Exception:      # noqa: BLE001 -- a hung or missing tool only costs the field
+        proc.kill()
+        return None, None
+    vals = []
+    for ln in out.splitlines():
+        if re.search(r"sclk|GFX_\d+|gfx", ln, re.I):
+            m = re.search(r"(\d{3,4})\s*M[Hh]z", ln)
+            if m:
+                vals.append(float(m.group(1)))
+    vals = [v for v in vals if v >= 500.0]
+    if not vals:
+        return None, None
+    return (vals[min(local, len(vals) - 1)] if tool == "rocm-smi" else max(vals)), tool
 
 
 def mfma_peak_record():
@@ -305,6 +353,8 @@ def main():
                     "and the only one with --graph / --profile-kernels)")
     ap.add_argument("--overlap-encoder", action="store_true", help="model.overlap_encoder also with --streams > 1 (default: only with one stream)")
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds the step keeps running after the timed region for `sustained_ms_per_step` (0: off)")
+    ap.add_argument("--regime-utterances", type=int, default=0, help="one GPU: run the batch as a SHARD of a batch of this many utterances (its phoneme count scaled "
+                    "alike): the kernel variants of the larger batch on this one, what every rank of the sharded path does (fs2_batch.regime_*); measures the cost of that choice")
     ap.add_argument("--padded", action="store_true", help="N > 1: every rank also unpacks the gathered mels into the padded [B, Lcap, odim] tensor "
                                                            "(default: the packed form, gathered packs + offsets, no unpack launch)")
     args = ap.parse_args()
@@ -369,6 +419,12 @@ def main():
     # throughput mode: the all-gather of step i (side stream) overlaps the forward of step i + 1; FS2_DIST_SERIAL=1 keeps everything on one stream
     synth = ShardedSynthesizer(model, overlap=os.environ.get("FS2_DIST_SERIAL") != "1") if use_dist else None
 
+    regime = None
+    if args.regime_utterances:
+        if use_dist or args.graph or args.regime_utterances < B:
+            raise SystemExit("--regime-utterances N >= the batch's %d utterances serves the one-GPU eager path" % B)
+        regime = (int(round(float(il.sum()) * args.regime_utterances / B)), int(args.regime_utterances))
+
     graph_run = None
     # throughput mode: consecutive steps go to `n_streams` streams in turn, so that many whole steps are in flight and every kernel's tail round,
     # HBM burst and launch gap is filled by another step's workgroups (profiles/r05_ab_stream_schedules.txt).  Nothing in the library knows
@@ -407,7 +463,7 @@ def main():
         # nothing on the host waits for the GPU: the frame layout is built on the device (fs2_decode's device-driven
         # mode); the very first call is synchronous and teaches the capacity predictor the frames-per-phoneme ratio
         # (--profile-kernels uses the host-driven layout so that the per-site FLOP counts are those of the rows in use)
-        return model.inference_batch(xs, il, sync=args.profile_kernels)
+        return model.inference_batch(xs, il, sync=args.profile_kernels, regime=regime)
 
     def all_ok():
         if graph_run is not None:
@@ -472,6 +528,7 @@ def main():
             n_sus = max(args.steps, int(args.sustain / max(dt / args.steps, 1e-6)) + 1)
             read_clk = sclk_reader(local)
             clk = []
+            smi = None
             if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
@@ -482,6 +539,8 @@ def main():
                     v = read_clk()
                     if v:
                         clk.append(v)
+                if i == n_sus // 4 and rank == 0 and (not clk or statistics.median(clk) < 500.0):
+                    smi = smi_sclk_start()          # sysfs is absent or reads the node's clock: one SMI query while the queue is full
             if synth is not None:
                 synth.wait()
             torch.cuda.synchronize()
@@ -493,14 +552,21 @@ def main():
                 t = torch.tensor([dts], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dts = float(t.item())
-            sustained = dict(steps=n_sus, seconds=round(dts, 3), ms_per_step=round(1e3 * dts / n_sus, 3),
-                             sclk_mhz=(dict(min=min(clk), median=statistics.median(clk), max=max(clk), samples=len(clk),
-                                            source="amdgpu sysfs pp_dpm_sclk, sampled by the host while the queue is full (a reading far below 1 GHz at normal step times is the node's, not the chip's)") if clk else None))
+            smi_mhz, smi_tool = smi_sclk_finish(smi, local)
+            if clk and statistics.median(clk) >= 500.0:
+                sclk = dict(min=min(clk), median=statistics.median(clk), max=max(clk), samples=len(clk),
+                            source="amdgpu sysfs pp_dpm_sclk, sampled by the host while the queue is full")
+            elif smi_mhz is not None:
+                sclk = dict(median=smi_mhz, samples=1, source="%s, queried once while the queue was full (the sysfs node read %s MHz: the node's clock, not the chip's)"
+                                                              % (smi_tool, statistics.median(clk) if clk else None))
+            else:
+                sclk = None                          # no trustworthy reading on this box: null, not the node's 95 MHz
+            sustained = dict(steps=n_sus, seconds=round(dts, 3), ms_per_step=round(1e3 * dts / n_sus, 3), sclk_mhz=sclk)
         # ---- the same steps on ONE stream (not part of `value`): the A/B of the schedule, and the dominant kernel alone on the chip -- in the
         # timed region above its launches share the CUs with the other step's kernels, so their bracketed duration there is not the kernel's own
         alone = None
         if step_streams is not None:
-            n_al = max(4, min(args.steps, 10))
+            n_al = max(4, args.steps)               # the same K as the timed region (10 steps behind a 2-s burn were not comparable)
             one_stream[0] = True
             for _ in range(2):
                 step()
@@ -532,6 +598,12 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # which binary ran: the ISA-audit state of libfs2_hip.so and whether the hand-scheduled kernels were allowed to run (a library without a clean audit
+    # record of its own hash runs attn_bf16 / gemm_row8_bf16 instead -- slower, and until round 5 invisible in this line), and how many waves of attn_w32
+    # left the fast path since the handle was created (0 on this synthetic model's flat attention; a trained model's peaked rows would show here)
+    from fastspeech2_amd import _lib as _fs2lib
+    kernels = _fs2lib.kernel_state()
+    slow_waves = model.counter("attn_slow_path_waves")
     multi_gpu = None
     if use_dist and synth is not None and graph_run is None:
         with torch.no_grad():
@@ -711,10 +783,23 @@ def main():
             #  trustworthy the other way round: one run read 158 .. 202 MHz at unchanged step times.  Read it beside `one_stream` and `roofline`.)
             line["sustained"] = dict(sustained, ratio_to_timed=round(sustained["ms_per_step"] / (1e3 * dt / args.steps), 4),
                                      value=round(total_frames * 1e3 / sustained["ms_per_step"], 1))
+        line["kernels"] = kernels
+        line["attn_slow_path_waves"] = slow_waves
+        if regime is not None:
+            line["config"]["regime"] = dict(phonemes=regime[0], utterances=regime[1], note="kernel variants chosen as for a batch of this size (this batch run as its shard)")
+        elif use_dist:
+            line["config"]["regime"] = "the whole batch on every rank (sharded == unsharded bit for bit)" if synth.global_regime else "each shard's own"
         if alone is not None:
+            line["value_one_forward"] = round(total_frames * 1e3 / alone["ms_per_step"], 1)
+            line["ms_per_forward"] = alone["ms_per_step"]
+            line["value_note"] = ("value / ms_per_step: %d whole forwards in flight on %d streams (a throughput schedule; each step does all its work); value_one_forward / "
+                                  "ms_per_forward: the same K steps one after another on one stream -- SURVEY 8(d)'s 'wall time of one full forward', the figure of rounds 1-4"
+                                  % (n_streams, n_streams))
             line["one_stream"] = dict(steps=alone["steps"], ms_per_step=alone["ms_per_step"], value=round(total_frames * 1e3 / alone["ms_per_step"], 1),
                                       note="the same steps issued on one stream (rounds 1-4's schedule%s), measured behind the timed region"
                                            % (" + overlap_encoder" if model.overlap_encoder else ""))
+        elif not model.overlap_encoder:      # --streams 1 --no-overlap-encoder (or --graph / --profile-kernels): the timed schedule IS one forward after another
+            line["value_one_forward"], line["ms_per_forward"] = line["value"], line["ms_per_step"]
         if use_dist:
             line["config"]["gather"] = "padded" if (args.padded or args.profile_kernels) else "packed"
             line["config"]["collective_world_size"] = dist.get_world_size()

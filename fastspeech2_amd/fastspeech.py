@@ -913,8 +913,19 @@ def _profile_methods():
         n = L.fs2_get_profile(self._handle, names, ms, fl, by, cap)
         return [(names[i].decode(), float(ms[i]), float(fl[i]), float(by[i])) for i in range(n)]
 
+    def counter(self, name, reset=False):
+        """Cumulative event counter of this model's device handle (include/fs2.h: fs2_get_counter; waits for the current stream):
+        "attn_slow_path_waves" = waves of attn_w32 that left the fast path and were recomputed by the plain fp32 loop."""
+        if self._handle is None:
+            return 0
+        v = C.c_int64(0)
+        with torch.cuda.device(self._handle_device):
+            _lib.check(_lib.lib().fs2_get_counter(self._handle, _stream(self._handle_device), name.encode(), C.byref(v), int(bool(reset))), self._handle)
+        return int(v.value)
+
     FeedForwardTransformer.set_profiling = set_profiling
     FeedForwardTransformer.get_profile = get_profile
+    FeedForwardTransformer.counter = counter
 
 
 _profile_methods()

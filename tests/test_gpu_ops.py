@@ -14,6 +14,18 @@ def _dev():
     return torch.device("cuda:0")
 
 
+def test_the_library_under_test_is_the_audited_one_with_every_hand_scheduled_kernel_allowed():
+    """First GPU test of the suite: libfs2_hip.so found a clean ISA-audit record of its own hash, so attn_w32 /
+    gemm_row4_bf16 / the QKV passes on it are allowed to run.  Without it every parity test below would still pass -- on attn_bf16 /
+    gemm_row8_bf16 -- and every timing would be of other kernels; a benchmark line carries the same four flags (`kernels`)."""
+    _dev()
+    from fastspeech2_amd import _lib
+    st = _lib.kernel_state()
+    assert st == dict(audit_clean=True, attn_w32_active=True, row4_active=True, qkv4_active=True), st
+    rec = _lib.audit_record()
+    assert rec is not None and rec["clean"] and rec["violations"] == 0
+
+
 def _rand(rs, *shape, scale=1.0):
     return torch.from_numpy(rs.uniform(-scale, scale, size=shape).astype(np.float32))
 

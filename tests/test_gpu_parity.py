@@ -37,9 +37,26 @@ def _maxabs(a, b):
     return float((a.detach().cpu().float() - torch.as_tensor(b).float()).abs().max())
 
 
-def test_g1_teacher_forced_single(env, golden_dir):
+# the reference's own fixtures in every mode that ships (until round 5 they ran in the module default, fp32, only; the mode
+# bench.py runs reached the reference through the pinned oracle alone)
+SHIPPING_MODES = ("fp32", "bf16x3", "mix_mx")
+
+
+@pytest.fixture
+def in_mode(env):
+    model = env[0]
+
+    def set_(precision):
+        model.precision = precision
+    yield set_
+    model.precision = "fp32"
+
+
+@pytest.mark.parametrize("precision", SHIPPING_MODES)
+def test_g1_teacher_forced_single(env, golden_dir, in_mode, precision):
     model, sd, cfg, O = env
     g = np.load(golden_dir + "/g1_teacher_b1.npz")
+    in_mode(precision)
     with torch.no_grad():
         r = model._run(_t(g["xs"]), g["ilens"], g["olens"], _t(g["ds"]), _t(g["es"]), _t(g["ps"]), is_inference=False,
                        want=("before", "after", "e_outs", "p_outs", "qe", "qp", "lr_index", "encoder_out", "decoder_out"))
@@ -49,7 +66,7 @@ def test_g1_teacher_forced_single(env, golden_dir):
     d = {k: _maxabs(r[k], g[k]) for k in ("before", "after", "e_outs", "p_outs", "encoder_out")}
     d["d_outs"] = _maxabs(r["d_log"], g["d_outs"])
     d["decoder_rows"] = _maxabs(r["decoder_out"][0][torch.as_tensor(g["decoder_rows"])], g["decoder_out_rows"])
-    print("G1 max-abs:", {k: "%.2e" % v for k, v in d.items()})
+    print("G1 [%s] max-abs:" % precision, {k: "%.2e" % v for k, v in d.items()})
     assert max(d.values()) <= MEL_TOL, d
 
 
@@ -96,11 +113,13 @@ def test_g9_weighted_masking_losses_on_device(golden_dir):
             model(_t(g["xs"]), _t(g["ilens"]), _t(g["ys"]), _t(g["olens"]), _t(g["ds"]), _t(g["es"]), _t(g["ps"]))
 
 
-def test_g6_per_utterance_semantics_in_a_batch(env, golden_dir):
+@pytest.mark.parametrize("precision", SHIPPING_MODES)
+def test_g6_per_utterance_semantics_in_a_batch(env, golden_dir, in_mode, precision):
     """Default semantics: every utterance of a padded batch comes out as if it had been run alone."""
     model, sd, cfg, O = env
     g2 = np.load(golden_dir + "/g2_teacher_padded_b3.npz")
     g6 = np.load(golden_dir + "/g6_teacher_per_utt_b3.npz")
+    in_mode(precision)
     with torch.no_grad():
         before, after, *_ = model._forward(_t(g2["xs"]), _t(g2["ilens"]), _t(g2["olens"]), _t(g2["ds"]), _t(g2["es"]), _t(g2["ps"]))
     for b in range(3):
@@ -110,10 +129,14 @@ def test_g6_per_utterance_semantics_in_a_batch(env, golden_dir):
         assert float(after[b, L:].abs().max()) == 0.0 if L < after.shape[1] else True
 
 
-def test_g3_free_running_inference(env, golden_dir):
+@pytest.mark.parametrize("precision", SHIPPING_MODES)
+def test_g3_free_running_inference(env, golden_dir, in_mode, precision):
+    """The reference's `inference()` (fastspeech.py:339-357) on fixture G3, free-running in durations, pitch and energy: every integer decision
+    (24 durations; 102 + 102 bucket indices) equals the reference's in every shipping mode, the mel within the tolerance."""
     model, sd, cfg, O = env
     from fastspeech2_amd.synthetic import bias_durations
     g = np.load(golden_dir + "/g3_inference_t24.npz")
+    in_mode(precision)
     model.load_state_dict(bias_durations(sd, 4.0))
     try:
         with torch.no_grad():
@@ -125,8 +148,65 @@ def test_g3_free_running_inference(env, golden_dir):
     assert mel.shape == tuple(g["mel"].shape)
     assert oe.shape == (1, mel.shape[0], 256) and float(oe.sum()) == mel.shape[0]
     agree = float((oe.argmax(-1)[0].cpu() == torch.as_tensor(g["qe"][0])).float().mean())
-    print("G3 mel max-abs %.2e, energy-code agreement %.3f" % (_maxabs(mel, g["mel"]), agree))
+    print("G3 [%s] mel max-abs %.2e, energy-code agreement %.3f" % (precision, _maxabs(mel, g["mel"]), agree))
     assert _maxabs(mel, g["mel"]) <= MEL_TOL and _maxabs(after[0], g["mel"]) <= MEL_TOL
+
+
+PEAK_SCALE = 4.0      # factor on the decoder's Q and K projections (weights and biases): the attention logits grow 16-fold
+
+
+def test_peaked_decoder_attention_takes_the_slow_path_and_keeps_parity(env):
+    """attn_w32 runs the softmax relative to the FIRST key tile's maximum and sends a wave whose probabilities then sum beyond 2^60 to a plain fp32
+    two-pass loop (attn_w32_rows_slow).  Random-init weights give flat attention, so no benchmark or model-level test ever took that exit (VERDICT r05
+    item 6) while a trained model's peaked rows would.  Here the decoder's Q / K projections are scaled so that its attention IS peaked: the whole
+    forward (c2 batch, teacher-forced, mix_mx: decoder attention on attn_w32) must match the oracle on the same weights, the handle's counter
+    `attn_slow_path_waves` must have moved, and the per-call status word of a sync-free call must report the same exit (reference
+    core/attention.py:55-62: one softmax formula for every row)."""
+    from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
+    from fastspeech2_amd.synthetic import make_batch
+    from tests.conftest import record_measurement
+    _, sd, cfg, O = env
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    for k in sd2:
+        if k.startswith("decoder.encoders_.") and (".self_attn.linear_q." in k or ".self_attn.linear_k." in k):
+            sd2[k] = sd2[k] * PEAK_SCALE
+    hp = default_hparams()
+    model = FeedForwardTransformer(N_PHONEME_SYMBOLS, hp.audio.num_mels, hp).eval()
+    model.load_state_dict(sd2)
+    model = model.to("cuda:0")
+    model.precision = "mix_mx"
+    b = make_batch("c2")
+    with torch.no_grad():
+        r = model._run(b["xs"].cuda(), b["ilens"], b["olens"], b["ds"].cuda(), b["es"].cuda(), b["ps"].cuda(), is_inference=False, want=("after",))
+        slow = model.counter("attn_slow_path_waves", reset=True)
+        # the flat model of the other tests on the same batch: no wave leaves the fast path
+        flat = env[0]
+        flat.precision = "mix_mx"
+        try:
+            flat._run(b["xs"].cuda(), b["ilens"], b["olens"], b["ds"].cuda(), b["es"].cuda(), b["ps"].cuda(), is_inference=False, want=("after",))
+            slow_flat = flat.counter("attn_slow_path_waves", reset=True)
+        finally:
+            flat.precision = "fp32"
+        # sync-free call: the same count in this call's own status word
+        model.inference_batch(b["xs"].cuda(), b["ilens"], d_override=b["ds"].cuda())
+        model.counter("attn_slow_path_waves", reset=True)
+        res = model.inference_batch(b["xs"].cuda(), b["ilens"], d_override=b["ds"].cuda(), sync=False)
+        st = res.status.cpu()
+        assert res.ok()
+        slow_call = model.counter("attn_slow_path_waves")
+    o = O.per_utterance_forward(sd2, cfg, b["xs"], b["ilens"], b["ds"], b["es"], b["ps"])
+    worst = 0.0
+    for i in range(b["xs"].shape[0]):
+        L = int(b["olens"][i])
+        worst = max(worst, _maxabs(r["after"][i, :L], o["after"][i, :L]))
+    print("peaked decoder attention (Q, K x %.0f): %d wave(s) took attn_w32's slow path in one teacher-forced c2 forward (flat model: %d), %d in one sync-free "
+          "call (its status word: %d); mel max-abs vs the oracle %.2e" % (PEAK_SCALE, slow, slow_flat, slow_call, int(st[5]), worst))
+    record_measurement("c2_peaked_attention_mel_maxabs_mix_mx", worst)
+    record_measurement("c2_peaked_attention_slow_path_waves", slow)
+    assert slow > 0, "the scaled model's attention did not leave the fast path: raise PEAK_SCALE"
+    assert slow_flat == 0
+    assert int(st[5]) == slow_call > 0
+    assert worst <= MEL_TOL, worst
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])

@@ -57,8 +57,39 @@ def test_the_shipped_library_carries_a_clean_audit_record_of_its_own_binary():
     assert rec is not None, "no audit record for this binary: build it with __graft_entry__.build()"
     assert rec["clean"] and rec["violations"] == 0, rec
     kinds = [v["kind"] for v in rec["kernels"].values()]
-    assert kinds.count("attn_w32") >= 2 and kinds.count("gemm_row4_bf16") >= 8, kinds
+    assert {k: kinds.count(k) for k in _audit.EXPECTED_KERNELS} == _audit.EXPECTED_KERNELS, kinds      # every instantiation the launchers use was found AND audited
     assert all(v["asm_mfma"] > 0 for v in rec["kernels"].values())
+
+
+@pytest.mark.skipif(not os.path.exists(_lib.LIB_PATH), reason="libfs2_hip.so not built")
+def test_the_library_itself_gates_the_literal_register_kernels_on_its_audit_record(tmp_path):
+    """The gate lives in libfs2_hip.so (round-5 advisor finding: it used to live in the ctypes binding only, so libfs2_torch.so and C programs got
+    the kernels unaudited): the library hashes ITSELF when it is first used and looks for the record next to it.  The shipped binary reports a
+    clean audit and all three kernels allowed; a byte-identical copy WITHOUT the record, and one with a record of another hash, report 0 and
+    start with the kernels off.  (No GPU needed: fs2_get_option touches no device.)"""
+    import shutil
+    import subprocess
+    import sys
+    probe = ("import ctypes as C, sys; L = C.CDLL(sys.argv[1]); v = C.c_int32(-7); out = []\n"
+             "for n in (b'FS2_AUDIT_CLEAN', b'attn_w32_active', b'row4_active', b'qkv4_active'):\n"
+             "    assert L.fs2_get_option(n, C.byref(v)) == 0; out.append(v.value)\n"
+             "assert L.fs2_get_option(b'no_such_option', C.byref(v)) != 0\n"
+             "print(out)")
+    run = lambda so: subprocess.run([sys.executable, "-c", probe, so], capture_output=True, text=True, timeout=120)
+    r = run(_lib.LIB_PATH)
+    assert r.returncode == 0 and r.stdout.strip() == "[1, 1, 1, 1]", (r.stdout, r.stderr[-500:])
+    d1 = tmp_path / "bare"
+    d1.mkdir()
+    shutil.copy(_lib.LIB_PATH, d1 / "libfs2_hip.so")
+    r = run(str(d1 / "libfs2_hip.so"))
+    assert r.returncode == 0 and r.stdout.strip() == "[0, 0, 0, 0]" and "no clean ISA-audit record" in r.stderr, (r.stdout, r.stderr[-500:])
+    d2 = tmp_path / "stale"
+    d2.mkdir()
+    shutil.copy(_lib.LIB_PATH, d2 / "libfs2_hip.so")
+    rec = open(_lib.AUDIT_PATH).read().replace(_lib.audit_record()["so_sha16"], "0123456789abcdef")
+    (d2 / "libfs2_hip.audit.json").write_text(rec)
+    r = run(str(d2 / "libfs2_hip.so"))
+    assert r.returncode == 0 and r.stdout.strip() == "[0, 0, 0, 0]", (r.stdout, r.stderr[-500:])
 
 
 def test_a_valu_written_dma_base_too_close_is_found():
