@@ -134,7 +134,9 @@ __device__ __forceinline__ void mfma_o(const bf16x8_t& a_v, const bf16x8_t& b_v)
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }      // 16 states: an 8-pass MFMA result is readable
 
 // Ablations for tools/probes/attn_w32_probe.hip (timing only, results wrong): FS2_W32_ABL bit 6 (64): no V^T pieces; bit 7 (128): no K pieces; bit 4 (16): no closing vmcnt wait; bit 5 (32): no closing barrier; bit 0: no DMA pieces in the tile loop; bit 1: no
-// softmax work in the blocks; bit 2: no closing wait / barrier; bit 3: no fragment reads inside the blocks (the first ones are reused).
+// softmax work in the blocks; bit 2: no closing wait / barrier; bit 3: no fragment reads inside the blocks (the first ones are reused);
+// bit 8 (256): P.V at the MFMA count of an fp16 + e4m3 form: the V_lo . P_hi MFMAs are not issued -- 4 instead of 6 per group, what
+// one fp16 MFMA + two block-scaled 8-bit cross terms at half rate would cost the matrix pipe; an optimistic bound (that form also reads e4m3 planes).
 #ifndef FS2_W32_ABL
 #define FS2_W32_ABL 0
 #endif
@@ -541,9 +543,9 @@ __global__ __launch_bounds__(256, 1) void attn_w32(AttnB16Args a) {
             if constexpr (U == 0 && G + kFB < NG && !(FS2_W32_ABL & 8)) fetch(std::integral_constant<int, G + kFB>{});
             const bf16x8_t pf_h = __builtin_bit_cast(bf16x8_t, u32x4{phw[4 * M], phw[4 * M + 1], phw[4 * M + 2], phw[4 * M + 3]});
             const bf16x8_t pf_l = __builtin_bit_cast(bf16x8_t, u32x4{plw[4 * M], plw[4 * M + 1], plw[4 * M + 2], plw[4 * M + 3]});
-            if constexpr (U == 0) mfma_o<N0, true>(vl[BB][0], pf_h);          // (pads the VALU-written P fragment)
-            else if constexpr (U == 1) mfma_o<N0 + 1, false>(vl[BB][1], pf_h);
-            else if constexpr (U == 2) mfma_o<N0, false>(vh[BB][0], pf_l);
+            if constexpr (U == 0) { if constexpr (!(FS2_W32_ABL & 256)) mfma_o<N0, true>(vl[BB][0], pf_h); }          // (pads the VALU-written P fragment)
+            else if constexpr (U == 1) { if constexpr (!(FS2_W32_ABL & 256)) mfma_o<N0 + 1, false>(vl[BB][1], pf_h); }
+            else if constexpr (U == 2) mfma_o<N0, (FS2_W32_ABL & 256) != 0>(vh[BB][0], pf_l);
             else if constexpr (U == 3) mfma_o<N0 + 1, false>(vh[BB][1], pf_l);
             else if constexpr (U == 4) mfma_o<N0, false>(vh[BB][0], pf_h);
             else mfma_o<N0 + 1, false>(vh[BB][1], pf_h);

@@ -102,6 +102,10 @@ struct GemmArgs {
     int xp_row_chunks, k_groups, ln_groups, dot_gstride;
     int yp_col_off;                        // column offset of this launch's outputs inside the rows of Yp (a layer that fills one group of a stacked plane buffer)
     const int* Rp;                         // device-driven layout: rows actually used (tiles at or beyond round_up(*Rp, 128) exit at once); nullptr: R
+    // planes-only residual stream (gemm_row4.h: RES): the residual as the PLANES the producing launch wrote (residp_chunks 32-channel chunks per row;
+    // residp_mx != 0: mx planes, whose e4m3 residual words carry the scale 1 / residp_scale = 2^(ka+11)), instead of fp32 rows (resid must then be
+    // nullptr); a launch with Y == nullptr and Yp != nullptr writes planes only.  Only gemm_row4_bf16 implements both: launch_gemm refuses otherwise.
+    const void* residp; int residp_chunks; int residp_mx; float residp_scale;
 };
 
 __device__ __forceinline__ float wave16_sum(float v) {

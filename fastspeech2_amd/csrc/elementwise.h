@@ -215,7 +215,7 @@ __device__ __forceinline__ int scaled_duration(int64_t d, float alpha) {
     return f > 0.f ? (int)f : 0;
 }
 
-// ids != nullptr (fs2_encode): an utterance that holds a phoneme id outside [0, idim) gets the frame count -1 -- the reference's
+// ids != nullptr (fs2_encode): an utterance whose row of xs (all Tmax positions, pads included) holds a phoneme id outside [0, idim) gets the frame count -1 -- the reference's
 // torch.nn.Embedding raises for it (fastspeech.py:65-67, core/encoder.py:196); embed_pe reads row 0 instead of indexing out of range, and
 // the marker reaches the caller with the frame counts it reads anyway (host-driven layout) or as FS2_OVF_BAD_ID in the status word of
 // fs2_decode's device-driven layout (frame_layout_dev), whose outputs are then NaN-filled.
@@ -231,10 +231,11 @@ __global__ __launch_bounds__(256) void dur_scan(const int64_t* ds, int Tmax, con
     __syncthreads();
     // pass 1: total
     int tot = 0, bad = 0;
-    for (int t = tid; t < T; t += 256) {
-        tot += scaled_duration(d[t], alpha);
-        if (ids != nullptr) { const int64_t id = ids[(size_t)b * Tmax + t]; bad |= (id < 0 || id >= idim) ? 1 : 0; }
-    }
+    for (int t = tid; t < T; t += 256) tot += scaled_duration(d[t], alpha);
+    // (ALL Tmax positions of the row, pads included: the reference's nn.Embedding indexes the whole padded xs, so an id outside [0, idim) in the pad
+    //  region -- a -1 padding convention, say -- raises there too; round-5 advisor finding)
+    if (ids != nullptr)
+        for (int t = tid; t < Tmax; t += 256) { const int64_t id = ids[(size_t)b * Tmax + t]; bad |= (id < 0 || id >= idim) ? 1 : 0; }
     if (bad) bad_s = 1;
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
     if (lane == 0) wsum[wave] = tot;

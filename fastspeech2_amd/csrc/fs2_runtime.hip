@@ -444,31 +444,48 @@ inline int row4_mt(long rows) {
     const long r4 = ((rows + 127) / 128 + kCus - 1) / kCus * 128, r5 = ((rows + 159) / 160 + kCus - 1) / kCus * 160;
     return r5 <= r4 ? 5 : 4;
 }
-// the epilogues it has (gemm_row4.h: EPI); -1: none, the launch stays on gemm_row8_bf16
+// the epilogues it has (gemm_row4.h: EPI); -1: none, the launch stays on gemm_row8_bf16.  Since round 6 the kernel serves the PLANES-ONLY form of
+// these launches only (gemm_row4.h: RES): no fp32 rows out (Y == nullptr, Yp given), the residual -- where there is one -- as the producing launch's
+// planes (residp; resid == nullptr).  fs2_decode / run_stack build their arguments in that form exactly when planes_only_regime() says the
+// decoder's LayerNorm-fused launches will run here; a launch in the other form stays on gemm_row8_bf16.
 inline int row4_epi(const GemmArgs& a) {
-    if (a.ktaps != 1 || a.N != 384 || !a.ln_g || !a.Y || !a.Yp || a.relu_pre || a.dot_w || a.k_groups > 1 || a.ln_groups > 1 || a.qk_hi || a.yp_col_off) return -1;
+    if (a.ktaps != 1 || a.N != 384 || !a.ln_g || a.Y || !a.Yp || a.resid || a.relu_pre || a.dot_w || a.k_groups > 1 || a.ln_groups > 1 || a.qk_hi || a.yp_col_off) return -1;
     if (a.Cpad % 64 != 0 || a.yp_chunks * 32 != a.N) return -1;      // an even number of k-steps; planes exactly N wide
-    if (a.pe) return (a.act_post == 1 && a.yp_f16 == 0) ? 2 : -1;
-    if (a.act_post != 0) return -1;
-    return a.yp_f16 == 0 ? 0 : (a.yp_f16 == 2 ? 1 : -1);
+    if (a.residp && a.residp_chunks * 32 != a.N) return -1;
+    if (a.pe) return (a.act_post == 1 && a.yp_f16 == 0 && !a.residp) ? 2 : -1;
+    if (a.act_post != 0 || !a.residp) return -1;
+    if (a.yp_f16 == 2) return a.residp_mx ? -1 : 1;      // out-proj + LN1 of mix_mx: residual = split-bf16 planes of the block input, result = mx planes
+    return a.yp_f16 == 0 ? 0 : -1;
 }
-template <int MT, int EPI, int ARITH>
+template <int MT, int EPI, int ARITH, int RES>
 hipError_t launch_row4_t(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
     constexpr size_t lds = row4_lds_bytes<3, MT>();
-    allow_lds(reinterpret_cast<const void*>(&gemm_row4_bf16<3, 3, MT, EPI, 2, ARITH>), lds, attr);
-    hipLaunchKernelGGL((gemm_row4_bf16<3, 3, MT, EPI, 2, ARITH>), dim3((a.R + 32 * MT - 1) / (32 * MT)), dim3(256), lds, s, a);
+    allow_lds(reinterpret_cast<const void*>(&gemm_row4_bf16<3, 3, MT, EPI, 2, ARITH, RES>), lds, attr);
+    hipLaunchKernelGGL((gemm_row4_bf16<3, 3, MT, EPI, 2, ARITH, RES>), dim3((a.R + 32 * MT - 1) / (32 * MT)), dim3(256), lds, s, a);
     return hipGetLastError();
 }
-template <int EPI, int ARITH>
+template <int EPI, int ARITH, int RES>
 hipError_t launch_row4_e(hipStream_t s, const GemmArgs& a) {
     const int mt = (opts().mt4 == 4 || opts().mt4 == 5) ? opts().mt4 : row4_mt(rows_in_use(a, a.R));
-    return mt == 5 ? launch_row4_t<5, EPI, ARITH>(s, a) : launch_row4_t<4, EPI, ARITH>(s, a);
+    return mt == 5 ? launch_row4_t<5, EPI, ARITH, RES>(s, a) : launch_row4_t<4, EPI, ARITH, RES>(s, a);
 }
 // (the DMA-spreading schedule is fixed at SCHED = 2: same-box A/B in the model, c3: 0 -> 7.21, 2 -> 7.20, 4 -> 7.17 M frames/s; stand-alone 2 and 4 are 5-13 % ahead of 0)
+// The instantiations the library holds (fastspeech2_amd/_audit.py: EXPECTED_KERNELS counts them): EPI 0 x {split-bf16 arithmetic with the residual from
+// split-bf16 or from mx planes, mx arithmetic with the residual from mx planes}, EPI 1 (residual from split-bf16 planes), EPI 2 (no residual), each at two
+// tile heights, + the QKV passes (launch_qkv4_t).
 hipError_t launch_row4(hipStream_t s, const GemmArgs& a, int epi) {
-    if (a.mx) return launch_row4_e<0, 2>(s, a);
-    return epi == 0 ? launch_row4_e<0, 0>(s, a) : (epi == 1 ? launch_row4_e<1, 0>(s, a) : launch_row4_e<2, 0>(s, a));
+    if (epi == 2) return launch_row4_e<2, 0, 3>(s, a);
+    if (epi == 1) return launch_row4_e<1, 0, 1>(s, a);
+    if (a.mx) return a.residp_mx ? launch_row4_e<0, 2, 2>(s, a) : hipErrorInvalidValue;      // (FFN2 in the mx arithmetic exists in mix_mx only, where LN1's output is mx planes)
+    return a.residp_mx ? launch_row4_e<0, 0, 2>(s, a) : launch_row4_e<0, 0, 1>(s, a);
+}
+// Will the decoder's LayerNorm-fused k = 1 launches (out-proj + LN1, FFN2 + LN2, the input layer) run on gemm_row4_bf16 -- i.e. do its activations
+// travel as planes ONLY?  Same predicates as use_row8 / launch_gemm, asked once per fs2_decode so that every site of the stack agrees.
+inline bool planes_only_regime(const fs2_config& c, const Stack& st, int prec, long regime_rows) {
+    if (prec != FS2_PREC_BF16X3 || opts().row4 == 0 || c.ddim != 384 || st.pre_ln || st.concat || c.dunits % 64 != 0 || c.adim % 64 != 0) return false;
+    if (opts().row8 >= 0) return opts().row8 != 0;
+    return (regime_rows + 127) / 128 >= 128;
 }
 
 template <int NSPLIT, int NB, int MT, int GROUPS = 1>
@@ -644,6 +661,8 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         if (!a.Xp && !a.xp_scratch) return fail(h, FS2_ERR_STATE, "%s: no activation planes and no scratch to build them", name);
         if (a.ldy % 4 != 0 || (a.resid && a.ldr % 4 != 0)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: bf16 path needs row strides that are multiples of 4", name);
         const bool row8 = use_row8(a);
+        if ((a.residp || (need_rows && !a.Y && a.Yp && !a.dot_w && a.ktaps == 1 && !a.scratch)) && !(row8 && precision == FS2_PREC_BF16X3 && opts().row4 != 0 && row4_epi(a) >= 0))
+            return fail(h, FS2_ERR_STATE, "%s: a planes-only launch (residual as planes / no fp32 rows) exists on gemm_row4_bf16 only and this one would not run there", name);
         if (a.yp_col_off && !(row8 && a.ktaps > 1)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: a plane column offset exists in the row-complete conv kernel only", name);
         const bool y_needed = (need_rows && !row8) || (!a.Yp && !a.qk_hi && !(row8 && a.dot_w));      // (row-complete + scalar head: nothing but dot_out leaves)
         if (!t.Y && y_needed) { t.Y = a.scratch; t.ldy = a.N; }
@@ -981,9 +1000,11 @@ int run_stack_general(fs2_handle* h, hipStream_t s, const char* tag, const Stack
                       int mask_q, const StackBufs& b, int prec, bool x0p_ready, int regime_rows);
 
 // x0 holds the input; returns the buffer holding the output (x0 again).
+// po: the planes-only residual stream (gemm_row4.h: RES; fs2_decode decides with planes_only_regime): the LayerNorm-fused launches write no fp32
+// rows and take their residual from the planes of the producing launch -- x0 / x1 are then never written: the output is b.x0p.
 int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, int D, int heads, int R,
               const HostLayout& L, const DevLayout& dl, int mask_q, const StackBufs& b, int prec, bool x0p_ready = false, bool allow_splitk = false,
-              int regime_rows = 0, int ffn_terms = 0) {
+              int regime_rows = 0, int ffn_terms = 0, bool po = false) {
     if (st.pre_ln || st.concat) return run_stack_general(h, s, tag, st, D, heads, R, L, dl, mask_q, b, prec, x0p_ready, regime_rows);
     const int Dp = st.Dp;      // attention width (= D unless the head dim is padded)
     char nm[96];
@@ -1017,18 +1038,22 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         else rc = launch_attention_b16(h, s, nm, fused_split ? nullptr : b.qkv, pl ? nullptr : b.ctx, Dp, heads, R, L.Rpad, dl, L.nwork(), mask_q, att_flops, prec, b.qkh, b.qkl, b.vth, b.vtl, ctxp, st.dk);
         if (rc) return rc;
         snprintf(nm, sizeof nm, "%s.out_ln", tag);
-        a = gemm_args(ly.out, b.ctx, Dp, R, dl.row_pos, b.x1, D);
+        a = gemm_args(ly.out, b.ctx, Dp, R, dl.row_pos, po ? nullptr : b.x1, D);
         a.Rp = dl.dims; a.regime_rows = regime_rows;
-        a.resid = b.x0; a.ldr = D; a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
+        a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
+        if (po) { a.residp = b.x0p; a.residp_chunks = D / 32; }      // (x0p: split-bf16 planes, from the input layer or the previous block's FFN2 + LN2)
+        else { a.resid = b.x0; a.ldr = D; }
         const bool mxl = pl && ffn_terms == kFfnMx && ly.w1.wm;                                   // this layer's FFN conv in the mx arithmetic?
         const int f16t = (pl && ffn_terms && ffn_terms != kFfnMx && ly.w1.ktaps > 1 && ly.w1.wf) ? ffn_terms : 0;      // ... or on fp16 operands?
         if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; a.yp_f16 = mxl ? 2 : (f16t ? 1 : 0); a.yp_scale = mxl ? exp2f((float)ly.ka) : 1.f; }       // x1p feeds only that conv
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         // the second FFN GEMM: built first, because WHERE it will run decides the format the hidden layer leaves FFN1 in (mx planes for gemm_row4_bf16's
         // mx form, split-bf16 planes for everything else)
-        GemmArgs a2 = gemm_args(ly.w2, b.hid, ly.w1.N, R, dl.row_pos, b.x0, D);
+        GemmArgs a2 = gemm_args(ly.w2, b.hid, ly.w1.N, R, dl.row_pos, po ? nullptr : b.x0, D);
         a2.Rp = dl.dims; a2.regime_rows = regime_rows;
-        a2.resid = b.x1; a2.ldr = D; a2.ln_g = ly.ln2g; a2.ln_b = ly.ln2b; a2.ln_eps = 1e-5f;
+        a2.ln_g = ly.ln2g; a2.ln_b = ly.ln2b; a2.ln_eps = 1e-5f;
+        if (po) { a2.residp = b.x1p; a2.residp_chunks = D / 32; a2.residp_mx = mxl ? 1 : 0; a2.residp_scale = mxl ? exp2f(-(float)(ly.ka + 11)) : 1.f; }      // (x1p: LN1's output in the format the FFN conv wants)
+        else { a2.resid = b.x1; a2.ldr = D; }
         if (pl) { a2.Xp = hidp; a2.Yp = b.x0p; a2.yp_chunks = D / 32; }
         const bool mx2 = mxl && ly.w2.wm && opts().ffn2_mx && prec == FS2_PREC_BF16X3 && ffn2_on_row4_mx(h, a2);
         if (mx2) { a2.mx = 1; a2.Wb = ly.w2.wm; a2.mx_scale = scale_byte4(127 - ly.kh - 11); a2.mx_scale_b = scale_byte4(127 - ly.w2.kw); }
@@ -1944,8 +1969,12 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         HIP_TRY(h, hipGetLastError());
     }
     const bool dec_pl = prec != FS2_PREC_FP32;
+    // Planes-only residual stream (round 6): where the decoder's LayerNorm-fused launches run on gemm_row4_bf16 they write planes and nothing else and
+    // read their residual from planes (gemm_row4.h: RES) -- the fp32 rows x0 / x1 are not written at all (0.9 GB per c3 step, 11 GB per c4 step of HBM
+    // writes).  Not in the fp16 two- / one-term modes (their LN1 output is a fp16 hi + lo pair, a format the residual reader does not have).
+    const bool po = dec_pl && planes_only_regime(c, h->dec, prec, regime_rows) && (ffn_terms == 0 || ffn_terms == kFfnMx);
     if (c.decoder_input_layer) {   // decoder input layer: Linear -> LN -> ReLU -> + alpha * pe   (reference encoder.py:118-125)
-        GemmArgs a = gemm_args(h->dec_in, f.hfr, c.adim, R, dl.row_pos, f.sb.x0, c.ddim);
+        GemmArgs a = gemm_args(h->dec_in, f.hfr, c.adim, R, dl.row_pos, po ? nullptr : f.sb.x0, c.ddim);
         a.Rp = dl.dims; a.regime_rows = regime_rows;
         a.ln_g = h->dec_in_lng; a.ln_b = h->dec_in_lnb; a.ln_eps = 1e-5f; a.act_post = 1;
         a.pe = h->dec.pe; a.pe_ld = c.ddim; a.pe_alpha = h->dec.alpha; a.x_scale = c.use_scaled_pos_enc ? 1.f : sqrtf((float)c.ddim);
@@ -1964,7 +1993,13 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
         HIP_TRY(h, hipGetLastError());
     }
     const int mask_q = (b.compat_padded && io->masked) ? 1 : 0;
-    if ((rc = run_stack(h, s, "dec", h->dec, c.ddim, c.aheads, R, L, dl, mask_q, f.sb, prec, /*x0p_ready=*/dec_pl, /*allow_splitk=*/false, regime_rows, ffn_terms))) return rc;
+    if ((rc = run_stack(h, s, "dec", h->dec, c.ddim, c.aheads, R, L, dl, mask_q, f.sb, prec, /*x0p_ready=*/dec_pl, /*allow_splitk=*/false, regime_rows, ffn_terms, po))) return rc;
+    if (po && io->dec_out) {      // the API hands the decoder output out as fp32 rows: rebuilt from the planes (hi + lo) only when asked for
+        Scope sc(h, s, "dec.out.rows", 0.0, 8.0 * R * c.ddim);
+        const int64_t n = (int64_t)R * (c.ddim / 4);
+        hipLaunchKernelGGL(planes_to_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f.sb.x0p, c.ddim / 32, R, c.ddim, f.sb.x0, c.ddim);
+        HIP_TRY(h, hipGetLastError());
+    }
     // reduction_factor r (reference fastspeech.py:153,228-230): feat_out emits r mel frames per decoder frame; its [R, odim r] output
     // IS the [R r, odim] row image the Postnet runs on (decoder row i -> rows i r .. i r + r - 1, gap rows stay zero rows), so only the
     // row metadata is rebuilt at the finer rate.  r = 1 uses the decoder's own metadata and buffers.

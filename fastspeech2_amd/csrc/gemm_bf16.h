@@ -158,6 +158,10 @@ __device__ __forceinline__ f32x4 load4_or_zero(const float* p, bool ok) {
     const float* q = ok ? p : g_zero16;
     return *reinterpret_cast<const f32x4*>(q);
 }
+__device__ __forceinline__ uint2 load8_or_zero(const char* p, bool ok) {
+    const char* q = ok ? p : reinterpret_cast<const char*>(g_zero16);
+    return *reinterpret_cast<const uint2*>(q);
+}
 __device__ __forceinline__ int loadi_or_zero(const int* p, bool ok) {
     const int* q = ok ? p : reinterpret_cast<const int*>(g_zero16);
     return *q;

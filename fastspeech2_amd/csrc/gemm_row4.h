@@ -121,9 +121,17 @@ __device__ long long g_row_phase[8][8];
 // layer leaves FFN1's epilogue that way, with the static scale 2^kh of its a-priori bound), the weight image is the mx image of w_2: the first half of
 // the 128-byte units are 64 fp16 channels (two fp16 MFMAs per fragment pair), the second half 128 e4m3 channels (ONE block-scaled MFMA): 32 matrix-pipe
 // cycles per accumulator and unit instead of 48.  Same DMA pieces, ring, barriers and fragment reads; simulated first (tools/arith_sim_ffn2.py).
-template <int NSPLIT, int NB, int MT, int EPI = 0, int SCHED = 2, int ARITH = 0>
+// RES (round 6, VERDICT r05 item 2: these launches are HBM-bound and half their algorithmic bytes were a second copy of the residual stream): where the
+// residual comes from and what leaves.  0 = rounds 1-5: residual from fp32 rows (a.resid, or none), result as fp32 rows AND planes (kept for
+// tools/probes/row_probe.hip, which holds it against gemm_row8_bf16 bit for bit; the library no longer instantiates it for EPI 0-2).  1 / 2 / 3 =
+// PLANES ONLY: the result leaves as planes and nothing else (the next GEMM's A operand and the next LayerNorm-fused launch's residual are the same
+// bytes), and the residual is what the producing launch's planes hold -- 1: split-bf16 planes (hi + lo, exact in fp32: 16-17 significant bits of the
+// value the fp32 row held), 2: mx planes (fp16(x) + e4m3((x - fp16(x)) 2^(ka+11)) 2^-(ka+11): 12 of the row's 16 bytes per 4 channels are read,
+// ~15 significant bits), 3: no residual (the decoder input layer).  Simulated first: tools/arith_sim_residual.py (mel +1.9e-5 / +2.8e-5 at c2).
+template <int NSPLIT, int NB, int MT, int EPI = 0, int SCHED = 2, int ARITH = 0, int RES = 0>
 __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     static_assert(ARITH == 0 || (ARITH == 2 && NSPLIT == 3), "split-bf16 (0) or mx (2) operands");
+    static_assert(RES >= 0 && RES <= 3 && (EPI != 3 || RES == 0), "residual source / output form");
     constexpr int NT = 4 * NB, NP = NT / 2, BM = 32 * MT, BN = 128 * NB, RW = 16 * MT;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int PIECES = MT + 4 * NB;                       // one-KB LDS-DMA pieces per wave and stage: A pieces first (they come from HBM), then B
@@ -193,7 +201,14 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     for (int r = 0; r < 4; ++r) rp[r] = rperm(lg * 4 + r);
     // (residual rows of m-tile mt + 1 are requested before those of m-tile mt go into the accumulators: one exposed round trip, 24 NB registers)
     static_assert(MT * NT <= 64, "the accumulators are a[0 : 4 MT NT)");
+    // (planes as the residual: the raw words are held -- hi | lo of four channels (RES 1), fp16 x 4 | e4m3 x 4 (RES 2): no more registers than the
+    //  fp32 form -- and converted where they go into the accumulators, so that the loads of m-tile mt + 1 are still in flight behind those of m-tile mt)
     f32x4 rv[2][NB][4];
+    u32x4 rraw[2][NB][4];
+    const char* rpl = reinterpret_cast<const char*>(a.residp);
+    // RES 1: plane_byte(row, chunks, col0 + 64 g) = row chunks 128 + this lane's constant + 256 g;  RES 2: row 4 C + 2 (col0 + 64 g) [fp16] and + 2 C + col0 + 64 g [e4m3 residual]
+    const size_t rrow_bytes = (size_t)a.residp_chunks * 128;
+    const unsigned rlane = RES == 1 ? (unsigned)plane_byte(0, a.residp_chunks, col0) : (unsigned)(2 * col0);
     auto load_resid = [&](auto mt_tag) __attribute__((always_inline)) {
         constexpr int mt = decltype(mt_tag)::value;
 #pragma unroll
@@ -201,22 +216,51 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = rowb + mt * 16 + rp[r];
-                rv[mt & 1][g][r] = load4_or_zero(a.resid + (size_t)row * a.ldr + col0 + 64 * g, a.resid != nullptr && row < a.R);
+                if constexpr (RES == 0) {
+                    rv[mt & 1][g][r] = load4_or_zero(a.resid + (size_t)row * a.ldr + col0 + 64 * g, a.resid != nullptr && row < a.R);
+                } else if constexpr (RES == 1) {
+                    const char* q = rpl + (size_t)row * rrow_bytes + rlane + 256 * g;
+                    const uint2 hi = load8_or_zero(q, row < a.R), lo = load8_or_zero(q + 64, row < a.R);
+                    rraw[mt & 1][g][r] = u32x4{hi.x, hi.y, lo.x, lo.y};
+                } else if constexpr (RES == 2) {
+                    const char* q = rpl + (size_t)row * rrow_bytes;
+                    const uint2 hf = load8_or_zero(q + rlane + 128 * g, row < a.R);
+                    const unsigned e8 = (unsigned)loadi_or_zero(reinterpret_cast<const int*>(q + rrow_bytes / 2 + col0 + 64 * g), row < a.R);
+                    rraw[mt & 1][g][r] = u32x4{hf.x, hf.y, e8, 0u};
+                }
             }
+    };
+    const float rscale = a.residp_scale;
+    // the four channels of one raw residual word group as fp32 (exact: see RES above)
+    auto resid4 = [&](const u32x4& w) __attribute__((always_inline)) {
+        if constexpr (RES == 1) {
+            return f32x4{__uint_as_float(w[0] << 16) + __uint_as_float(w[2] << 16), __uint_as_float(w[0] & 0xffff0000u) + __uint_as_float(w[2] & 0xffff0000u),
+                         __uint_as_float(w[1] << 16) + __uint_as_float(w[3] << 16), __uint_as_float(w[1] & 0xffff0000u) + __uint_as_float(w[3] & 0xffff0000u)};
+        } else {
+            const uint2 hw = uint2{w[0], w[1]};
+            const f16x4_t hf = *reinterpret_cast<const f16x4_t*>(&hw);
+            return f32x4{(float)hf[0] + __builtin_amdgcn_cvt_f32_fp8((int)w[2], 0) * rscale, (float)hf[1] + __builtin_amdgcn_cvt_f32_fp8((int)w[2], 1) * rscale,
+                         (float)hf[2] + __builtin_amdgcn_cvt_f32_fp8((int)w[2], 2) * rscale, (float)hf[3] + __builtin_amdgcn_cvt_f32_fp8((int)w[2], 3) * rscale};
+        }
     };
     f32x4 bv[NB];
 #pragma unroll
     for (int g = 0; g < NB; ++g) bv[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + col0 + 64 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (EPI != 3) load_resid(I0{});
+    constexpr bool HAS_RES = EPI != 3 && RES != 3;
+    if constexpr (HAS_RES) load_resid(I0{});
     for_seq_i<0, MT>([&](auto mt_tag) __attribute__((always_inline)) {
         constexpr int mt = decltype(mt_tag)::value;
-        if constexpr (mt + 1 < MT && EPI != 3) load_resid(std::integral_constant<int, mt + 1>{});
+        if constexpr (mt + 1 < MT && HAS_RES) load_resid(std::integral_constant<int, mt + 1>{});
         __builtin_amdgcn_sched_barrier(0);
         for_seq_i<0, NB>([&](auto g_tag) __attribute__((always_inline)) {
             constexpr int g = decltype(g_tag)::value;
             f32x4 v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = EPI == 3 ? bv[g] : bv[g] + rv[mt & 1][g][r];
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (!HAS_RES) v[r] = bv[g];
+                else if constexpr (RES == 0) v[r] = bv[g] + rv[mt & 1][g][r];
+                else v[r] = bv[g] + resid4(rraw[mt & 1][g][r]);
+            }
             for_seq_i<0, 4>([&](auto j_tag) __attribute__((always_inline)) {      // tuple (mt, 4 g + j): register r = row r, channel col0 + 64 g + j
                 constexpr int j = decltype(j_tag)::value;
                 acc_set<mt * NT + 4 * g + j>(f32x4{v[0][j], v[1][j], v[2][j], v[3][j]});
@@ -521,7 +565,7 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
                     v[j] = live ? t : 0.f;
                 }
                 if (row < a.R) {
-                    *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
+                    if constexpr (RES == 0) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
                     if constexpr (EPI == 1) store_planes4_mx(Yp, row, a.yp_chunks, col, v, a.yp_scale);
                     else store_planes4(Yp, row, a.yp_chunks, col, v);
                 }

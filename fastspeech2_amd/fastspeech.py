@@ -273,7 +273,11 @@ class FeedForwardTransformer(nn.Module):
         see pad rows).  ``forward()`` (the loss path) always uses "padded_compat".
       * ``overlap_encoder`` (default False): throughput mode of the sync-free entry points -- each call's token-level half (encoder +
         duration predictor) runs on a side stream and overlaps the previous call's frame-level kernels; results are unchanged; the
-        caller prepares the ids of a call under ``input_stream(device)`` or guarantees they are complete.
+        caller prepares the ids of a call under ``input_stream(device)``, guarantees they are complete, or hands the call an event
+        recorded behind the work that produces them (``inference_batch(..., inputs_ready=event)``: the side stream waits for it).
+
+    Pickling / ``copy.deepcopy`` / ``torch.save(model)`` carry the parameters and the knobs above, never the per-process runtime state (the
+    library handle, side streams, pinned staging slots, calls in flight): the copy builds its own on first use.
     """
 
     def __init__(self, idim: int, odim: int, hp, _script_twin: bool = False):
@@ -363,6 +367,21 @@ class FeedForwardTransformer(nn.Module):
             self.encoder.embed[-1].alpha.data = torch.tensor(float(init_enc_alpha))
             self.decoder.embed[-1].alpha.data = torch.tensor(float(init_dec_alpha))
 
+    # per-process runtime state: never pickled / deep-copied (a ctypes handle, HIP streams and events, pinned host memory; round-5 advisor finding)
+    _RUNTIME_STATE = dict(_handle=None, _handle_device=None, _fingerprint=None, _weights_generation=0, _fp_refs=None, _fp_pes=None,
+                          last_async=None, last_olens=None)
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in list(self._RUNTIME_STATE) + ["_enc_streams", "_enc_gen_seen", "_pending", "_pin_ring", "_pin_next"]:
+            st.pop(k, None)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self.__dict__.update(self._RUNTIME_STATE)
+        self.__dict__.update(_enc_streams={}, _enc_gen_seen={}, _pending=[], _pin_ring=[], _pin_next=0)
+
     # ------------------------------------------------------------------ library handle / weights
     def __del__(self):
         try:
@@ -444,7 +463,7 @@ class FeedForwardTransformer(nn.Module):
 
     # ------------------------------------------------------------------ the path
     def _run(self, xs, ilens, olens=None, ds=None, es=None, ps=None, is_inference=False, compat=False,
-             want=("before", "after"), d_override=None, capacity=None, alpha=1.0, packed_out=None, regime=None):
+             want=("before", "after"), d_override=None, capacity=None, alpha=1.0, packed_out=None, regime=None, inputs_ready=None):
         """Runs fs2_encode -> (olens readback) -> fs2_decode.  Returns a dict of device tensors.
 
         ``capacity=(total_frames_bound, per_utterance_bound)`` selects the device-driven frame layout instead: no host
@@ -510,6 +529,8 @@ class FeedForwardTransformer(nn.Module):
                 if self._enc_gen_seen.get(side.cuda_stream) != self._weights_generation:      # the weights were (re-)uploaded on some stream since this side stream last looked
                     torch.cuda.synchronize(dev)
                     self._enc_gen_seen[side.cuda_stream] = self._weights_generation
+            if side is not None and inputs_ready is not None:
+                side.wait_event(inputs_ready)          # the caller's marker behind whatever produces xs / d_override (otherwise: its promise that they are complete)
             with torch.cuda.stream(side if side is not None else cur):
                 st_e = _stream(dev)
                 tok_ws = torch.empty(L.fs2_token_workspace_bytes(h, C.byref(batch)), dtype=torch.uint8, device=dev)
@@ -705,7 +726,8 @@ class FeedForwardTransformer(nn.Module):
         self._learn_ratio(il, r["olens"], alpha)
         return r["after"][0]
 
-    def inference_batch(self, xs, ilens, d_override=None, packed=False, sync=True, capacity=None, alpha=1.0, packed_out=None, regime=None):
+    def inference_batch(self, xs, ilens, d_override=None, packed=False, sync=True, capacity=None, alpha=1.0, packed_out=None, regime=None,
+                        inputs_ready=None):
         """Batched free-running synthesis (not in the reference, which only has single-utterance
         ``inference``): per-utterance semantics; returns (mels [B, Lmax, odim], olens [B] on the host = MEL frames per utterance,
         i.e. decoder frames x reduction_factor), or with
@@ -725,7 +747,11 @@ class FeedForwardTransformer(nn.Module):
 
         ``regime=(phonemes, utterances)``: this batch is a SHARD of a batch of that size -- choose the kernel variants (which differ in
         summation order, i.e. in the last bits) as the one-call run of the whole batch would, so that every utterance comes out bit-identical
-        to that run (what ``ShardedSynthesizer`` passes on every rank; include/fs2.h: fs2_batch.regime_tokens / regime_utterances)."""
+        to that run (what ``ShardedSynthesizer`` passes on every rank; include/fs2.h: fs2_batch.regime_tokens / regime_utterances).
+
+        ``inputs_ready`` (a ``torch.cuda.Event``; ``overlap_encoder`` mode only, ignored otherwise): recorded by the caller behind the work that
+        produces ``xs`` / ``d_override``; the encoder's side stream waits for it.  Without it the mode relies on the caller's promise that the
+        inputs are complete when the call is made (the side stream does not wait for the caller's stream: that wait is the overlap)."""
         il = torch.as_tensor(ilens).detach().to("cpu", torch.int64).reshape(-1)
         if not float(alpha) > 0.0:
             raise ValueError("alpha must be > 0 (reference length_regulator.py:57), got %r" % (alpha,))
@@ -738,7 +764,7 @@ class FeedForwardTransformer(nn.Module):
             total, Lcap = capacity if capacity is not None else self.predict_capacity(il, alpha)
             key = "after_packed" if packed else "after"         # (packed: the padded mels are neither built nor written)
             r = self._run(xs, il, is_inference=True, compat=False, want=(key,), d_override=d_override, capacity=(total, Lcap), alpha=alpha,
-                          packed_out=packed_out if packed else None, regime=regime)
+                          packed_out=packed_out if packed else None, regime=regime, inputs_ready=inputs_ready)
             mel_lens = r["olens"] if self.reduction_factor == 1 else r["olens"] * self.reduction_factor     # mel frames per utterance
             if torch.cuda.is_current_stream_capturing():     # graph capture: no host-side bookkeeping inside the graph
                 return AsyncMels(r[key], mel_lens, r["status"], None)

@@ -130,7 +130,8 @@ typedef struct fs2_encode_io {
     int64_t *d_int;           /* device [B, Tmax] clamp(round(exp(y)-1),0), pads = 0, or NULL    */
     int64_t *olens;           /* device [B] frames per utterance = sum of the durations used
                                  (an all-zero row counts as all ones, length_regulator.py:86-88);
-                                 -1 for an utterance that holds a phoneme id outside [0, idim): the
+                                 -1 for an utterance whose row of xs (all Tmax positions, the padding behind
+                                 ilens included) holds a phoneme id outside [0, idim): the
                                  reference's nn.Embedding raises there (fastspeech.py:65-67), a caller
                                  of the host-driven layout must too (fs2_decode refuses the value), the
                                  device-driven layout reports FS2_OVF_BAD_ID                     */

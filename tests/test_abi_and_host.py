@@ -260,3 +260,28 @@ def test_load_checkpoint_forms(tmp_path):
         load_checkpoint(model, dict(bare))
     extras = load_checkpoint(model, dict(bare), old_model=True)
     assert any("concat_linear" in k for k in extras["missing_keys"]) and not extras["unexpected_keys"]
+
+
+def test_module_pickles_and_deep_copies_without_its_runtime_state():
+    """`copy.deepcopy(model)` / `torch.save(model)` carry parameters and knobs, never the per-process runtime state (ctypes handle, HIP streams,
+    pinned staging slots, calls in flight: round-5 advisor finding -- a model that had run once in overlap_encoder mode could not be copied)."""
+    import copy
+    import ctypes as C
+    import io
+    from fastspeech2_amd import FeedForwardTransformer, default_hparams, N_PHONEME_SYMBOLS
+    m = FeedForwardTransformer(N_PHONEME_SYMBOLS, 80, default_hparams()).eval()
+    m.precision, m.overlap_encoder = "mix_mx", True
+    m.__dict__["_handle"] = None
+    m._enc_streams = {"key": C.c_void_p(5)}          # stand-ins for what a used model holds: none of them can be pickled
+    m._pin_ring = [[1, 2, C.c_void_p(3)]]
+    m._pending = [C.c_void_p(7)]
+    m2 = copy.deepcopy(m)
+    assert m2._enc_streams == {} and m2._pin_ring == [] and m2._pending == [] and m2._handle is None and m2._fingerprint is None
+    assert m2.precision == "mix_mx" and m2.overlap_encoder is True
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert list(m3.state_dict()) == list(m.state_dict())
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m3.state_dict().values()))
+    m._enc_streams, m._pin_ring, m._pending = {}, [], []

@@ -152,10 +152,15 @@ def test_g3_free_running_inference(env, golden_dir, in_mode, precision):
     assert _maxabs(mel, g["mel"]) <= MEL_TOL and _maxabs(after[0], g["mel"]) <= MEL_TOL
 
 
-PEAK_SCALE = 4.0      # factor on the decoder's Q and K projections (weights and biases): the attention logits grow 16-fold
+# Factor on the decoder's Q and K projections (weights and biases): the attention logits grow 49-fold.  Measured on MI355X, c2 teacher-forced
+# (slow-path waves of one forward / mel max-abs vs the oracle in mix_mx, bf16x3, fp32): x5: 0 / 6.9e-5, 6.3e-5, 1.3e-5; x6: 49 / 2.5e-4, 1.5e-4, 1.6e-5;
+# x7: 640 / 5.1e-4, 3.8e-4, 4.2e-5; x8: 1,584 / 9.2e-4, 9.3e-4, 9.9e-5; x16: 3,127 / 4.1e-2, 3.5e-2, 4.9e-3 -- beyond x8 the softmax is an argmax between
+# near-equal logits and even fp32 on the GPU leaves the fp32 CPU result.  The growth in the split-bf16 modes is the operands' (Q and K at 16-17
+# significant bits under logits of several hundred), not the slow path's: the 64-query kernel, which has none, lands on the same numbers.
+PEAK_SCALE = 7.0
 
 
-def test_peaked_decoder_attention_takes_the_slow_path_and_keeps_parity(env):
+def test_peaked_decoder_attention_takes_the_slow_path_and_keeps_parity(env, fs2_option):
     """attn_w32 runs the softmax relative to the FIRST key tile's maximum and sends a wave whose probabilities then sum beyond 2^60 to a plain fp32
     two-pass loop (attn_w32_rows_slow).  Random-init weights give flat attention, so no benchmark or model-level test ever took that exit (VERDICT r05
     item 6) while a trained model's peaked rows would.  Here the decoder's Q / K projections are scaled so that its attention IS peaked: the whole
@@ -179,6 +184,11 @@ def test_peaked_decoder_attention_takes_the_slow_path_and_keeps_parity(env):
     with torch.no_grad():
         r = model._run(b["xs"].cuda(), b["ilens"], b["olens"], b["ds"].cuda(), b["es"].cuda(), b["ps"].cuda(), is_inference=False, want=("after",))
         slow = model.counter("attn_slow_path_waves", reset=True)
+        # the same forward on the 64-query kernel (running maximum, no slow path): what separates the exit's arithmetic from the operands' precision
+        fs2_option("FS2_ATTN_W32", 0)
+        r64 = model._run(b["xs"].cuda(), b["ilens"], b["olens"], b["ds"].cuda(), b["es"].cuda(), b["ps"].cuda(), is_inference=False, want=("after",))
+        assert model.counter("attn_slow_path_waves", reset=True) == 0
+        fs2_option("FS2_ATTN_W32", -1)
         # the flat model of the other tests on the same batch: no wave leaves the fast path
         flat = env[0]
         flat.precision = "mix_mx"
@@ -195,14 +205,19 @@ def test_peaked_decoder_attention_takes_the_slow_path_and_keeps_parity(env):
         assert res.ok()
         slow_call = model.counter("attn_slow_path_waves")
     o = O.per_utterance_forward(sd2, cfg, b["xs"], b["ilens"], b["ds"], b["es"], b["ps"])
-    worst = 0.0
+    worst, worst64, between = 0.0, 0.0, 0.0
     for i in range(b["xs"].shape[0]):
         L = int(b["olens"][i])
         worst = max(worst, _maxabs(r["after"][i, :L], o["after"][i, :L]))
+        worst64 = max(worst64, _maxabs(r64["after"][i, :L], o["after"][i, :L]))
+        between = max(between, _maxabs(r["after"][i, :L], r64["after"][i, :L].cpu()))
     print("peaked decoder attention (Q, K x %.0f): %d wave(s) took attn_w32's slow path in one teacher-forced c2 forward (flat model: %d), %d in one sync-free "
-          "call (its status word: %d); mel max-abs vs the oracle %.2e" % (PEAK_SCALE, slow, slow_flat, slow_call, int(st[5]), worst))
+          "call (its status word: %d); mel max-abs vs the oracle %.2e (the 64-query kernel, which has no such exit: %.2e; the two kernels apart by %.2e)"
+          % (PEAK_SCALE, slow, slow_flat, slow_call, int(st[5]), worst, worst64, between))
     record_measurement("c2_peaked_attention_mel_maxabs_mix_mx", worst)
+    record_measurement("c2_peaked_attention_mel_maxabs_mix_mx_attn_bf16", worst64)
     record_measurement("c2_peaked_attention_slow_path_waves", slow)
+    assert worst64 <= MEL_TOL and between <= MEL_TOL, (worst64, between)
     assert slow > 0, "the scaled model's attention did not leave the fast path: raise PEAK_SCALE"
     assert slow_flat == 0
     assert int(st[5]) == slow_call > 0
@@ -286,13 +301,17 @@ def test_c2_row_complete_tile_heights_are_bit_identical(env, fs2_option):
         model.precision = "fp32"
 
 
-def test_c2_one_wave_per_simd_row_kernel_is_bit_identical_to_the_8_wave_one(env, fs2_option):
+def test_c2_one_wave_per_simd_row_kernel_against_the_8_wave_one(env, fs2_option):
     """gemm_row4_bf16 (one wave per SIMD, accumulators in literal AGPRs; the decoder's out-proj + LN1, FFN2 + LN2 and input layer) keeps
-    gemm_row8_bf16's operands, layouts and per-accumulator MFMA order: with the row-complete kernels forced at c2, the forward with FS2_ROW4 = 0 and
-    with FS2_ROW4 = 1 at both tile heights (FS2_MT4 = 4 | 5: 128 / 160 rows) must not differ in a single bit -- in split-bf16 and, with FFN2 kept
-    on split-bf16 (FS2_FFN2_MX = 0), in mix_mx (whose out-proj epilogue writes mx planes: EPI 1).  With FFN2 + LN2 in the mx arithmetic
-    (gemm_row4.h ARITH = 2, the default of mix_mx where that kernel runs) the result is another rounding of the same sums: within 5e-5 of the
-    split-bf16 FFN2, the same at both tile heights bit for bit, and within the mode's tolerance of the oracle."""
+    gemm_row8_bf16's operands, layouts and per-accumulator MFMA order, and since round 6 runs the PLANES-ONLY form of these launches: no fp32 rows
+    out, the residual read from the producing launch's planes (16-17 significant bits of the fp32 row, ~15 from mx planes).  With the row-complete
+    kernels forced at c2: the forward at both tile heights (FS2_MT4 = 4 | 5: 128 / 160 rows) must not differ in a single bit, and must stay within
+    1e-4 of the forward with FS2_ROW4 = 0 (gemm_row8_bf16: fp32 residual) -- in split-bf16 and, with FFN2 kept on split-bf16 (FS2_FFN2_MX = 0), in
+    mix_mx (out-proj epilogue writes mx planes: EPI 1; FFN2's residual comes out of them: RES 2).  Bit-identity of the kernel itself against
+    gemm_row8_bf16 on the same (reconstructed) residual is tools/probes/row_probe.hip's job (profiles/r06_row_probe.txt: 0 words differ in all
+    eight forms).  With FFN2 + LN2 in the mx arithmetic (gemm_row4.h ARITH = 2, the default of mix_mx where that kernel runs) the result is another
+    rounding of the same sums: within 5e-5 of the split-bf16 FFN2, the same at both tile heights bit for bit, and within the mode's tolerance of
+    the oracle.  (The variance adaptor runs in front of the decoder: the bucket decisions of the runs compared here are the same.)"""
     model, sd, cfg, O = env
     from fastspeech2_amd.synthetic import make_batch
     b = make_batch("c2")
@@ -309,7 +328,12 @@ def test_c2_one_wave_per_simd_row_kernel_is_bit_identical_to_the_8_wave_one(env,
                 fs2_option("FS2_MT4", mt)
                 with torch.no_grad():
                     outs[(row4, mt)] = run()
-            assert torch.equal(outs[(0, -1)], outs[(1, 4)]) and torch.equal(outs[(0, -1)], outs[(1, 5)]), precision
+            assert torch.equal(outs[(1, 4)], outs[(1, 5)]), precision
+            d8 = float((outs[(0, -1)] - outs[(1, 5)]).abs().max())
+            print("c2 [%s]: planes-only residual stream (gemm_row4_bf16) vs fp32 residual rows (gemm_row8_bf16): mel max-abs %.2e" % (precision, d8))
+            from tests.conftest import record_measurement
+            record_measurement("c2_planes_only_vs_fp32_residual_mel_maxabs_" + precision, d8)
+            assert 0.0 < d8 <= 1e-4, (precision, d8)
         fs2_option("FS2_FFN2_MX", 1)                                   # (mix_mx still selected)
         mx = {}
         for mt in (4, 5):
@@ -616,8 +640,9 @@ def test_errors(env):
 def test_out_of_range_phoneme_ids_raise(env, bad_id):
     """A phoneme id outside [0, idim): the reference's torch.nn.Embedding raises IndexError (fastspeech.py:65-67, core/encoder.py:196).  Here
     fs2_encode marks the utterance (frame count -1, include/fs2.h); the synchronous entry points raise `Fs2IndexError` (an IndexError) before
-    any mel is returned, an asynchronous call reports FS2_OVF_BAD_ID: NaN-filled mels, `check()` raises, `async_ok()` is False.  Ids in the
-    padding behind an utterance's `ilens` are never looked at."""
+    any mel is returned, an asynchronous call reports FS2_OVF_BAD_ID: NaN-filled mels, `check()` raises, `async_ok()` is False.  An id outside
+    the range in the PADDING behind an utterance's `ilens` raises as well (round 6; round-5 advisor finding): the reference's nn.Embedding indexes
+    the whole padded `xs`, so a -1 padding convention fails there too, and `dur_scan` now walks all Tmax positions of a row."""
     from fastspeech2_amd.fastspeech import Fs2IndexError, FS2_OVF_BAD_ID
     from fastspeech2_amd.synthetic import make_batch
     model = env[0]
@@ -633,8 +658,8 @@ def test_out_of_range_phoneme_ids_raise(env, bad_id):
     with torch.no_grad():
         ref, ol = model.inference_batch(b["xs"].cuda(), il)
         assert model.async_ok()
-        m2, ol2 = model.inference_batch(padded_only.cuda(), il)                 # out-of-range values in the padding: not an error, same result
-        assert torch.equal(ol2, ol) and torch.equal(m2, ref)
+        with pytest.raises(Fs2IndexError):
+            model.inference_batch(padded_only.cuda(), il)                        # out-of-range values in the padding: the reference's embedding raises for them too
         with pytest.raises(Fs2IndexError):
             model.inference_batch(bad.cuda(), il)
         with pytest.raises(IndexError):

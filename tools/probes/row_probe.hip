@@ -10,6 +10,7 @@
 #include <vector>
 #include "gemm_row4.h"
 #include "gemm_mx.h"
+#include "elementwise.h"
 using namespace fs2;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -50,6 +51,27 @@ static void launch_row4(const GemmArgs& a) {
     static bool done = false;
     if (!done) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_row4_bf16<3, 3, MT, EPI, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
     hipLaunchKernelGGL((gemm_row4_bf16<3, 3, MT, EPI, SCHED>), dim3((a.R + 32 * MT - 1) / (32 * MT)), dim3(256), lds, 0, a);
+}
+
+template <int MT, int EPI, int ARITH, int RES>
+static void launch_row4_po(const GemmArgs& a) {      // the planes-only forms the library runs since round 6 (gemm_row4.h: RES)
+    constexpr size_t lds = row4_lds_bytes<3, MT>();
+    static bool done = false;
+    if (!done) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_row4_bf16<3, 3, MT, EPI, 2, ARITH, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    hipLaunchKernelGGL((gemm_row4_bf16<3, 3, MT, EPI, 2, ARITH, RES>), dim3((a.R + 32 * MT - 1) / (32 * MT)), dim3(256), lds, 0, a);
+}
+// mx planes -> the fp32 value their reader reconstructs: fp16(x) + e4m3 residual x scale (gemm_row4.h: resid4)
+__global__ void mx_planes_to_rows(const void* planes, int C, int R, float scale, float* dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)R * C) return;
+    const int row = (int)(i / C), c = (int)(i % C);
+    const char* p = reinterpret_cast<const char*>(planes) + (size_t)row * 4 * C;
+    const _Float16 hf = *reinterpret_cast<const _Float16*>(p + 2 * c);
+    const int w = *reinterpret_cast<const int*>(p + 2 * C + (c & ~3));
+    float e;
+    switch (c & 3) { case 0: e = __builtin_amdgcn_cvt_f32_fp8(w, 0); break; case 1: e = __builtin_amdgcn_cvt_f32_fp8(w, 1); break;
+                     case 2: e = __builtin_amdgcn_cvt_f32_fp8(w, 2); break; default: e = __builtin_amdgcn_cvt_f32_fp8(w, 3); }
+    dst[i] = (float)hf + e * scale;
 }
 
 static size_t compare(const char* what, const void* d_ref, const void* d_got, size_t bytes, bool bf16_pairs = false) {
@@ -140,6 +162,71 @@ int main(int argc, char** argv) {
         if (epi == 2) { check("row4<128,s2>", [&](const GemmArgs& a) { launch_row4<4, 2, 2>(a); }); check("row4<160,s2>", [&](const GemmArgs& a) { launch_row4<5, 2, 2>(a); }); }
     }
     printf("bit-identity: %s\n", bad ? "FAILED" : "ok");
+    // ---- the planes-only forms (RES 1 / 2 / 3): residual read from split-bf16 / mx planes, no fp32 rows out.  hi + lo and fp16 + e4m3 x 2^-(ka+11) are
+    // exact in fp32, so gemm_row8_bf16 on the RECONSTRUCTED fp32 residual must give the same planes bit for bit.
+    {
+        void *rpb[2], *rpm[2]; float *rrb, *rrm;
+        const int kra = 3;      // static scale 2^ka of the mx residual planes (|x| < 1 here; the model's comes from the LayerNorm bound)
+        const int64_t nres = (int64_t)Rpad * (N / 4);
+        CK(hipMalloc(&rrb, hres.size() * 4)); CK(hipMalloc(&rrm, hres.size() * 4));
+        for (int sI = 0; sI < 2; ++sI) {
+            CK(hipMalloc(&rpb[sI], hres.size() * 4)); CK(hipMalloc(&rpm[sI], hres.size() * 4));
+            hipLaunchKernelGGL(to_planes, dim3((unsigned)((nres + 255) / 256)), dim3(256), 0, 0, res[sI], N, N, Rpad, N / 32, rpb[sI], 0, 1.f);
+            hipLaunchKernelGGL(to_planes, dim3((unsigned)((nres + 255) / 256)), dim3(256), 0, 0, res[sI], N, N, Rpad, N / 32, rpm[sI], 2, exp2f((float)kra));
+        }
+        hipLaunchKernelGGL(planes_to_rows, dim3((unsigned)((nres + 255) / 256)), dim3(256), 0, 0, rpb[0], N / 32, Rpad, N, rrb, N);
+        hipLaunchKernelGGL(mx_planes_to_rows, dim3((unsigned)(((int64_t)Rpad * N + 255) / 256)), dim3(256), 0, 0, rpm[0], N, Rpad, exp2f(-(float)(kra + 11)), rrm);
+        CK(hipDeviceSynchronize());
+        auto po_args = [&](int epi, int res_kind, int set, const Bufs& o) {
+            GemmArgs a = args(epi, set, o);
+            a.Y = nullptr; a.resid = nullptr;
+            if (res_kind == 1) { a.residp = rpb[set]; a.residp_chunks = N / 32; a.residp_mx = 0; a.residp_scale = 1.f; }
+            if (res_kind == 2) { a.residp = rpm[set]; a.residp_chunks = N / 32; a.residp_mx = 1; a.residp_scale = exp2f(-(float)(kra + 11)); }
+            return a;
+        };
+        size_t bad2 = 0;
+        auto check_po = [&](const char* nm, int epi, int res_kind, auto launch) {
+            GemmArgs r8 = args(epi, 0, ref);
+            if (res_kind) r8.resid = res_kind == 1 ? rrb : rrm;
+            CK(hipMemset(ref.yp, 0xff, ybytes)); CK(hipMemset(out[0].yp, 0xff, ybytes)); CK(hipMemset(out[0].y, 0xee, ybytes));
+            launch_row8<2>(r8);
+            launch(po_args(epi, res_kind, 0, out[0]));
+            CK(hipDeviceSynchronize());
+            printf("   %s vs row8<128 rows> on the reconstructed residual:\n", nm);
+            bad2 += compare("planes", ref.yp, out[0].yp, (size_t)R * N * 4);
+            std::vector<unsigned> probe(64);
+            CK(hipMemcpy(probe.data(), out[0].y, 256, hipMemcpyDeviceToHost));
+            for (unsigned w : probe) if (w != 0xeeeeeeeeu) { printf("    fp32 rows were written\n"); ++bad2; break; }
+        };
+        check_po("EPI 0, residual from split-bf16 planes, 128 rows", 0, 1, [&](const GemmArgs& a) { launch_row4_po<4, 0, 0, 1>(a); });
+        check_po("EPI 0, residual from split-bf16 planes, 160 rows", 0, 1, [&](const GemmArgs& a) { launch_row4_po<5, 0, 0, 1>(a); });
+        check_po("EPI 0, residual from mx planes, 160 rows", 0, 2, [&](const GemmArgs& a) { launch_row4_po<5, 0, 0, 2>(a); });
+        check_po("EPI 0, residual from mx planes, 128 rows", 0, 2, [&](const GemmArgs& a) { launch_row4_po<4, 0, 0, 2>(a); });
+        check_po("EPI 1 (mx planes out), residual from split-bf16 planes, 160 rows", 1, 1, [&](const GemmArgs& a) { launch_row4_po<5, 1, 0, 1>(a); });
+        check_po("EPI 1 (mx planes out), residual from split-bf16 planes, 128 rows", 1, 1, [&](const GemmArgs& a) { launch_row4_po<4, 1, 0, 1>(a); });
+        check_po("EPI 2 (input layer), no residual, 160 rows", 2, 0, [&](const GemmArgs& a) { launch_row4_po<5, 2, 0, 3>(a); });
+        check_po("EPI 2 (input layer), no residual, 128 rows", 2, 0, [&](const GemmArgs& a) { launch_row4_po<4, 2, 0, 3>(a); });
+        printf("planes-only forms: %s\n", bad2 ? "FAILED" : "ok");
+        bad += bad2;
+        for (int pass = 0; pass < 3; ++pass) {      // (interleaved with the rounds-1-5 forms, three times: the order of measurement matters by ~5 % on a warm chip)
+            auto Tp = [&](const char* nm, int epi, int res_kind, auto launch) {
+                const float us = time_kernel([&](int i) { launch(po_args(epi, res_kind, i & 1, out[i & 1])); }, reps);
+                printf("  planes-only  %-44s %8.1f us   %7.1f TFLOP/s\n", nm, us, flop / us * 1e-6);
+            };
+            Tp("EPI 0 resid bf16 planes row4<160>", 0, 1, [&](const GemmArgs& a) { launch_row4_po<5, 0, 0, 1>(a); });
+            Tp("EPI 0 resid mx planes   row4<160>", 0, 2, [&](const GemmArgs& a) { launch_row4_po<5, 0, 0, 2>(a); });
+            Tp("EPI 1 resid bf16 planes row4<160>", 1, 1, [&](const GemmArgs& a) { launch_row4_po<5, 1, 0, 1>(a); });
+            Tp("EPI 2 no residual       row4<160>", 2, 0, [&](const GemmArgs& a) { launch_row4_po<5, 2, 0, 3>(a); });
+            Tp("EPI 0 resid bf16 planes row4<128>", 0, 1, [&](const GemmArgs& a) { launch_row4_po<4, 0, 0, 1>(a); });
+            auto Tl = [&](const char* nm, int epi, auto launch) {
+                const float us = time_kernel([&](int i) { launch(args(epi, i & 1, out[i & 1])); }, reps);
+                printf("  rows+planes  %-44s %8.1f us   %7.1f TFLOP/s\n", nm, us, flop / us * 1e-6);
+            };
+            Tl("EPI 0 resid fp32 rows    row4<160>", 0, [&](const GemmArgs& a) { launch_row4<5, 0, 2>(a); });
+            Tl("EPI 1 resid fp32 rows    row4<160>", 1, [&](const GemmArgs& a) { launch_row4<5, 1, 2>(a); });
+            Tl("EPI 2 no residual        row4<160>", 2, [&](const GemmArgs& a) { launch_row4<5, 2, 2>(a); });
+        }
+    }
     // ---- timing (two operand / output sets in turn: 2 x (A planes + residual + rows + planes) exceed the MALL at the c3 shape)
     for (int epi = 0; epi < 3; ++epi) {
         auto T = [&](const char* nm, auto launch) {
