@@ -36,10 +36,11 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "mix_f16x2": 2500.0, "mix_f16x1": 2500.0, "mix_mx": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "mix_f16x2": 2500.0, "mix_f16x1": 2500.0, "mix_mx": 2500.0, "mix_mx4": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
 DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3", "bf16": "bf16", "mix_f16x2": "bf16x3 (FFN conv: f16x2)", "mix_f16x1": "bf16x3 (FFN conv: f16)",
-              "mix_mx": "bf16x3 (FFN conv: f16 x f16 + block-scaled e4m3 cross terms)"}
-MFMA_PER_PRODUCT = {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1, "mix_mx": 2.0}       # MFMAs issued per algorithmic product in the dominant kernel (the FFN conv)
+              "mix_mx": "bf16x3 (FFN conv: f16 x f16 + block-scaled e4m3 cross terms)",
+              "mix_mx4": "bf16x3 (FFN conv: f16 x f16 + block-scaled e4m3 cross terms; the decoder's: block-scaled e2m1 cross terms, one scale per frame / output channel)"}
+MFMA_PER_PRODUCT = {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1, "mix_mx": 2.0, "mix_mx4": 1.5}       # MFMAs issued per algorithmic product in the dominant kernel (the FFN conv)
 HBM_PEAK_GBPS = 8000.0
 WORKLOAD_TEXT = {
     "c1": "c1: 1 utterance, 80 phonemes",
@@ -671,7 +672,7 @@ def main():
             roofline["measured_mfma_peak"] = rec["random_operands_tflops"]
             roofline["measured_mfma_peak_all_ones"] = rec["all_ones_operands_tflops"]
             roofline["measured_mfma_peak_source"] = rec["source"]
-            roofline["issued_frac_of_measured_peak"] = round(achieved * {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1, "mix_mx": 2}.get(args.precision, 1)
+            roofline["issued_frac_of_measured_peak"] = round(achieved * {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1, "mix_mx": 2, "mix_mx4": 1.5}.get(args.precision, 1)
                                                              / rec["random_operands_tflops"], 4) \
                 if dom_name.endswith("ffn1") or args.precision == "bf16x3" else None
     # Algorithmic HBM bytes of one launch of the dominant kernel, from the launch's own shapes (valid rows of this rank): every operand read
@@ -683,7 +684,10 @@ def main():
     algo_bytes = None
     if dom_name in shapes:
         Cc, Nn, kk = shapes[dom_name]
-        algo_bytes = dict(a_planes_read=rows * Cc * eb, weight_image_read=Nn * kk * Cc * eb, result_written=rows * Nn * eb * (2 if dom_name.endswith("_ln") else 1))
+        # (mix_mx4, decoder FFN conv: 9 of the 12 units of a plane row are read -- fp16 + the fp4 cross units -- and the weight image has those 9 only: 3 bytes per element;
+        #  the LayerNorm-fused launches write planes only since round 6: 4 bytes per element, not 8)
+        ab = 3 if (args.precision == "mix_mx4" and dom_name == "dec.ffn1") else eb
+        algo_bytes = dict(a_planes_read=rows * Cc * ab, weight_image_read=Nn * kk * Cc * ab, result_written=rows * Nn * eb)
     elif dom_name in per_launch:
         Dd = c["ddim"] if dom_name.startswith("dec") else c["adim"]
         algo_bytes = dict(qkv_planes_read=rows * 3 * Dd * eb, context_planes_written=rows * Dd * eb)

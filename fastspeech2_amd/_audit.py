@@ -23,8 +23,8 @@ import re
 
 # What a clean record must hold (round-5 advisor finding: "clean" used to require one attn_w32 record only, so a symbol regex that stopped
 # matching would have let the row kernels through unaudited): the library instantiates attn_w32 for two head dims and gemm_row4_bf16 for
-# {MT 4, 5} x {EPI 0 in split-bf16 with the residual from split-bf16 / from mx planes, EPI 0 in the mx arithmetic, EPI 1, EPI 2, EPI 3 (the QKV passes)}.  fs2_runtime.hip: launch_attn_w32_t / launch_row4_t / launch_qkv4_t.
-EXPECTED_KERNELS = {"attn_w32": 2, "gemm_row4_bf16": 12}
+# {MT 4, 5} x {EPI 0 in split-bf16 with the residual from split-bf16 / from mx planes, EPI 0 in the mx arithmetic, EPI 1, EPI 2, EPI 3 (the QKV passes), EPI 4 (mx4 planes)}.  fs2_runtime.hip: launch_attn_w32_t / launch_row4_t / launch_qkv4_t.
+EXPECTED_KERNELS = {"attn_w32": 2, "gemm_row4_bf16": 14}
 
 _REG = re.compile(r'([va])\[(\d+):(\d+)\]|([va])(\d+)$')
 

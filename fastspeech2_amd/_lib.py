@@ -11,9 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfs2_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-FS2_PREC_FP32, FS2_PREC_BF16X3, FS2_PREC_BF16, FS2_PREC_MIX_F16X2, FS2_PREC_MIX_F16X1, FS2_PREC_MIX_MX = 0, 1, 2, 3, 4, 5
+FS2_PREC_FP32, FS2_PREC_BF16X3, FS2_PREC_BF16, FS2_PREC_MIX_F16X2, FS2_PREC_MIX_F16X1, FS2_PREC_MIX_MX, FS2_PREC_MIX_MX4 = 0, 1, 2, 3, 4, 5, 6
 PRECISIONS = {"fp32": FS2_PREC_FP32, "bf16x3": FS2_PREC_BF16X3, "bf16": FS2_PREC_BF16, "mix_f16x2": FS2_PREC_MIX_F16X2,
-              "mix_f16x1": FS2_PREC_MIX_F16X1, "mix_mx": FS2_PREC_MIX_MX}
+              "mix_f16x1": FS2_PREC_MIX_F16X1, "mix_mx": FS2_PREC_MIX_MX, "mix_mx4": FS2_PREC_MIX_MX4}
 
 
 class Fs2LibraryError(RuntimeError):

@@ -105,7 +105,10 @@ struct GemmArgs {
     // planes-only residual stream (gemm_row4.h: RES): the residual as the PLANES the producing launch wrote (residp_chunks 32-channel chunks per row;
     // residp_mx != 0: mx planes, whose e4m3 residual words carry the scale 1 / residp_scale = 2^(ka+11)), instead of fp32 rows (resid must then be
     // nullptr); a launch with Y == nullptr and Yp != nullptr writes planes only.  Only gemm_row4_bf16 implements both: launch_gemm refuses otherwise.
-    const void* residp; int residp_chunks; int residp_mx; float residp_scale;
+    const void* residp; int residp_chunks; int residp_mx; float residp_scale;      // residp_mx: 1 = mx planes (e4m3 residual at byte 2 C + c of the row), 2 = mx4 planes (at 3 C + c)
+    // mx4 (gemm_planes.h: ARITH = 3; yp_f16 == 3 / mx == 2): one E8M0 scale byte per ROW of the activation planes (2^-11 folded in) -- written by the
+    // producing LayerNorm epilogue (yp_rowscale), read by the conv (x_rowscale) -- and one per output channel of the weight image (w_rowscale)
+    unsigned char* yp_rowscale; const unsigned char* x_rowscale; const unsigned char* w_rowscale;
 };
 
 __device__ __forceinline__ float wave16_sum(float v) {
@@ -186,6 +189,45 @@ __device__ __forceinline__ void store_planes4_mx(void* planes, size_t row, int n
     *reinterpret_cast<uint2*>(p + 2 * c) = *reinterpret_cast<uint2*>(&h);
     *reinterpret_cast<unsigned*>(p + 2 * C + c) = pack_fp8x4(rs);
     *reinterpret_cast<unsigned*>(p + 3 * C + c) = pack_fp8x4(hs);
+}
+// E8M0 byte of the scale 2^e of a slice whose largest |fp16 value| is m: the OCP MX rule, e = floor(log2 m) - 2 (2 = e2m1's largest exponent), so that
+// m / 2^e lies in [4, 8): the values of the slice's top quarter-binade (6, 8) saturate at 6, in exchange for one more binade at the small end than a
+// scale that fits the maximum would leave (simulated both ways: tools/arith_sim_ffn_pareto.py, "variant" rows -- 9.7e-5 against 1.3e-4 on the mel).
+// Clamped to [40, 200]: a slice of zeros gets a harmless scale instead of 2^-127 (whose reciprocal would turn 0 into NaN).
+__host__ __device__ inline int mx4_scale_byte(float m) {
+    const unsigned u = __builtin_bit_cast(unsigned, m);
+    const int eb = (int)((u >> 23) & 0xff) - 2;
+    return eb < 40 ? 40 : (eb > 200 ? 200 : eb);
+}
+__host__ __device__ inline float mx4_inv_scale(int eb) { return __builtin_bit_cast(float, (unsigned)(254 - eb) << 23); }      // 2^(127 - eb) = 1 / 2^(eb - 127)
+
+// "mx4" planes (gemm_planes.h: ARITH = 3): [ fp16(a): C/64 units | cross units: per 4 channels c .. c + 3 the bytes (ra4 ra4 | ra4 ra4 | ah4 ah4 | ah4 ah4), e2m1 of
+// (a - fp16(a)) 2^11 / s_row and of fp16(a) / s_row, at byte 2 C + c of the row | ra8 = e4m3((a - fp16(a)) 2^(ka+11)) at byte 3 C + c: the residual reader's ].
+// inv_s = 1 / s_row (the row's own scale: the caller reduced the row maximum); sa = 2^ka (the static scale of the e4m3 residual, as in the mx planes).
+__device__ __forceinline__ void store_planes4_mx4(void* planes, size_t row, int nchunks, int c, const f32x4 v, float sa, float inv_s) {
+    f16x4_t h;
+    f32x4 rs;
+    float h4[4], r4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x = fminf(fmaxf(v[j], -65504.f), 65504.f);
+        const _Float16 hb = (_Float16)x;
+        h[j] = hb;
+        const float r = x - (float)hb;
+        rs[j] = r * (sa * 2048.f);
+        h4[j] = (float)hb * inv_s;
+        r4[j] = r * 2048.f * inv_s;
+    }
+    unsigned w = 0;
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, r4[0], r4[1], 1.f, 0);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, r4[2], r4[3], 1.f, 1);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, h4[0], h4[1], 1.f, 2);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, h4[2], h4[3], 1.f, 3);
+    const size_t C = (size_t)nchunks * 32;
+    char* p = reinterpret_cast<char*>(planes) + row * (4 * C);
+    *reinterpret_cast<uint2*>(p + 2 * c) = *reinterpret_cast<uint2*>(&h);
+    *reinterpret_cast<unsigned*>(p + 2 * C + c) = w;
+    *reinterpret_cast<unsigned*>(p + 3 * C + c) = pack_fp8x4(rs);
 }
 // planes of 4 consecutive channels in the format `mode`: 0 split-bf16, 1 split-fp16, 2 mx (scale = 2^ka)
 __device__ __forceinline__ void store_planes4m(void* planes, size_t row, int nchunks, int c, const f32x4 v, int mode, float scale);

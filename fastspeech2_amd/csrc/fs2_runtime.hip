@@ -42,6 +42,8 @@ struct Gemm {          // one repacked Linear / Conv1d
     void* wf = nullptr;      // the same image in fp16 (FFN w_1 only): operand of the two- / one-term arithmetic modes
     void* wm = nullptr;      // weight image of the "mx" mode (gemm_mx.h; FFN w_1 convolutions with C % 128 == 0 and N % 128 == 0) ...
     int kw = 0;              // ... and the exponent of its static scale: |w| 2^kw <= 448
+    void* wm4 = nullptr;     // weight image of the "mx4" mode (gemm_planes.h ARITH = 3: both cross terms in e2m1) ...
+    unsigned char* ws4 = nullptr;      // ... and its E8M0 scale bytes, one per output channel [Npad]
     float* bias = nullptr;   // [N] or null
     int N = 0, C = 0, Cpad = 0, ktaps = 1;
 };
@@ -214,9 +216,10 @@ inline int padded_head_dim(int dk) { return dk <= 64 ? 64 : (dk <= 128 ? 128 : (
 inline int att_width(int D, int heads) { return heads * padded_head_dim(D / heads); }
 
 // Mixed modes: everything as bf16x3 except the FFN convolution w_1, which runs on fp16 operands with 2 or 1 MFMA per fragment pair.
-inline int base_precision(int p) { return (p == FS2_PREC_MIX_F16X2 || p == FS2_PREC_MIX_F16X1 || p == FS2_PREC_MIX_MX) ? FS2_PREC_BF16X3 : p; }
+inline int base_precision(int p) { return (p == FS2_PREC_MIX_F16X2 || p == FS2_PREC_MIX_F16X1 || p == FS2_PREC_MIX_MX || p == FS2_PREC_MIX_MX4) ? FS2_PREC_BF16X3 : p; }
 constexpr int kFfnMx = 9;      // value of "ffn_terms" that selects the fp16 + block-scaled-fp8 arithmetic (gemm_mx.h)
-inline int ffn_f16_terms(int p) { return p == FS2_PREC_MIX_F16X2 ? 2 : (p == FS2_PREC_MIX_F16X1 ? 1 : (p == FS2_PREC_MIX_MX ? kFfnMx : 0)); }
+constexpr int kFfnMx4 = 10;    // ... the fp16 + block-scaled-fp4 arithmetic where the planes-only regime offers it (gemm_planes.h ARITH = 3), kFfnMx's elsewhere
+inline int ffn_f16_terms(int p) { return p == FS2_PREC_MIX_F16X2 ? 2 : (p == FS2_PREC_MIX_F16X1 ? 1 : (p == FS2_PREC_MIX_MX ? kFfnMx : (p == FS2_PREC_MIX_MX4 ? kFfnMx4 : 0))); }
 inline int scale_byte4(int e) { const int b = std::min(std::max(e, 1), 254); return b * 0x01010101; }
 
 // max over the rows n of a [N][K] weight of (sum_k |w[n][k]|) xmax + |b[n]|: the a-priori bound of relu(w x + b) for |x| <= xmax (weight-load time only)
@@ -455,6 +458,7 @@ inline int row4_epi(const GemmArgs& a) {
     if (a.pe) return (a.act_post == 1 && a.yp_f16 == 0 && !a.residp) ? 2 : -1;
     if (a.act_post != 0 || !a.residp) return -1;
     if (a.yp_f16 == 2) return a.residp_mx ? -1 : 1;      // out-proj + LN1 of mix_mx: residual = split-bf16 planes of the block input, result = mx planes
+    if (a.yp_f16 == 3) return (a.residp_mx || !a.yp_rowscale) ? -1 : 4;      // ... of mix_mx4: result = mx4 planes + one scale byte per row
     return a.yp_f16 == 0 ? 0 : -1;
 }
 template <int MT, int EPI, int ARITH, int RES>
@@ -472,11 +476,12 @@ hipError_t launch_row4_e(hipStream_t s, const GemmArgs& a) {
 }
 // (the DMA-spreading schedule is fixed at SCHED = 2: same-box A/B in the model, c3: 0 -> 7.21, 2 -> 7.20, 4 -> 7.17 M frames/s; stand-alone 2 and 4 are 5-13 % ahead of 0)
 // The instantiations the library holds (fastspeech2_amd/_audit.py: EXPECTED_KERNELS counts them): EPI 0 x {split-bf16 arithmetic with the residual from
-// split-bf16 or from mx planes, mx arithmetic with the residual from mx planes}, EPI 1 (residual from split-bf16 planes), EPI 2 (no residual), each at two
-// tile heights, + the QKV passes (launch_qkv4_t).
+// split-bf16 or from mx planes, mx arithmetic with the residual from mx planes}, EPI 1 and EPI 4 (residual from split-bf16 planes), EPI 2 (no residual),
+// each at two tile heights, + the QKV passes (launch_qkv4_t).
 hipError_t launch_row4(hipStream_t s, const GemmArgs& a, int epi) {
     if (epi == 2) return launch_row4_e<2, 0, 3>(s, a);
     if (epi == 1) return launch_row4_e<1, 0, 1>(s, a);
+    if (epi == 4) return launch_row4_e<4, 0, 1>(s, a);
     if (a.mx) return a.residp_mx ? launch_row4_e<0, 2, 2>(s, a) : hipErrorInvalidValue;      // (FFN2 in the mx arithmetic exists in mix_mx only, where LN1's output is mx planes)
     return a.residp_mx ? launch_row4_e<0, 0, 2>(s, a) : launch_row4_e<0, 0, 1>(s, a);
 }
@@ -628,6 +633,18 @@ hipError_t launch_mx(hipStream_t s, const GemmArgs& a) {
     return bm == 128 ? launch_pl_t<1, 128, false, 2>(s, a) : launch_pl_t<1, 64, false, 2>(s, a);
 }
 
+// fp16 + block-scaled-fp4 form of the conv (gemm_planes.h ARITH = 3): 256-row tiles only -- it runs where the planes-only regime holds (>= 16 k rows: the
+// tile-height rule above picks 256 there for every N >= 1024), + 512 bytes of LDS for the A tile's row-scale bytes
+hipError_t launch_mx4(hipStream_t s, const GemmArgs& a) {
+    static LdsAttr attr;
+    constexpr size_t lds = pl_lds_bytes<256, false>() + 512;
+    static_assert(pl_arows<256, false>() <= 512, "one scale byte per A-tile row");
+    allow_lds(reinterpret_cast<const void*>(&gemm_pl_bf16<1, 256, false, 3>), lds, attr);
+    dim3 grid((a.N + kB16BN - 1) / kB16BN, (a.R + 255) / 256, 1);
+    hipLaunchKernelGGL((gemm_pl_bf16<1, 256, false, 3>), grid, dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
 // fp16-operand form of the conv kernel (FFN w_1 in the mixed modes): NSPLIT MFMAs per fragment pair
 template <int NSPLIT>
 hipError_t launch_pl_f16(hipStream_t s, const GemmArgs& a) {
@@ -696,6 +713,7 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         const bool mx_row4 = a.mx && a.ktaps == 1 && precision == FS2_PREC_BF16X3 && ffn2_on_row4_mx(h, a);      // FFN2 + LN2 in the mx arithmetic (gemm_row4.h)
         if ((a.f16_terms || a.mx) && !mx_row4 && (a.ktaps == 1 || need_rows || a.qk_hi)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: the fp16 arithmetic exists for plain convolutions only", name);
         if (a.mx && !mx_row4 && (a.ktaps < 3 || a.C % 128 != 0 || a.N % 128 != 0)) return fail(h, FS2_ERR_UNSUPPORTED, "%s: the mx arithmetic needs a convolution with C %% 128 == 0 and N %% 128 == 0", name);
+        if (a.mx == 2 && (!a.x_rowscale || !a.w_rowscale || !a.Xp || t.ksplit > 1)) return fail(h, FS2_ERR_STATE, "%s: the mx4 arithmetic needs mx4 planes with their row scales and the weight image's channel scales", name);
 
         if (!a.Xp) {
             char nm[112];
@@ -710,6 +728,8 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
             if (mx_row4) {
                 t.W = reinterpret_cast<const float*>(a.Wb);
                 e = launch_row4(s, t, 0);
+            } else if (a.mx == 2) {
+                e = launch_mx4(s, t);
             } else if (a.mx) {
                 e = launch_mx(s, t);
             } else if (a.f16_terms) {
@@ -994,7 +1014,7 @@ int device_layout(fs2_handle* h, hipStream_t s, const HostLayout& L, int* dev, D
 // ------------------------------------------------------------------ FFT block stack
 // x0p / x1p: split-bf16 planes of x0 / x1 (gemm_planes.h); xps: planes scratch for activations produced without planes.
 // In the bf16 modes the attention context and the FFN hidden layer exist ONLY as planes, in the ctx / hid storage.
-struct StackBufs { float *x0, *x1, *qkv, *ctx, *hid; __bf16 *qkh, *qkl, *vth, *vtl; void *x0p, *x1p, *xps; };
+struct StackBufs { float *x0, *x1, *qkv, *ctx, *hid; __bf16 *qkh, *qkl, *vth, *vtl; void *x0p, *x1p, *xps; unsigned char* xs4 = nullptr; };      // xs4: row-scale bytes of x1p in the mx4 format
 
 int run_stack_general(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, int D, int heads, int R, const HostLayout& L, const DevLayout& dl,
                       int mask_q, const StackBufs& b, int prec, bool x0p_ready, int regime_rows);
@@ -1043,16 +1063,18 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
         if (po) { a.residp = b.x0p; a.residp_chunks = D / 32; }      // (x0p: split-bf16 planes, from the input layer or the previous block's FFN2 + LN2)
         else { a.resid = b.x0; a.ldr = D; }
-        const bool mxl = pl && ffn_terms == kFfnMx && ly.w1.wm;                                   // this layer's FFN conv in the mx arithmetic?
-        const int f16t = (pl && ffn_terms && ffn_terms != kFfnMx && ly.w1.ktaps > 1 && ly.w1.wf) ? ffn_terms : 0;      // ... or on fp16 operands?
-        if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; a.yp_f16 = mxl ? 2 : (f16t ? 1 : 0); a.yp_scale = mxl ? exp2f((float)ly.ka) : 1.f; }       // x1p feeds only that conv
+        const bool mx4l = po && ffn_terms == kFfnMx4 && ly.w1.wm4 && b.xs4;                       // this layer's FFN conv in the mx4 arithmetic (fp4 cross terms; planes-only regime)?
+        const bool mxl = pl && (ffn_terms == kFfnMx || ffn_terms == kFfnMx4) && ly.w1.wm;         // ... in the mx arithmetic (also the fallback of mix_mx4 wherever mx4 does not apply)?
+        const int f16t = (pl && ffn_terms && ffn_terms != kFfnMx && ffn_terms != kFfnMx4 && ly.w1.ktaps > 1 && ly.w1.wf) ? ffn_terms : 0;      // ... or on fp16 operands?
+        if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; a.yp_f16 = mx4l ? 3 : (mxl ? 2 : (f16t ? 1 : 0)); a.yp_scale = mxl ? exp2f((float)ly.ka) : 1.f; }       // x1p feeds only that conv
+        if (mx4l) a.yp_rowscale = b.xs4;
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         // the second FFN GEMM: built first, because WHERE it will run decides the format the hidden layer leaves FFN1 in (mx planes for gemm_row4_bf16's
         // mx form, split-bf16 planes for everything else)
         GemmArgs a2 = gemm_args(ly.w2, b.hid, ly.w1.N, R, dl.row_pos, po ? nullptr : b.x0, D);
         a2.Rp = dl.dims; a2.regime_rows = regime_rows;
         a2.ln_g = ly.ln2g; a2.ln_b = ly.ln2b; a2.ln_eps = 1e-5f;
-        if (po) { a2.residp = b.x1p; a2.residp_chunks = D / 32; a2.residp_mx = mxl ? 1 : 0; a2.residp_scale = mxl ? exp2f(-(float)(ly.ka + 11)) : 1.f; }      // (x1p: LN1's output in the format the FFN conv wants)
+        if (po) { a2.residp = b.x1p; a2.residp_chunks = D / 32; a2.residp_mx = mx4l ? 2 : (mxl ? 1 : 0); a2.residp_scale = mxl ? exp2f(-(float)(ly.ka + 11)) : 1.f; }      // (x1p: LN1's output in the format the FFN conv wants)
         else { a2.resid = b.x1; a2.ldr = D; }
         if (pl) { a2.Xp = hidp; a2.Yp = b.x0p; a2.yp_chunks = D / 32; }
         const bool mx2 = mxl && ly.w2.wm && opts().ffn2_mx && prec == FS2_PREC_BF16X3 && ffn2_on_row4_mx(h, a2);
@@ -1064,7 +1086,8 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         if (pl) { a.Xp = b.x1p; a.Yp = hidp; a.yp_chunks = round_up(ly.w1.N, 32) / 32; }
         if (mx2) { a.yp_f16 = 2; a.yp_scale = exp2f((float)ly.kh); }
         if (f16t) { a.f16_terms = f16t; a.Wb = ly.w1.wf; }
-        if (mxl) { a.mx = 1; a.Wb = ly.w1.wm; a.mx_scale = scale_byte4(127 - ly.ka - 11); a.mx_scale_b = scale_byte4(127 - ly.w1.kw); }
+        if (mx4l) { a.mx = 2; a.Wb = ly.w1.wm4; a.x_rowscale = b.xs4; a.w_rowscale = ly.w1.ws4; }
+        else if (mxl) { a.mx = 1; a.Wb = ly.w1.wm; a.mx_scale = scale_byte4(127 - ly.ka - 11); a.mx_scale_b = scale_byte4(127 - ly.w1.kw); }
         if ((rc = launch_gemm(h, s, nm, a, prec))) return rc;
         snprintf(nm, sizeof nm, "%s.ffn2_ln", tag);
         if ((rc = launch_gemm(h, s, nm, a2, prec))) return rc;
@@ -1361,6 +1384,16 @@ struct Loader {
             g.wm = pm;
             hipLaunchKernelGGL(repack_weight_mx, dim3((unsigned)((bytes / 2 + 255) / 256)), dim3(256), 0, s, (const float*)d->data, g.N, C, k, Npad, g.kw,
                                reinterpret_cast<unsigned short*>(pm));
+            if (k > 1) {      // the mx4 image of the same convolution (fp4 cross terms, one scale byte per output channel)
+                const size_t b4 = mx4_image_bytes(Npad, C, k);
+                void *p4 = nullptr, *ps = nullptr;
+                if (hipMalloc(&p4, b4) != hipSuccess || hipMalloc(&ps, (size_t)Npad + 16) != hipSuccess) { if (!rc) rc = fail(h, FS2_ERR_HIP, "hipMalloc of the mx4 weight image failed"); return g; }
+                h->allocs.push_back(p4); h->allocs.push_back(ps);
+                g.wm4 = p4; g.ws4 = reinterpret_cast<unsigned char*>(ps);
+                hipLaunchKernelGGL(weight_rowscale_mx4, dim3(Npad), dim3(256), 0, s, (const float*)d->data, g.N, C * k, Npad, g.ws4);
+                hipLaunchKernelGGL(repack_weight_mx4, dim3((unsigned)((b4 / 4 + 255) / 256)), dim3(256), 0, s, (const float*)d->data, g.N, C, k, Npad, g.ws4,
+                                   reinterpret_cast<unsigned*>(p4));
+            }
         }
         if (f16_image) {
             void* pf = nullptr;
@@ -1485,7 +1518,7 @@ int check_batch(fs2_handle* h, const fs2_batch& b) {
     if (b.B <= 0 || b.Tmax <= 0 || !b.ilens) return fail(h, FS2_ERR_ARG, "batch: B=%d Tmax=%d ilens=%p", b.B, b.Tmax, (const void*)b.ilens);
     for (int i = 0; i < b.B; ++i)
         if (b.ilens[i] <= 0 || b.ilens[i] > b.Tmax) return fail(h, FS2_ERR_ARG, "ilens[%d]=%lld outside [1,%d]", i, (long long)b.ilens[i], b.Tmax);
-    if (b.precision < FS2_PREC_FP32 || b.precision > FS2_PREC_MIX_MX) return fail(h, FS2_ERR_ARG, "unknown precision mode %d", b.precision);
+    if (b.precision < FS2_PREC_FP32 || b.precision > FS2_PREC_MIX_MX4) return fail(h, FS2_ERR_ARG, "unknown precision mode %d", b.precision);
     if (b.regime_tokens < 0 || b.regime_utterances < 0 || (b.regime_tokens > 0) != (b.regime_utterances > 0))
         return fail(h, FS2_ERR_ARG, "batch: regime_tokens=%lld / regime_utterances=%d must be given together (0 / 0 = this call's own batch)", (long long)b.regime_tokens, b.regime_utterances);
     return FS2_OK;
@@ -1595,6 +1628,7 @@ size_t carve_frames(const fs2_config& c, const HostLayout& L, void* ws, size_t c
     f.sb.x0p = bp.take<float>(R * (size_t)round_up(std::max(c.ddim, c.postnet_chans), 32));
     f.sb.x1p = bp.take<float>(R * (size_t)round_up(std::max(std::max(c.adim, c.ddim), c.postnet_chans), 32));    // also holds the length-regulator output's planes
     f.sb.xps = bp.take<float>(R * (size_t)round_up(std::max(std::max(c.adim, c.ddim), std::max(std::max(c.var_chans, c.postnet_chans), c.odim)), 32));
+    f.sb.xs4 = bp.take<unsigned char>(R + 16);
     const size_t rf = (size_t)std::max(c.reduction_factor, 1);
     f.before = bp.take<float>(R * rf * c.odim);
     f.after = bp.take<float>(R * rf * c.odim);
@@ -1972,7 +2006,7 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
     // Planes-only residual stream (round 6): where the decoder's LayerNorm-fused launches run on gemm_row4_bf16 they write planes and nothing else and
     // read their residual from planes (gemm_row4.h: RES) -- the fp32 rows x0 / x1 are not written at all (0.9 GB per c3 step, 11 GB per c4 step of HBM
     // writes).  Not in the fp16 two- / one-term modes (their LN1 output is a fp16 hi + lo pair, a format the residual reader does not have).
-    const bool po = dec_pl && planes_only_regime(c, h->dec, prec, regime_rows) && (ffn_terms == 0 || ffn_terms == kFfnMx);
+    const bool po = dec_pl && planes_only_regime(c, h->dec, prec, regime_rows) && (ffn_terms == 0 || ffn_terms == kFfnMx || ffn_terms == kFfnMx4);
     if (c.decoder_input_layer) {   // decoder input layer: Linear -> LN -> ReLU -> + alpha * pe   (reference encoder.py:118-125)
         GemmArgs a = gemm_args(h->dec_in, f.hfr, c.adim, R, dl.row_pos, po ? nullptr : f.sb.x0, c.ddim);
         a.Rp = dl.dims; a.regime_rows = regime_rows;
@@ -2118,8 +2152,8 @@ int fs2_op_conv_gemm(void* stream, const fs2_op_gemm_args* o) {
     if (!o) return fail(nullptr, FS2_ERR_ARG, "fs2_op_conv_gemm: null argument");
     ABI_CHECK(nullptr, "fs2_op_conv_gemm", o, fs2_op_gemm_args);
     if (!o->x || !o->w || o->R <= 0) return fail(nullptr, FS2_ERR_ARG, "fs2_op_conv_gemm: bad arguments");
-    if (o->precision < FS2_PREC_FP32 || o->precision > FS2_PREC_MIX_MX) return fail(nullptr, FS2_ERR_ARG, "unknown precision %d", o->precision);
-    const bool mx = o->precision == FS2_PREC_MIX_MX;   // THIS operator in the fp16 + block-scaled-fp8 arithmetic (convolutions, C % 128 == 0)
+    if (o->precision < FS2_PREC_FP32 || o->precision > FS2_PREC_MIX_MX4) return fail(nullptr, FS2_ERR_ARG, "unknown precision %d", o->precision);
+    const bool mx = o->precision == FS2_PREC_MIX_MX || o->precision == FS2_PREC_MIX_MX4;   // THIS operator in the fp16 + block-scaled-fp8 arithmetic (convolutions, C % 128 == 0; the fp4 form exists inside the model only: its operand comes with row scales from a LayerNorm epilogue)
     const int f16t = mx ? 1 : ffn_f16_terms(o->precision);      // mixed modes: THIS operator on fp16 operands with 2 / 1 MFMAs per fragment pair
     hipStream_t s = (hipStream_t)stream;
     Gemm g; g.N = o->N; g.C = o->C; g.ktaps = o->ktaps; g.Cpad = round_up(o->C, kBK);

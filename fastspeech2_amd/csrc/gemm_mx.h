@@ -65,4 +65,56 @@ __global__ void repack_weight_mx(const float* w, int N, int C, int k, int Npad, 
     out[i] = o;
 }
 
+// ---- mx4 (gemm_planes.h: ARITH = 3; precision mode mix_mx4): the weight image with both cross terms in e2m1 and ONE scale per output channel.
+// units per (n, tap): C/64 of fp16 channels, then C/128 cross units (layout: gemm_planes.h)
+__host__ __device__ inline size_t mx4_image_bytes(int Npad, int C, int ktaps) { return (size_t)Npad * (C / 64 + C / 128) * ktaps * 128; }
+
+// ws[n] = scale byte of output channel n (max over channels and taps of |fp16(w)|); rows n >= N: 127
+__global__ void weight_rowscale_mx4(const float* w, int N, int CK, int Npad, unsigned char* ws) {
+    const int n = blockIdx.x;
+    float m = 0.f;
+    if (n < N)
+        for (int i = threadIdx.x; i < CK; i += blockDim.x) m = fmaxf(m, fabsf((float)(_Float16)w[(size_t)n * CK + i]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[n] = n < N ? (unsigned char)mx4_scale_byte(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))) : (unsigned char)127;
+}
+
+// weights [N][C][k] fp32 -> mx4 image [Npad][unit][tap][128 B]; one 4-byte word (four channels of one part) per thread
+__global__ void repack_weight_mx4(const float* w, int N, int C, int k, int Npad, const unsigned char* ws, unsigned* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nmain = C / 64, units = nmain + C / 128;
+    const int64_t total = (int64_t)Npad * units * k * 32;
+    if (i >= total) return;
+    const int word = (int)(i & 31);
+    int64_t rest = i >> 5;
+    const int tap = (int)(rest % k); rest /= k;
+    const int unit = (int)(rest % units);
+    const int n = (int)(rest / units);
+    auto wv = [&](int c) { return (n < N && c < C) ? w[((size_t)n * C + c) * k + tap] : 0.f; };
+    unsigned o;
+    if (unit < nmain) {          // fp16 channels 64 unit + 2 word, + 1
+        const _Float16 h0 = (_Float16)wv(unit * 64 + 2 * word), h1 = (_Float16)wv(unit * 64 + 2 * word + 1);
+        o = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    } else {                     // cross unit: channels c .. c + 3: bytes [wh4 wh4 | wh4 wh4 | rw4 rw4 | rw4 rw4] (common.h: store_planes4_mx4 writes the activations the same way)
+        const int c = (unit - nmain) * 128 + 4 * word;
+        const float inv = mx4_inv_scale(n < N ? ws[n] : 127);
+        float h[4], r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = wv(c + j);
+            const float wh = (float)(_Float16)v;
+            h[j] = wh * inv; r[j] = (v - wh) * 2048.f * inv;
+        }
+        o = 0;
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(o, h[0], h[1], 1.f, 0);
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(o, h[2], h[3], 1.f, 1);
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(o, r[0], r[1], 1.f, 2);
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(o, r[2], r[3], 1.f, 3);
+    }
+    out[i] = o;
+}
+
 }  // namespace fs2

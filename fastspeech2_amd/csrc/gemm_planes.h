@@ -93,10 +93,25 @@ __device__ long long g_gemm_phase[8];
 // (the second half: ONE block-scaled K = 128 MFMA per fragment pair; first the units of ra8 against wh8, then those of ah8 against
 // rw8 -- the two cross terms).  Everything else -- DMA pattern, swizzle, double buffering, barriers, the two 16-byte LDS reads per
 // fragment -- is exactly the split-bf16 loop: per k-step 64 fp16 MFMAs or 32 scaled ones (both 1024 MFMA cycles) instead of 96.
+// ARITH = 3 ("mx4", round 6; precision mode mix_mx4; conv form only): the same product with BOTH cross terms in fp4 (e2m1): 1.5 MFMA-equivalents per
+// product instead of 2.0 (simulated first: tools/arith_sim_ffn_pareto.py, profiles/r06_ffn_arith_pareto.txt; timed first: tools/probes/make_fp4_probe.py).
+// A row of C channels is C/64 units of fp16 channels, as above, followed by C/128 CROSS units: unit j holds, for the channels c = 128 j + 4 q .. + 3
+// (q = 0 .. 31), the four bytes [ra4(c), ra4(c+1) | ra4(c+2), ra4(c+3) | ah4(c), ah4(c+1) | ah4(c+2), ah4(c+3)] with ra4 = e2m1((a - ah) 2^11 / s_row),
+// ah4 = e2m1(ah / s_row); the weight image has [wh4 wh4 | wh4 wh4 | rw4 rw4 | rw4 rw4] with rw4 = e2m1((w - wh) 2^11 / s_n), wh4 = e2m1(wh / s_n) at the
+// same byte positions, so that position by position the products are ra.wh 2^11 / (s_row s_n) and ah.rw 2^11 / (s_row s_n): ONE pair of E8M0 scale bytes per
+// (row, output channel), s_row = 2^e from the row's own maximum (written by the producing LayerNorm epilogue, one byte per row, 2^-11 folded in), s_n from
+// the output channel's.  e2m1 has two exponent bits: static per-tensor scales (what the e4m3 form uses) flush the residuals of small activations -- 4.4e-4
+// on the mel with fp6, worse with fp4; the per-row scale costs the producer one more reduction pass and this loop one ds_read_u8 per m-tile and step.
+// A cross unit issues TWO v_mfma_scale_f32_16x16x128_f8f6f4 with cbsz = blgp = 4 per fragment pair (16 cycles each; the operands are the two 16-byte
+// pieces slot lg / slot 4 + lg of the row: 64 channels each, both terms); the scale of a lane's 32-value block comes from the lane's own register
+// (tools/probes/fp4_probe.hip).  Per row 9 units are walked instead of 12 (C = 384): a quarter fewer MFMA cycles, LDS-DMA bytes, fragment reads and barriers.
+// The last C/128 units of the row (e4m3 of the residual, as in the mx planes) are never read here: they serve the planes-only residual reader of
+// gemm_row4_bf16 (RES = 2).
 template <int NSPLIT, int BM, bool K1, int ARITH = 0>
 __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs a) {
     constexpr bool F16 = ARITH == 1;
-    static_assert(ARITH != 2 || !K1, "the mx arithmetic exists for the conv form");
+    constexpr bool MX4 = ARITH == 3;
+    static_assert((ARITH != 2 && ARITH != 3) || !K1, "the mx arithmetics exist for the conv form");
     constexpr int MT = BM / 32;               // 16-row MFMA tiles per wave (wave tile = BM/2 x 64)
     constexpr int AROWS = pl_arows<BM, K1>();
     extern __shared__ __attribute__((aligned(16))) char smem_p[];
@@ -117,7 +132,8 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     const __bf16* Wb = reinterpret_cast<const __bf16*>(a.W);
     const __bf16* Xp = reinterpret_cast<const __bf16*>(a.Xp);
 
-    const int nchunks = a.Cpad / 32;
+    const int xunits = a.Cpad / 32;                      // 128-byte units per plane row
+    const int nchunks = MX4 ? xunits - xunits / 4 : xunits;      // units the loop walks (mx4: C/64 of fp16 channels + C/128 cross units; the weight image holds exactly these)
     const int niter = nchunks * ktaps;
     const int jrow = lane >> 3, jslot = lane & 7;        // this lane's (row, physical slot) inside a 1-KB DMA instruction
 
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     const int a_instr = K1 ? BM / 8 : (BM + 2 * P + 7) >> 3;
     const int sA = jslot ^ (jrow >> 1) ^ ((wave & 1) << 2);
     const int arow0 = m0 - P + wave * 8 + jrow;
-    const int xrc = a.xp_row_chunks ? a.xp_row_chunks : nchunks;      // chunks per plane row; grouped conv: this N tile's group starts at chunk cg
+    const int xrc = a.xp_row_chunks ? a.xp_row_chunks : xunits;      // chunks per plane row; grouped conv: this N tile's group starts at chunk cg
     const int cg = a.k_groups > 1 ? (n0 / (a.N / a.k_groups)) * nchunks : 0;
     const __bf16* a_src0 = Xp + (ptrdiff_t)arow0 * xrc * 64 + sA * 8 + cg * 64;      // dereferenced only when the row is in [0, R)
     const size_t a_qstride = (size_t)32 * xrc * 64;
@@ -165,6 +181,17 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     const int c_begin = (a.ksplit > 1) ? ks * (nchunks / a.ksplit) : 0;
     const int c_end = (a.ksplit > 1) ? c_begin + nchunks / a.ksplit : nchunks;
     const int it_end = c_end * ktaps;
+    // mx4: the E8M0 scale bytes of the A tile's rows (one per row, the same for every unit) into LDS behind the operand buffers; the first
+    // dma_barrier of the loop makes them visible.  This lane's four output channels' weight scales: one register, byte nt = n-tile nt (op_sel).
+    unsigned char* Sc = reinterpret_cast<unsigned char*>(smem_p) + pl_lds_bytes<BM, K1>();
+    int sbw = 0;
+    if constexpr (MX4) {
+        for (int t = tid; t < AROWS; t += 256) {
+            const int row = m0 - P + t;
+            Sc[t] = (row >= 0 && row < a.R) ? a.x_rowscale[row] : (unsigned char)127;
+        }
+        sbw = *reinterpret_cast<const int*>(a.w_rowscale + n0 + wn * 64 + 4 * lr);
+    }
     dma_A(c_begin, K1 ? (c_begin & 1) : 0);
     dma_B(c_begin * ktaps, (c_begin * ktaps) & 1);
     // The accumulators start at bias + residual (loaded while the first tiles are in flight), so the epilogue has no
@@ -191,7 +218,7 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     const long long t_begin = tprev, r_begin = __builtin_amdgcn_s_memrealtime();      // shader cycles vs the constant 100-MHz counter
 #endif
     // the k-loop over chunks [cb, ce) x taps; KIND (compile time) picks the MFMA body: 0 = split arithmetic per NSPLIT / ARITH, 1 = mx units
-    // of fp16 channels, 2 = mx units of e4m3 channels.  (Two instantiations for ARITH = 2 instead of a branch inside one loop: with both
+    // of fp16 channels, 2 = mx units of e4m3 channels, 3 = mx4 cross units (e2m1, both terms).  (Two instantiations for ARITH = 2 instead of a branch inside one loop: with both
     // bodies in one loop hipcc ran out of registers -- 108 spilled at BM = 256.)
     auto k_loop = [&](auto kind_tag, const int cb, const int ce) {
         constexpr int KIND = decltype(kind_tag)::value;
@@ -230,7 +257,23 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(ap0 + mt * 2048);
-                    if constexpr (KIND == 2) {
+                    if constexpr (KIND == 3) {
+                        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(ap1 + mt * 2048);
+                        const int sa = Sc[rb + mt * 16];             // this lane's row of m-tile mt at this tap
+                        const v4i_t z4 = v4i_t{0, 0, 0, 0};
+                        const v8i_t av0 = __builtin_shufflevector(__builtin_bit_cast(v4i_t, a0), z4, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const v8i_t av1 = __builtin_shufflevector(__builtin_bit_cast(v4i_t, a1), z4, 0, 1, 2, 3, 4, 5, 6, 7);
+#define FS2_MX4_PAIR(NT_)                                                                                                                              \
+                        acc[mt][NT_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av0, __builtin_shufflevector(__builtin_bit_cast(v4i_t, b0[NT_]), z4, 0, 1, 2, 3, 4, 5, 6, 7), \
+                                                                                       acc[mt][NT_], 4, 4, 0, sa, NT_, sbw);
+                        FS2_MX4_PAIR(0) FS2_MX4_PAIR(1) FS2_MX4_PAIR(2) FS2_MX4_PAIR(3)
+#undef FS2_MX4_PAIR
+#define FS2_MX4_PAIR(NT_)                                                                                                                              \
+                        acc[mt][NT_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av1, __builtin_shufflevector(__builtin_bit_cast(v4i_t, b1[NT_]), z4, 0, 1, 2, 3, 4, 5, 6, 7), \
+                                                                                       acc[mt][NT_], 4, 4, 0, sa, NT_, sbw);
+                        FS2_MX4_PAIR(0) FS2_MX4_PAIR(1) FS2_MX4_PAIR(2) FS2_MX4_PAIR(3)
+#undef FS2_MX4_PAIR
+                    } else if constexpr (KIND == 2) {
                         const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(ap1 + mt * 2048);
                         const v8i_t av = __builtin_shufflevector(__builtin_bit_cast(v4i_t, a0), __builtin_bit_cast(v4i_t, a1), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
@@ -268,7 +311,11 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
             }
         }
     };
-    if constexpr (ARITH == 2) {
+    if constexpr (ARITH == 3) {
+        const int nmain = xunits >> 1;         // units of fp16 channels
+        if (c_begin < nmain) k_loop(std::integral_constant<int, 1>{}, c_begin, c_end < nmain ? c_end : nmain);
+        if (c_end > nmain) k_loop(std::integral_constant<int, 3>{}, c_begin > nmain ? c_begin : nmain, c_end);
+    } else if constexpr (ARITH == 2) {
 #ifndef FS2_MX_SKIP      // (tools/probes/mx_conv_probe.hip: 1 = no fp16 units, 2 = no e4m3 units)
 #define FS2_MX_SKIP 0
 #endif

@@ -132,6 +132,7 @@ template <int NSPLIT, int NB, int MT, int EPI = 0, int SCHED = 2, int ARITH = 0,
 __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     static_assert(ARITH == 0 || (ARITH == 2 && NSPLIT == 3), "split-bf16 (0) or mx (2) operands");
     static_assert(RES >= 0 && RES <= 3 && (EPI != 3 || RES == 0), "residual source / output form");
+    static_assert(EPI != 4 || RES != 0, "EPI 4 (LayerNorm -> mx4 planes + one scale byte per row, the A operand of gemm_pl_bf16<.., ARITH = 3>) exists planes-only");
     constexpr int NT = 4 * NB, NP = NT / 2, BM = 32 * MT, BN = 128 * NB, RW = 16 * MT;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int PIECES = MT + 4 * NB;                       // one-KB LDS-DMA pieces per wave and stage: A pieces first (they come from HBM), then B
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     // RES 1: plane_byte(row, chunks, col0 + 64 g) = row chunks 128 + this lane's constant + 256 g;  RES 2: row 4 C + 2 (col0 + 64 g) [fp16] and + 2 C + col0 + 64 g [e4m3 residual]
     const size_t rrow_bytes = (size_t)a.residp_chunks * 128;
     const unsigned rlane = RES == 1 ? (unsigned)plane_byte(0, a.residp_chunks, col0) : (unsigned)(2 * col0);
+    const size_t roff8 = a.residp_mx == 2 ? 3 * rrow_bytes / 4 : rrow_bytes / 2;      // the e4m3 residual words of the row: mx planes at 2 C, mx4 planes at 3 C
     auto load_resid = [&](auto mt_tag) __attribute__((always_inline)) {
         constexpr int mt = decltype(mt_tag)::value;
 #pragma unroll
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
                 } else if constexpr (RES == 2) {
                     const char* q = rpl + (size_t)row * rrow_bytes;
                     const uint2 hf = load8_or_zero(q + rlane + 128 * g, row < a.R);
-                    const unsigned e8 = (unsigned)loadi_or_zero(reinterpret_cast<const int*>(q + rrow_bytes / 2 + col0 + 64 * g), row < a.R);
+                    const unsigned e8 = (unsigned)loadi_or_zero(reinterpret_cast<const int*>(q + roff8 + col0 + 64 * g), row < a.R);
                     rraw[mt & 1][g][r] = u32x4{hf.x, hf.y, e8, 0u};
                 }
             }
@@ -529,6 +531,49 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     f32x4 gam[NB], bet[NB];
 #pragma unroll
     for (int g = 0; g < NB; ++g) { gam[g] = *reinterpret_cast<const f32x4*>(a.ln_g + col0 + 64 * g); bet[g] = *reinterpret_cast<const f32x4*>(a.ln_b + col0 + 64 * g); }
+    // EPI 4 (mx4 planes): e2m1 has two exponent bits, so the cross-term copies carry ONE scale per ROW, taken from the row's own largest |LayerNorm output|:
+    // a fourth pass over the accumulators (the normalised values are recomputed in the store pass below: keeping 24 MT of them costs more than redoing 3 VALU
+    // each), reduced like the variances -- 16 lanes, then the two N-waves through LDS.  inv_row[mt][r] = 1 / s_row; the byte (2^-11 of the residuals'
+    // pre-scale folded in) goes to a.yp_rowscale[row], what gemm_pl_bf16<.., ARITH = 3> hands the scaled MFMA for this row.
+    float inv_row[MT][4];
+    if constexpr (EPI == 4) {
+        float rmax[MT][4];
+        for_seq_i<0, MT>([&](auto mt_tag) __attribute__((always_inline)) {
+            constexpr int mt = decltype(mt_tag)::value;
+            f32x4 m4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            for_seq_i<0, NB>([&](auto g_tag) __attribute__((always_inline)) {
+                constexpr int g = decltype(g_tag)::value;
+                for_seq_i<0, 4>([&](auto j_tag) __attribute__((always_inline)) {
+                    constexpr int j = decltype(j_tag)::value;
+                    const f32x4 x = acc_get<mt * NT + 4 * g + j>();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m4[r] = fmaxf(m4[r], fabsf((x[r] - mean[mt][r]) * rstd[mt][r] * gam[g][j] + bet[g][j]));
+                });
+            });
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = m4[r];
+                v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+                rmax[mt][r] = v;
+            }
+        });
+        __syncthreads();                                // (every wave has read the variance partials)
+        if (lr == 0)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * RW + mt * 16 + lg * 4 + r] = rmax[mt][r];
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int eb = mx4_scale_byte(fmaxf(rmax[mt][r], red[(wave ^ 1) * RW + mt * 16 + lg * 4 + r]));
+                inv_row[mt][r] = mx4_inv_scale(eb);
+                const int row = rowb + mt * 16 + rp[r];
+                if (lr == 0 && wn == 0 && row < a.R) a.yp_rowscale[row] = (unsigned char)(eb - 11);
+            }
+    }
     for_seq_i<0, MT>([&](auto mt_tag) __attribute__((always_inline)) {
         constexpr int mt = decltype(mt_tag)::value;
         int pos[4];
@@ -566,7 +611,8 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
                 }
                 if (row < a.R) {
                     if constexpr (RES == 0) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
-                    if constexpr (EPI == 1) store_planes4_mx(Yp, row, a.yp_chunks, col, v, a.yp_scale);
+                    if constexpr (EPI == 4) store_planes4_mx4(Yp, row, a.yp_chunks, col, v, a.yp_scale, inv_row[mt][r]);
+                    else if constexpr (EPI == 1) store_planes4_mx(Yp, row, a.yp_chunks, col, v, a.yp_scale);
                     else store_planes4(Yp, row, a.yp_chunks, col, v);
                 }
             }

@@ -69,6 +69,25 @@ def q_row(x, fmt, dims):
     return minifloat(x / sc, fmt) * sc
 
 
+def q_row2(x, fmt, dims, rule):
+    """q_row with the scale rule spelled out: "ocp" = 2^(floor(log2 max) - emax) (max / scale in [2^emax, 2^(emax+1)): the top quarter saturates);
+    "fit" = 2^(floor(log2(max / vmax)) + 1) (max / scale in [vmax / 2, vmax): nothing saturates, up to one binade of range unused)"""
+    E, M, vmax, emax = FORMATS[fmt]
+    mx = x.abs().amax(dim=dims, keepdim=True).clamp(min=2.0 ** -100)
+    sc = torch.exp2(torch.floor(torch.log2(mx)) - emax) if rule == "ocp" else torch.exp2(torch.floor(torch.log2(mx / vmax)) + 1.0)
+    return minifloat(x / sc, fmt) * sc
+
+
+def q_shared(x_main, x_res, fmt, dims, rule="fit", pre=2048.0):
+    """what the mix_mx4 kernels do (round 6): ONE power-of-two scale per slice for the fp16 part AND its residual x 2^11 (so that both cross terms
+    carry the same pair of scale bytes): scale = 2^(floor(log2(M / vmax)) + 1), M = max |x_main| over `dims` -- nothing saturates.  Returns the two
+    quantised tensors in their own scales."""
+    vmax, emax = FORMATS[fmt][2], FORMATS[fmt][3]
+    mx = x_main.abs().amax(dim=dims, keepdim=True).clamp(min=2.0 ** -100)
+    sc = torch.exp2(torch.floor(torch.log2(mx)) - emax) if rule == "ocp" else torch.exp2(torch.floor(torch.log2(mx / vmax)) + 1.0)
+    return minifloat(x_main / sc, fmt) * sc, minifloat(x_res * pre / sc, fmt) * sc / pre
+
+
 def exp_for(bound):
     return int(math.floor(math.log2(448.0 / max(bound, 1e-30))))
 
@@ -76,6 +95,8 @@ def exp_for(bound):
 # scheme = (MFMA-equivalents, label, cross term ra.wh, cross term ah.rw, taps that get cross terms); a cross term = (format, "static" | "block") or None
 E4, E5 = ("e4m3", "static"), ("e5m2", "static")
 F6, F6S, F4, F6W = ("e2m3", "block"), ("e2m3", "static"), ("e2m1", "block"), ("e3m2", "block")
+F4S = ("e2m1", "shared")
+F4SO, F4S12, F4SEP, F4SEPO = ("e2m1", "shared-ocp"), ("e2m1", "shared-4096"), ("e2m1", "sep-fit"), ("e2m1", "sep-ocp")      # the scheme built as precision mode mix_mx4: per frame / per output channel, fp16 part and residual x 2^11 under ONE scale
 F4R, F6R, F4H = ("e2m1", "row"), ("e2m3", "row"), ("e2m1", "hybrid")      # row: one scale per frame / per output channel; hybrid: activations per 32-block, weights per output channel
 SCHEMES = [
     (2.00, "today: both cross terms e4m3, static scales", E4, E4, "all"),
@@ -87,6 +108,11 @@ SCHEMES = [
     (1.50, "both cross terms fp6 e2m3, static scales", F6S, F6S, "all"),
     (1.50, "both cross terms fp4 e2m1, MX blocks of 32", F4, F4, "all"),
     (1.50, "both cross terms fp4 e2m1, one scale per frame / per output channel", F4R, F4R, "all"),
+    (1.50, "mix_mx4 as built: fp4 e2m1, ONE scale per frame / per output channel for both terms", F4S, F4S, "all"),
+    (1.50, "variant: one shared scale, OCP rule (top quarter saturates)", F4SO, F4SO, "all"),
+    (1.50, "variant: one shared scale, residual x 2^12", F4S12, F4S12, "all"),
+    (1.50, "variant: separate scales for the fp16 part and the residual, no saturation", F4SEP, F4SEP, "all"),
+    (1.50, "variant: separate scales, OCP rule", F4SEPO, F4SEPO, "all"),
     (1.50, "both cross terms fp6 e2m3, one scale per frame / per output channel", F6R, F6R, "all"),
     (1.50, "both fp4 e2m1: activations MX blocks, weights per output channel", F4H, F4H, "all"),
     (1.50, "ra.wh only (weights rounded to fp16 once), e4m3", E4, None, "all"),
@@ -126,10 +152,20 @@ def make_ffn(scheme, stats):
             if how == "row" or (how == "hybrid" and is_w):
                 return q_row(t, fmt, (1, 2) if is_w else (1,))
             return q_block(t, fmt, dim)
-        if c_ra is not None:
-            y = y + conv(quant(ra, c_ra, ka + 11, 1), quant(wh, c_ra, kw, 1) * mask)
-        if c_rw is not None:
-            y = y + conv(quant(ah, c_rw, ka, 1), quant(rw, c_rw, kw + 11, 1) * mask)
+        if c_ra is not None and c_ra[1].startswith("shared"):
+            rule = "ocp" if c_ra[1] == "shared-ocp" else "fit"
+            pre = 4096.0 if c_ra[1] == "shared-4096" else 2048.0
+            ah4, ra4 = q_shared(ah, ra, c_ra[0], (1,), rule, pre)
+            wh4, rw4 = q_shared(wh, rw, c_ra[0], (1, 2), rule, pre)
+            y = y + conv(ra4, wh4 * mask) + conv(ah4, rw4 * mask)
+        elif c_ra is not None and c_ra[1].startswith("sep"):
+            rule = c_ra[1][4:]
+            y = y + conv(q_row2(ra, c_ra[0], (1,), rule), q_row2(wh, c_ra[0], (1, 2), rule) * mask) + conv(q_row2(ah, c_ra[0], (1,), rule), q_row2(rw, c_ra[0], (1, 2), rule) * mask)
+        else:
+            if c_ra is not None:
+                y = y + conv(quant(ra, c_ra, ka + 11, 1), quant(wh, c_ra, kw, 1) * mask)
+            if c_rw is not None:
+                y = y + conv(quant(ah, c_rw, ka, 1), quant(rw, c_rw, kw + 11, 1) * mask)
         exact = conv(a, w1)
         stats.append((float((y - exact).abs().max()), float((y - exact).pow(2).mean().sqrt()), float(exact.abs().max())))
         h = torch.relu(y.float() + b1.view(1, -1, 1))
