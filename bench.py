@@ -52,7 +52,7 @@ WORKLOAD_TEXT = {
 
 
 def csrc_sha16():
-    """Fingerprint of the kernel sources (what profiles/r05_traffic.json was measured on)."""
+    """Fingerprint of the kernel sources (what profiles/r06_traffic.json was measured on)."""
     import hashlib
     hsh = hashlib.sha256()
     d = os.path.join(ROOT, "fastspeech2_amd", "csrc")
@@ -344,7 +344,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None, help="c1..c5 (default: c3 on one GPU, c5 = 128 utterances per GPU on several)")
-    ap.add_argument("--precision", default=os.environ.get("FS2_PRECISION", "mix_mx"))
+    ap.add_argument("--precision", default=os.environ.get("FS2_PRECISION", "mix_mx4"), help="arithmetic mode (default since round 6: mix_mx4 -- mix_mx with the decoder FFN "
+                    "conv's cross terms in block-scaled fp4 where the planes-only regime holds; rounds 3-5: mix_mx; rounds 1-2: bf16x3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-kernels", action="store_true", help="print the per-kernel hipEvent table to stderr")
     ap.add_argument("--graph", action="store_true", help="replay the forward as one captured HIP graph (single GPU; the launch-bound small configs)")
@@ -701,11 +702,11 @@ def main():
     try:    # HBM-side bytes per launch + the matrix-pipe occupancy of the same kernel: rocprofv3 PMC passes of this same command (tools/profile_round.sh
         # -> tools/pmc_summary.py -> profiles/).  The record names the kernel sources it was measured on: after any change to them it is stale and
         # the fields stay null instead of quoting an old kernel
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r05_traffic.json")))
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r06_traffic.json")))
         if (tr["workload"] == workload and tr["precision"] == args.precision and tr["kernel_site"] == dom_name and world == 1
                 and tr.get("csrc_sha16") == csrc_sha16()):
             roofline["traffic"] = tr["traffic_bytes"]
-            roofline["traffic_note"] = ("rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r05_traffic.json (separate --pmc passes of this "
+            roofline["traffic_note"] = ("rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per launch, profiles/r06_traffic.json (separate --pmc passes of this "
                                         "command on these kernel sources)")
             if roofline.get("algorithmic_bytes"):
                 roofline["traffic_over_algorithmic"] = round(tr["traffic_bytes"] / roofline["algorithmic_bytes"], 2)
@@ -769,7 +770,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s%s; default.yaml dims, free-running, random-init weights (seed 0), duration bias calibrated to 7.87 frames/phoneme"
                                    % (WORKLOAD_TEXT[workload], " -- here %d utterances on %d GPU(s)" % (B, world) if workload == "c5" else ""),
-                       "precision": args.precision,      # the arithmetic mode the line was measured in (rounds 1-2: bf16x3; since round 3: mix_mx)
+                       "precision": args.precision,      # the arithmetic mode the line was measured in (rounds 1-2: bf16x3; rounds 3-5: mix_mx; round 6: mix_mx4)
                        "utterances": B, "utterances_per_gpu": [len(p) for p in parts], "valid_frames_per_step": total_frames,
                        "phonemes": int(il.sum()),
                        "algorithmic_gflop_per_step": round(sum(path_flops(int(t), int(l)) for t, l in zip(il, ol_host)) / 1e9, 1),

@@ -108,8 +108,8 @@ SCHEMES = [
     (1.50, "both cross terms fp6 e2m3, static scales", F6S, F6S, "all"),
     (1.50, "both cross terms fp4 e2m1, MX blocks of 32", F4, F4, "all"),
     (1.50, "both cross terms fp4 e2m1, one scale per frame / per output channel", F4R, F4R, "all"),
-    (1.50, "mix_mx4 as built: fp4 e2m1, ONE scale per frame / per output channel for both terms", F4S, F4S, "all"),
-    (1.50, "variant: one shared scale, OCP rule (top quarter saturates)", F4SO, F4SO, "all"),
+    (1.50, "first candidate: ONE scale per frame / output channel that FITS the maximum (no saturation)", F4S, F4S, "all"),
+    (1.50, "mix_mx4 AS BUILT: one shared scale per frame / output channel, OCP rule (top quarter-binade saturates)", F4SO, F4SO, "all"),
     (1.50, "variant: one shared scale, residual x 2^12", F4S12, F4S12, "all"),
     (1.50, "variant: separate scales for the fp16 part and the residual, no saturation", F4SEP, F4SEP, "all"),
     (1.50, "variant: separate scales, OCP rule", F4SEPO, F4SEPO, "all"),

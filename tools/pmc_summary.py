@@ -7,9 +7,9 @@ HBM traffic = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes): on gfx950 FETCH_SIZE ta
 coalesced reads at 64 B (MI355X_MICROARCH.md, HBM/rocprofv3 section); WRITE_SIZE is used as is."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 workload = os.environ.get("FS2_PROF_WORKLOAD", "c3")
-precision = os.environ.get("FS2_PROF_PRECISION", "mix_mx")
+precision = os.environ.get("FS2_PROF_PRECISION", "mix_mx4")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")

@@ -2,17 +2,18 @@
 # Runs on the GPU box (gpurun): rocprofv3 passes over bench steps.  Kernel trace + stats in one run, each PMC group
 # in its own run (no trace domains together with --pmc).  Raw output -> gpurun_out/prof_<tag>/, summarise with
 # tools/pmc_summary.py on the build host and commit the summaries under profiles/.
-#   tools/profile_round.sh <tag> [workload] [precision] [pmc: 0|1]
+#   tools/profile_round.sh <tag> [workload] [precision] [pmc: 0|1] ["bench.py arguments" instead of the default --steps 4 --warmup 2]
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 WL=${2:-c3}
-PREC=${3:-mix_mx}
+PREC=${3:-mix_mx4}
 PMC=${4:-1}
+ARGS=${5:---steps 4 --warmup 2}
 OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python /root/repo/bench.py --workload $WL --precision $PREC --steps 4 --warmup 2 --no-cpu-baseline --sustain 0"
+CMD="python /root/repo/bench.py --workload $WL --precision $PREC $ARGS --no-cpu-baseline --sustain 0"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $CMD > "$OUT/trace.log" 2>&1
 if [ "$PMC" = "1" ]; then
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o p -- $CMD > "$OUT/fetch.log" 2>&1
