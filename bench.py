@@ -214,16 +214,24 @@ def smi_sclk_finish(started, local):
     except Exception:      # noqa: BLE001 -- a hung or missing tool only costs the field
         proc.kill()
         return None, None
-    vals = []
+    vals, in_gfx = [], False
     for ln in out.splitlines():
-        if re.search(r"sclk|GFX_\d+|gfx", ln, re.I):
-            m = re.search(r"(\d{3,4})\s*M[Hh]z", ln)
+        if tool == "amd-smi":      # "GFX_3:" opens a block (one per XCD) whose "CLK: 2103 MHz" line is the current clock (MIN_CLK / MAX_CLK are limits)
+            if re.match(r"\s*GFX_\d+:", ln):
+                in_gfx = True
+            elif in_gfx and re.match(r"\s*CLK:", ln):
+                m = re.search(r"(\d+)\s*M[Hh]z", ln)
+                if m:
+                    vals.append(float(m.group(1)))
+                in_gfx = False
+        elif re.search(r"sclk", ln, re.I):      # rocm-smi: "GPU[0] : sclk clock level: 7: (2100Mhz)"
+            m = re.search(r"\((\d+)\s*M[Hh]z\)", ln)
             if m:
                 vals.append(float(m.group(1)))
-    vals = [v for v in vals if v >= 500.0]
+    vals = [v for v in vals if v >= 500.0]          # (below the minimum DPM level: a sleeping XCD / the node's idle clock)
     if not vals:
         return None, None
-    return (vals[min(local, len(vals) - 1)] if tool == "rocm-smi" else max(vals)), tool
+    return (vals[min(local, len(vals) - 1)] if tool == "rocm-smi" else statistics.median(vals)), tool
 
 
 def mfma_peak_record():
@@ -541,7 +549,7 @@ def main():
                     v = read_clk()
                     if v:
                         clk.append(v)
-                if i == n_sus // 4 and rank == 0 and (not clk or statistics.median(clk) < 500.0):
+                if i == n_sus // 4 and rank == 0 and sum(1 for v in clk if v >= 500.0) < max(3, len(clk) // 2):
                     smi = smi_sclk_start()          # sysfs is absent or reads the node's clock: one SMI query while the queue is full
             if synth is not None:
                 synth.wait()
@@ -555,12 +563,13 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dts = float(t.item())
             smi_mhz, smi_tool = smi_sclk_finish(smi, local)
-            if clk and statistics.median(clk) >= 500.0:
-                sclk = dict(min=min(clk), median=statistics.median(clk), max=max(clk), samples=len(clk),
+            good = [v for v in clk if v >= 500.0]          # (readings below the lowest DPM level, 94-112 MHz, are a sleeping clock domain's, not this load's: discarded and counted)
+            if len(good) >= max(3, len(clk) // 2):
+                sclk = dict(min=min(good), median=statistics.median(good), max=max(good), samples=len(good), discarded_below_500mhz=len(clk) - len(good),
                             source="amdgpu sysfs pp_dpm_sclk, sampled by the host while the queue is full")
             elif smi_mhz is not None:
-                sclk = dict(median=smi_mhz, samples=1, source="%s, queried once while the queue was full (the sysfs node read %s MHz: the node's clock, not the chip's)"
-                                                              % (smi_tool, statistics.median(clk) if clk else None))
+                sclk = dict(median=smi_mhz, samples=1, source="%s, queried once while the queue was full (median over the XCDs; %d of %d sysfs samples read below 500 MHz)"
+                                                              % (smi_tool, len(clk) - len(good), len(clk)))
             else:
                 sclk = None                          # no trustworthy reading on this box: null, not the node's 95 MHz
             sustained = dict(steps=n_sus, seconds=round(dts, 3), ms_per_step=round(1e3 * dts / n_sus, 3), sclk_mhz=sclk)
