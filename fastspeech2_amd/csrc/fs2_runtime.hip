@@ -103,6 +103,7 @@ struct Options {
     int mt4 = -1;        // FS2_MT4      its m-tiles per wave (4 | 5: 128 / 160-row workgroups; -1: by the round count)
     int qkv4 = -1;       // FS2_QKV4     the fused QKV projection's passes on gemm_row4_bf16 (EPI 3) wherever gemm_qkv8_bf16 would run at D = 384: 0 never, else yes
     int ffn2_mx = 1;     // FS2_FFN2_MX  mix_mx mode: the second FFN GEMM in the mx arithmetic too, wherever gemm_row4_bf16 runs it (0: split-bf16 as in round 4)
+    int post_mx = 1;     // FS2_POST_MX  mixed modes: the Postnet's 512 -> 512 convolutions in the mx arithmetic (0: split-bf16 as until round 5)
 };
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -197,7 +198,7 @@ Options& opts() {
         Options x;
         x.bm = env_int("FS2_BM", -1); x.row8 = env_int("FS2_ROW8", -1); x.qkv8 = env_int("FS2_QKV8", -1);
         x.nosplitk = env_int("FS2_NOSPLITK", 0) != 0; x.f32_rows = env_int("FS2_F32_ROWS", 0) != 0; x.mt8 = env_int("FS2_MT8", -1); x.qkv_split = env_int("FS2_QKV_SPLIT", -1); x.op_att_planes = env_int("FS2_OP_ATT_PLANES", 0); x.fuse_var = env_int("FS2_FUSE_VAR", 1); x.bal = env_int("FS2_BAL", 0); x.w32 = env_int("FS2_ATTN_W32", -1);
-        x.row4 = env_int("FS2_ROW4", -1); x.mt4 = env_int("FS2_MT4", -1); x.ffn2_mx = env_int("FS2_FFN2_MX", 1); x.qkv4 = env_int("FS2_QKV4", -1);
+        x.row4 = env_int("FS2_ROW4", -1); x.mt4 = env_int("FS2_MT4", -1); x.ffn2_mx = env_int("FS2_FFN2_MX", 1); x.qkv4 = env_int("FS2_QKV4", -1); x.post_mx = env_int("FS2_POST_MX", 1);
         if (!audit_clean()) {
             x.w32 = 0; x.row4 = 0; x.qkv4 = 0;
             fprintf(stderr, "libfs2_hip: no clean ISA-audit record of this binary (libfs2_hip.audit.json next to it): attn_w32 and gemm_row4_bf16 are switched "
@@ -218,6 +219,7 @@ inline int att_width(int D, int heads) { return heads * padded_head_dim(D / head
 // Mixed modes: everything as bf16x3 except the FFN convolution w_1, which runs on fp16 operands with 2 or 1 MFMA per fragment pair.
 inline int base_precision(int p) { return (p == FS2_PREC_MIX_F16X2 || p == FS2_PREC_MIX_F16X1 || p == FS2_PREC_MIX_MX || p == FS2_PREC_MIX_MX4) ? FS2_PREC_BF16X3 : p; }
 constexpr int kFfnMx = 9;      // value of "ffn_terms" that selects the fp16 + block-scaled-fp8 arithmetic (gemm_mx.h)
+constexpr int kPostKa = 8;     // static scale exponent of the Postnet's mx operands: tanh outputs, |x| <= 1 -> 2^8 = 256 <= 448
 constexpr int kFfnMx4 = 10;    // ... the fp16 + block-scaled-fp4 arithmetic where the planes-only regime offers it (gemm_planes.h ARITH = 3), kFfnMx's elsewhere
 inline int ffn_f16_terms(int p) { return p == FS2_PREC_MIX_F16X2 ? 2 : (p == FS2_PREC_MIX_F16X1 ? 1 : (p == FS2_PREC_MIX_MX ? kFfnMx : (p == FS2_PREC_MIX_MX4 ? kFfnMx4 : 0))); }
 inline int scale_byte4(int e) { const int b = std::min(std::max(e, 1), 254); return b * 0x01010101; }
@@ -1418,6 +1420,18 @@ struct Loader {
             hipLaunchKernelGGL(repack_weight, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wsrc, Neach, C, k,
                                Neach, g.Cpad, bg, bv, 1e-5f, g.w + (size_t)p * Neach * k * g.Cpad, src_cols);
         }
+        if (!bn_prefix.empty() && k > 1 && parts == 1 && g.N % 128 == 0 && C % 128 == 0) {
+            // mx image of a BatchNorm-folded convolution (the Postnet's 512 -> 512 layers), from the library's own folded fp32 image; its operand is a tanh output:
+            // |x| <= 1 is the a-priori bound of the static activation scale (kPostKa)
+            if (!absmax_scratch && hipMalloc((void**)&absmax_scratch, 16) != hipSuccess) { if (!rc) rc = fail(h, FS2_ERR_HIP, "hipMalloc failed"); return g; }
+            g.kw = fp8_scale_exponent(device_absmax(s, g.w, (int64_t)Npad * k * g.Cpad, absmax_scratch));
+            const size_t bytes = mx_image_bytes(Npad, C, k);
+            void* pm = nullptr;
+            if (hipMalloc(&pm, bytes) != hipSuccess) { if (!rc) rc = fail(h, FS2_ERR_HIP, "hipMalloc of the mx weight image failed"); return g; }
+            h->allocs.push_back(pm);
+            g.wm = pm;
+            hipLaunchKernelGGL(repack_weight_mx, dim3((unsigned)((bytes / 2 + 255) / 256)), dim3(256), 0, s, g.w, g.N, C, k, Npad, g.kw, reinterpret_cast<unsigned short*>(pm), g.Cpad);
+        }
         if (!bnames.empty()) {
             g.bias = dalloc(g.N);
             if (!g.bias) return g;
@@ -2074,6 +2088,11 @@ int fs2_decode(fs2_handle* h, void* stream, const fs2_decode_io* io) {
             if (post_pl) {
                 a.Xp = (l == 0) ? f.sb.xps : ((l & 1) ? f.sb.x0p : f.sb.x1p);
                 if (!last) { a.Y = nullptr; a.Yp = (l & 1) ? f.sb.x1p : f.sb.x0p; a.yp_chunks = round_up(h->post[l].N, 32) / 32; }
+                // round 6: the 512 -> 512 layers in the mx arithmetic of the mixed modes (fp16 main term + e4m3 cross terms, 2 MFMA-equivalents instead of 3; simulated:
+                // mel +6e-6, tools/arith_sim_postnet.py): a layer whose image exists takes mx planes, so the layer in front of it writes them (tanh output: static scale 2^8)
+                const bool post_mx = (ffn_terms == kFfnMx || ffn_terms == kFfnMx4) && opts().post_mx;
+                if (post_mx && !last && h->post[l + 1].wm) { a.yp_f16 = 2; a.yp_scale = exp2f((float)kPostKa); }
+                if (post_mx && l > 0 && h->post[l].wm) { a.mx = 1; a.Wb = h->post[l].wm; a.mx_scale = scale_byte4(127 - kPostKa - 11); a.mx_scale_b = scale_byte4(127 - h->post[l].kw); }
             } else {
                 a.xp_scratch = rf > 1 ? f.xps2 : f.sb.xps;
             }
@@ -2351,6 +2370,7 @@ int fs2_set_option(const char* name, int32_t value) {
     else if (n == "FS2_MT4") o.mt4 = value;
     else if (n == "FS2_FFN2_MX") o.ffn2_mx = value != 0;
     else if (n == "FS2_QKV4") o.qkv4 = value;
+    else if (n == "FS2_POST_MX") o.post_mx = value != 0;
     else return fail(nullptr, FS2_ERR_ARG, "fs2_set_option: unknown option %s", name);
     return FS2_OK;
 }
@@ -2378,6 +2398,7 @@ int fs2_get_option(const char* name, int32_t* value) {
     else if (n == "FS2_MT4") *value = o.mt4;
     else if (n == "FS2_FFN2_MX") *value = o.ffn2_mx;
     else if (n == "FS2_QKV4") *value = o.qkv4;
+    else if (n == "FS2_POST_MX") *value = o.post_mx;
     else return fail(nullptr, FS2_ERR_ARG, "fs2_get_option: unknown option %s", name);
     return FS2_OK;
 }

@@ -32,8 +32,9 @@ namespace fs2 {
 // bytes of the mx weight image: Npad rows x (C / 32 units) x ktaps x 128 B  (= the split-bf16 image's size)
 __host__ __device__ inline size_t mx_image_bytes(int Npad, int C, int ktaps) { return (size_t)Npad * (C / 32) * ktaps * 128; }
 
-// weights [N][ldw or C][k] fp32 -> mx image [Npad][unit][tap][128 B]; kw: exponent of the static weight scale (|w| 2^kw <= 448)
-__global__ void repack_weight_mx(const float* w, int N, int C, int k, int Npad, int kw, unsigned short* out) {
+// weights [N][ldw or C][k] fp32 -> mx image [Npad][unit][tap][128 B]; kw: exponent of the static weight scale (|w| 2^kw <= 448).
+// repacked_ld > 0: the source is the library's own fp32 image [Npad][k][repacked_ld] (repack_weight: BatchNorm already folded in -- the Postnet's convolutions).
+__global__ void repack_weight_mx(const float* w, int N, int C, int k, int Npad, int kw, unsigned short* out, int repacked_ld = 0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 2-byte word per thread
     const int units = C / 32;
     const int64_t total = (int64_t)Npad * units * k * 64;
@@ -44,7 +45,7 @@ __global__ void repack_weight_mx(const float* w, int N, int C, int k, int Npad, 
     const int unit = (int)(rest % units);
     const int n = (int)(rest / units);
     const int nmain = C / 64, ncorr = C / 128;
-    auto wv = [&](int c) { return (n < N && c < C) ? w[((size_t)n * C + c) * k + tap] : 0.f; };
+    auto wv = [&](int c) { return (n < N && c < C) ? (repacked_ld ? w[((size_t)n * k + tap) * repacked_ld + c] : w[((size_t)n * C + c) * k + tap]) : 0.f; };
     unsigned short o;
     if (unit < nmain) {
         const _Float16 h = (_Float16)wv(unit * 64 + word);

@@ -278,7 +278,7 @@ int fs2_op_bucketize(void *stream, const float *x, int64_t n, const float *bins,
 int fs2_op_duration(void *stream, const float *d_log, int64_t n, int64_t *d);
 
 /* Kernel-choice switches for A/B measurements and tests ("FS2_BM", "FS2_ROW8", "FS2_QKV8", "FS2_NOSPLITK",
- * "FS2_F32_ROWS", "FS2_MT8", "FS2_FUSE_VAR", "FS2_BAL"; -1 = automatic).  Their initial values come from the environment variables of the same
+ * "FS2_F32_ROWS", "FS2_MT8", "FS2_FUSE_VAR", "FS2_BAL", "FS2_ATTN_W32", "FS2_ROW4", "FS2_MT4", "FS2_QKV4", "FS2_FFN2_MX", "FS2_POST_MX"; -1 = automatic).  Their initial values come from the environment variables of the same
  * names, read once when the library is first used; the launch path never reads the environment. */
 int fs2_set_option(const char *name, int32_t value);
 
