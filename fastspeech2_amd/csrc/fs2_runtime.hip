@@ -694,7 +694,7 @@ int launch_gemm(fs2_handle* h, hipStream_t s, const char* name, GemmArgs a, int 
         t.ksplit = 1;
         size_t y_slab = 0;       // 1: Y lives in the first slab of kpart (no fp32 output buffer of the caller's)
         const long rr = a.regime_rows ? a.regime_rows : a.R;
-        if (!row8 && !a.qk_hi && a.kpart && !opts().nosplitk && a.N <= 1024 && rr <= kSplitRegime && a.R <= kSplitRows) {
+        if (!row8 && !a.qk_hi && a.kpart && !opts().nosplitk && a.N <= 1024 && rr <= kSplitRegime && a.R <= kSplitRows && a.mx != 2) {      // (the mx4 conv walks 9 units per row, not Cpad / 32: it exists unsplit -- its regime never splits unless the row kernels are forced on a small batch)
             const int nchunks = a.Cpad / 32;
             const long wgs = (long)((a.N + kB16BN - 1) / kB16BN) * ((rr + 63) / 64);
             const bool own_y = t.Y != nullptr;

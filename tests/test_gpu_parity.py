@@ -587,6 +587,45 @@ def test_hip_graph_replay_of_the_forward(env):
         model.precision = "fp32"
 
 
+def test_planes_only_regime_through_the_other_entry_points(env, fs2_option):
+    """Round 6's big-regime forms -- the planes-only residual stream (gemm_row4_bf16 RES 1 / 2 / 3) and, in mix_mx4, the fp4 FFN conv with its row
+    scales -- reach every entry point, not only the synchronous per-utterance call the full-size tests make.  On a small batch with the row-complete kernels
+    forced (the regime a c3 / c4 batch is in): the device-driven layout is bit-identical to the host-driven one, a HIP-graph replay to the eager call, an
+    insufficient capacity NaN-fills the mels, `decoder_out` (rebuilt from the planes: no fp32 row exists any more) and the padded_compat teacher-forced pass
+    (`_forward` as the loss path runs it: convolutions and attention see the pad rows) match the oracle."""
+    model, sd, cfg, O = env
+    from fastspeech2_amd.synthetic import make_batch
+    b = make_batch("c3", B=6)
+    xs, il, ds = b["xs"].cuda(), b["ilens"], b["ds"].cuda()
+    fs2_option("FS2_ROW8", 1)
+    fs2_option("FS2_QKV8", 1)
+    for precision in ("mix_mx4", "bf16x3"):
+        model.precision = precision
+        try:
+            with torch.no_grad():
+                ref, ol = model.inference_batch(xs, il, d_override=ds)                       # host-driven layout
+                res = model.inference_batch(xs, il, d_override=ds, sync=False)               # device-driven layout
+                assert res.ok() and torch.equal(res[1].cpu(), ol) and torch.equal(res[0][:, : ref.shape[1]], ref), precision
+                small = model.inference_batch(xs, il, d_override=ds, sync=False, capacity=(int(ol.sum()) // 2, int(ol.max()) + 32))
+                assert not small.ok() and torch.isnan(small[0]).all()
+                assert not model.async_ok() and model.async_ok()
+                run = model.capture_graph(xs, il, d_override=ds)
+                mel, ol_dev, status = run(xs)
+                assert int(status.cpu()[2]) == 0 and torch.equal(mel[:, : ref.shape[1]], ref), precision
+                r = model._run(xs, il, b["olens"], ds, b["es"].cuda(), b["ps"].cuda(), is_inference=False, want=("after", "decoder_out"))
+                rc = model._run(xs, il, b["olens"], ds, b["es"].cuda(), b["ps"].cuda(), is_inference=False, compat=True, want=("after", "before"))
+        finally:
+            model.precision = "fp32"
+        o = O.per_utterance_forward(sd, cfg, b["xs"], b["ilens"], b["ds"], b["es"], b["ps"])
+        oc = O.padded_forward(sd, cfg, b["xs"], b["ilens"], b["olens"], b["ds"], b["es"], b["ps"])
+        tol = 3e-4 if precision == "mix_mx4" else 1e-4
+        for i in range(xs.shape[0]):
+            L = int(b["olens"][i])
+            assert _maxabs(r["after"][i, :L], o["after"][i, :L]) <= tol, (precision, i)
+            assert _maxabs(r["decoder_out"][i, :L], o["decoder_out"][i, :L]) <= 1e-3, (precision, i)
+        assert _maxabs(rc["after"], oc["after"]) <= tol and _maxabs(rc["before"], oc["before"]) <= tol, precision
+
+
 def test_graph_refuses_to_run_after_a_weight_reload_and_async_ring_wraps(env):
     """(1) A captured graph holds pointers into the library's weight copies: after the weights were re-uploaded `run` must raise instead
     of replaying onto released memory.  (2) More asynchronous calls in flight than pinned slots (16): the ring waits for and folds the
