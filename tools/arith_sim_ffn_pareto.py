@@ -78,12 +78,14 @@ def q_row2(x, fmt, dims, rule):
     return minifloat(x / sc, fmt) * sc
 
 
-def q_shared(x_main, x_res, fmt, dims, rule="fit", pre=2048.0):
+def q_shared(x_main, x_res, fmt, dims, rule="fit", pre=2048.0, clip=0.0):
     """what the mix_mx4 kernels do (round 6): ONE power-of-two scale per slice for the fp16 part AND its residual x 2^11 (so that both cross terms
     carry the same pair of scale bytes): scale = 2^(floor(log2(M / vmax)) + 1), M = max |x_main| over `dims` -- nothing saturates.  Returns the two
     quantised tensors in their own scales."""
     vmax, emax = FORMATS[fmt][2], FORMATS[fmt][3]
     mx = x_main.abs().amax(dim=dims, keepdim=True).clamp(min=2.0 ** -100)
+    if clip > 0.0:      # a robust maximum: an outlier saturates instead of taking the resolution of its whole slice
+        mx = torch.minimum(mx, clip * x_main.abs().mean(dim=dims, keepdim=True)).clamp(min=2.0 ** -100)
     sc = torch.exp2(torch.floor(torch.log2(mx)) - emax) if rule == "ocp" else torch.exp2(torch.floor(torch.log2(mx / vmax)) + 1.0)
     return minifloat(x_main / sc, fmt) * sc, minifloat(x_res * pre / sc, fmt) * sc / pre
 
@@ -96,7 +98,8 @@ def exp_for(bound):
 E4, E5 = ("e4m3", "static"), ("e5m2", "static")
 F6, F6S, F4, F6W = ("e2m3", "block"), ("e2m3", "static"), ("e2m1", "block"), ("e3m2", "block")
 F4S = ("e2m1", "shared")
-F4SO, F4S12, F4SEP, F4SEPO = ("e2m1", "shared-ocp"), ("e2m1", "shared-4096"), ("e2m1", "sep-fit"), ("e2m1", "sep-ocp")      # the scheme built as precision mode mix_mx4: per frame / per output channel, fp16 part and residual x 2^11 under ONE scale
+F4SO, F4S12, F4SEP, F4SEPO = ("e2m1", "shared-ocp"), ("e2m1", "shared-4096"), ("e2m1", "sep-fit"), ("e2m1", "sep-ocp")
+F4C8, F4C16, F4CW = ("e2m1", "shared-ocp-clip8"), ("e2m1", "shared-ocp-clip16"), ("e2m1", "shared-ocp-clipw8")      # the scheme built as precision mode mix_mx4: per frame / per output channel, fp16 part and residual x 2^11 under ONE scale
 F4R, F6R, F4H = ("e2m1", "row"), ("e2m3", "row"), ("e2m1", "hybrid")      # row: one scale per frame / per output channel; hybrid: activations per 32-block, weights per output channel
 SCHEMES = [
     (2.00, "today: both cross terms e4m3, static scales", E4, E4, "all"),
@@ -111,6 +114,9 @@ SCHEMES = [
     (1.50, "first candidate: ONE scale per frame / output channel that FITS the maximum (no saturation)", F4S, F4S, "all"),
     (1.50, "mix_mx4 AS BUILT: one shared scale per frame / output channel, OCP rule (top quarter-binade saturates)", F4SO, F4SO, "all"),
     (1.50, "variant: one shared scale, residual x 2^12", F4S12, F4S12, "all"),
+    (1.50, "robust: as built, maxima clipped at 8 x the slice's mean |x| (weights and activations)", F4C8, F4C8, "all"),
+    (1.50, "robust: as built, maxima clipped at 16 x mean", F4C16, F4C16, "all"),
+    (1.50, "robust: as built, WEIGHT maxima clipped at 8 x mean only", F4CW, F4CW, "all"),
     (1.50, "variant: separate scales for the fp16 part and the residual, no saturation", F4SEP, F4SEP, "all"),
     (1.50, "variant: separate scales, OCP rule", F4SEPO, F4SEPO, "all"),
     (1.50, "both cross terms fp6 e2m3, one scale per frame / per output channel", F6R, F6R, "all"),
@@ -153,10 +159,12 @@ def make_ffn(scheme, stats):
                 return q_row(t, fmt, (1, 2) if is_w else (1,))
             return q_block(t, fmt, dim)
         if c_ra is not None and c_ra[1].startswith("shared"):
-            rule = "ocp" if c_ra[1] == "shared-ocp" else "fit"
+            rule = "ocp" if c_ra[1].startswith("shared-ocp") else "fit"
             pre = 4096.0 if c_ra[1] == "shared-4096" else 2048.0
-            ah4, ra4 = q_shared(ah, ra, c_ra[0], (1,), rule, pre)
-            wh4, rw4 = q_shared(wh, rw, c_ra[0], (1, 2), rule, pre)
+            clip_w = 8.0 if c_ra[1].endswith(("clip8", "clipw8")) else (16.0 if c_ra[1].endswith("clip16") else 0.0)
+            clip_a = 0.0 if c_ra[1].endswith("clipw8") else clip_w
+            ah4, ra4 = q_shared(ah, ra, c_ra[0], (1,), rule, pre, clip_a)
+            wh4, rw4 = q_shared(wh, rw, c_ra[0], (1, 2), rule, pre, clip_w)
             y = y + conv(ra4, wh4 * mask) + conv(ah4, rw4 * mask)
         elif c_ra is not None and c_ra[1].startswith("sep"):
             rule = c_ra[1][4:]
@@ -177,6 +185,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--utterances", type=int, default=4)
     ap.add_argument("--only", default="", help="substring of the scheme labels to run")
+    ap.add_argument("--outliers", action="store_true", help="add a weight set with 0.1 %% of the FFN conv weights x 30")
     args = ap.parse_args()
     global SCHEMES
     if args.only:
@@ -191,6 +200,14 @@ def main():
     orig = O._ffn
     sets = [("default synthetic weights", sd0), ("LayerNorm gamma in [0.1, 8], beta in +-2", hostile_weights(sd0, "ln_wide")),
             ("Student-t(3) weights, same rms", hostile_weights(sd0, "student_t"))]
+    if args.outliers:
+        g = torch.Generator().manual_seed(3)
+        sdo = {k: v.clone() for k, v in sd0.items()}
+        for k, v in sdo.items():
+            if ".feed_forward.w_1.weight" in k:
+                m = torch.rand(v.shape, generator=g) < 1e-3
+                sdo[k] = torch.where(m, v * 30.0, v)
+        sets.append(("0.1 % of the FFN w_1 weights x 30", sdo))
     out = {}
     for wname, sd in sets:
         run = lambda: O.per_utterance_forward(sd, cfg, b["xs"], b["ilens"], b["ds"], b["es"], b["ps"])["after"]
