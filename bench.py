@@ -684,7 +684,7 @@ def main():
     if alone is not None and alone["avg_launch_ms"] > 0:
         # With several steps in flight a hipEvent bracket is not the kernel's duration: the second event waits for the kernel, the kernel waits in its
         # hardware queue for CUs that other streams' kernels hold (c3, 3 streams: bracket 0.57 ms, rocprofv3 dispatch timestamps of the same region
-        # 0.46 ms, the kernel alone 0.42 ms: profiles/r05_kernel_trace_by_region.txt).  The roofline of the kernel is therefore taken where the
+        # 0.46 ms, the kernel alone 0.42 ms: profiles/r06_kernel_trace_by_region.txt).  The roofline of the kernel is therefore taken where the
         # bracket IS the duration: the same launch site in the one-stream region behind the timed one (it agrees with rocprofv3 to 1 %).
         bracket_in_flight = avg_ms
         avg_ms = alone["avg_launch_ms"]
@@ -702,7 +702,7 @@ def main():
                                    "in flight an event bracket also holds the launch's wait in its hardware queue" % (alone["steps"], n_streams))
         roofline["timed_region_bracket"] = dict(steps_in_flight=n_streams, avg_bracket_ms=round(bracket_in_flight, 4),
                                                 frac_if_read_as_duration=round(algo / (bracket_in_flight * 1e-3) / 1e12 / peak, 4),
-                                                note="rocprofv3 dispatch timestamps of this region: profiles/r05_kernel_trace_by_region.txt")
+                                                note="rocprofv3 dispatch timestamps of this region: profiles/r06_kernel_trace_by_region.txt")
     if args.precision != "fp32":
         # what the chip sustains on random bf16 operands with nothing but MFMAs in flight (tools/probes/mfma_shape_probe.hip,
         # profiles/r02_mfma_shape_power_probe.txt: 1.8-2.1 PFLOP/s at 1.8-2.1 GHz, power-limited); `peak` stays the nominal figure
