@@ -43,7 +43,7 @@ struct Gemm {          // one repacked Linear / Conv1d
     void* wm = nullptr;      // weight image of the "mx" mode (gemm_mx.h; FFN w_1 convolutions with C % 128 == 0 and N % 128 == 0) ...
     int kw = 0;              // ... and the exponent of its static scale: |w| 2^kw <= 448
     void* wm4 = nullptr;     // weight image of the "mx4" mode (gemm_planes.h ARITH = 3: both cross terms in e2m1) ...
-    unsigned char* ws4 = nullptr;      // ... and its E8M0 scale bytes, one per output channel [Npad]
+    unsigned char* ws4 = nullptr;      // ... and its scale image: one E8M0 byte per 16-channel block of every weight row (gemm_mx.h: mx4_scale_image_bytes)
     float* bias = nullptr;   // [N] or null
     int N = 0, C = 0, Cpad = 0, ktaps = 1;
 };
@@ -639,7 +639,7 @@ hipError_t launch_mx(hipStream_t s, const GemmArgs& a) {
 // tile-height rule above picks 256 there for every N >= 1024), + 512 bytes of LDS for the A tile's row-scale bytes
 hipError_t launch_mx4(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
-    constexpr size_t lds = pl_lds_bytes<256, false>() + 512;
+    constexpr size_t lds = pl_lds_bytes<256, false>() + 512 + 2048;      // + the A tile's row-scale bytes + two stages of weight block scales
     static_assert(pl_arows<256, false>() <= 512, "one scale byte per A-tile row");
     allow_lds(reinterpret_cast<const void*>(&gemm_pl_bf16<1, 256, false, 3>), lds, attr);
     dim3 grid((a.N + kB16BN - 1) / kB16BN, (a.R + 255) / 256, 1);
@@ -1387,12 +1387,12 @@ struct Loader {
             hipLaunchKernelGGL(repack_weight_mx, dim3((unsigned)((bytes / 2 + 255) / 256)), dim3(256), 0, s, (const float*)d->data, g.N, C, k, Npad, g.kw,
                                reinterpret_cast<unsigned short*>(pm));
             if (k > 1) {      // the mx4 image of the same convolution (fp4 cross terms, one scale byte per output channel)
-                const size_t b4 = mx4_image_bytes(Npad, C, k);
+                const size_t b4 = mx4_image_bytes(Npad, C, k), bs = mx4_scale_image_bytes(Npad, C, k);
                 void *p4 = nullptr, *ps = nullptr;
-                if (hipMalloc(&p4, b4) != hipSuccess || hipMalloc(&ps, (size_t)Npad + 16) != hipSuccess) { if (!rc) rc = fail(h, FS2_ERR_HIP, "hipMalloc of the mx4 weight image failed"); return g; }
+                if (hipMalloc(&p4, b4) != hipSuccess || hipMalloc(&ps, bs) != hipSuccess) { if (!rc) rc = fail(h, FS2_ERR_HIP, "hipMalloc of the mx4 weight image failed"); return g; }
                 h->allocs.push_back(p4); h->allocs.push_back(ps);
                 g.wm4 = p4; g.ws4 = reinterpret_cast<unsigned char*>(ps);
-                hipLaunchKernelGGL(weight_rowscale_mx4, dim3(Npad), dim3(256), 0, s, (const float*)d->data, g.N, C * k, Npad, g.ws4);
+                hipMemsetAsync(ps, 127, bs, s);
                 hipLaunchKernelGGL(repack_weight_mx4, dim3((unsigned)((b4 / 4 + 255) / 256)), dim3(256), 0, s, (const float*)d->data, g.N, C, k, Npad, g.ws4,
                                    reinterpret_cast<unsigned*>(p4));
             }

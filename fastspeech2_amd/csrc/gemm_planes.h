@@ -99,8 +99,8 @@ __device__ long long g_gemm_phase[8];
 // (q = 0 .. 31), the four bytes [ra4(c), ra4(c+1) | ra4(c+2), ra4(c+3) | ah4(c), ah4(c+1) | ah4(c+2), ah4(c+3)] with ra4 = e2m1((a - ah) 2^11 / s_row),
 // ah4 = e2m1(ah / s_row); the weight image has [wh4 wh4 | wh4 wh4 | rw4 rw4 | rw4 rw4] with rw4 = e2m1((w - wh) 2^11 / s_n), wh4 = e2m1(wh / s_n) at the
 // same byte positions, so that position by position the products are ra.wh 2^11 / (s_row s_n) and ah.rw 2^11 / (s_row s_n): ONE pair of E8M0 scale bytes per
-// (row, output channel), s_row = 2^e from the row's own maximum (written by the producing LayerNorm epilogue, one byte per row, 2^-11 folded in), s_n from
-// the output channel's.  e2m1 has two exponent bits: static per-tensor scales (what the e4m3 form uses) flush the residuals of small activations -- 4.4e-4
+// (row, 16-channel block of the weight row), s_row = 2^e from the row's own maximum (written by the producing LayerNorm epilogue, one byte per row, 2^-11 folded
+// in), the weight side's from the block's own maximum (a lane's 16 bytes ARE the hardware's scale block: per-block scales are its native form).  e2m1 has two exponent bits: static per-tensor scales (what the e4m3 form uses) flush the residuals of small activations -- 4.4e-4
 // on the mel with fp6, worse with fp4; the per-row scale costs the producer one more reduction pass and this loop one ds_read_u8 per m-tile and step.
 // A cross unit issues TWO v_mfma_scale_f32_16x16x128_f8f6f4 with cbsz = blgp = 4 per fragment pair (16 cycles each; the operands are the two 16-byte
 // pieces slot lg / slot 4 + lg of the row: 64 channels each, both terms); the scale of a lane's 32-value block comes from the lane's own register
@@ -182,15 +182,22 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     const int c_end = (a.ksplit > 1) ? c_begin + nchunks / a.ksplit : nchunks;
     const int it_end = c_end * ktaps;
     // mx4: the E8M0 scale bytes of the A tile's rows (one per row, the same for every unit) into LDS behind the operand buffers; the first
-    // dma_barrier of the loop makes them visible.  This lane's four output channels' weight scales: one register, byte nt = n-tile nt (op_sel).
+    // dma_barrier of the loop makes them visible.  The weight side has a scale per 16-byte slot of every weight row (gemm_mx.h: mx4_scale_image_bytes): 1 KB per
+    // (N tile, cross unit, tap), fetched with the weight stage by ONE more LDS-DMA piece (wave 0) into a double buffer behind the row scales.
     unsigned char* Sc = reinterpret_cast<unsigned char*>(smem_p) + pl_lds_bytes<BM, K1>();
-    int sbw = 0;
+    const unsigned char* Sb = Sc + 512;
+    const int it_cross0 = (xunits >> 1) * ktaps;      // first cross-unit step
+    const unsigned char* wsb_tile = MX4 ? a.w_rowscale + (size_t)blockIdx.x * (xunits / 4) * ktaps * 1024 + lane * 16 : nullptr;
+    const unsigned ldsSb = lds0 + (unsigned)pl_lds_bytes<BM, K1>() + 512;
+    auto dma_S = [&](int it_next) {      // the scale block of step it_next (a cross-unit step) into buffer it_next & 1
+        if (MX4 && wave == 0 && it_next >= it_cross0) dma16(wsb_tile + (size_t)(it_next - it_cross0) * 1024, ldsSb + (it_next & 1) * 1024);
+    };
     if constexpr (MX4) {
         for (int t = tid; t < AROWS; t += 256) {
             const int row = m0 - P + t;
             Sc[t] = (row >= 0 && row < a.R) ? a.x_rowscale[row] : (unsigned char)127;
         }
-        sbw = *reinterpret_cast<const int*>(a.w_rowscale + n0 + wn * 64 + 4 * lr);
+        dma_S(c_begin * ktaps);
     }
     dma_A(c_begin, K1 ? (c_begin & 1) : 0);
     dma_B(c_begin * ktaps, (c_begin * ktaps) & 1);
@@ -233,6 +240,7 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
                 if (it + 1 < it_end && !(FS2_PROBE_DMA == 1 && (it & 1)) && FS2_PROBE_DMA != 2) {
                     dma_B(it + 1, (it + 1) & 1);
                     if (K1) dma_A(it + 1, (it + 1) & 1);
+                    if constexpr (MX4) dma_S(it + 1);
                 }
                 FS2_GT(1)
                 const char* As = As0 + (K1 ? (it & 1) : 0) * (AROWS * 128);
@@ -247,6 +255,8 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
                     b0[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
                     if (kNeedB1) b1[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
                 }
+                int2 sbq = int2{0, 0};
+                if constexpr (KIND == 3) sbq = *reinterpret_cast<const int2*>(Sb + (it & 1) * 1024 + (lg * 128 + wn * 64 + 4 * lr) * 2);
                 if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
                 // A fragments: the swizzle term ((row >> 1) & 7) of row wm BM/2 + 16 mt + lp + tap does not depend on mt, so the two pieces of
                 // m-tile mt sit at ONE per-step base address + mt * 2048 (an immediate offset of the LDS read) -- hipcc does not see this and
@@ -260,17 +270,18 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
                     if constexpr (KIND == 3) {
                         const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(ap1 + mt * 2048);
                         const int sa = Sc[rb + mt * 16];             // this lane's row of m-tile mt at this tap
+                        // (sbq: this lane's eight weight-scale bytes of the step -- [n-tile 0: slot lg | slot 4 + lg][n-tile 1: ..] | [n-tile 2 ..][n-tile 3 ..] -- read once per step below)
                         const v4i_t z4 = v4i_t{0, 0, 0, 0};
                         const v8i_t av0 = __builtin_shufflevector(__builtin_bit_cast(v4i_t, a0), z4, 0, 1, 2, 3, 4, 5, 6, 7);
                         const v8i_t av1 = __builtin_shufflevector(__builtin_bit_cast(v4i_t, a1), z4, 0, 1, 2, 3, 4, 5, 6, 7);
 #define FS2_MX4_PAIR(NT_)                                                                                                                              \
                         acc[mt][NT_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av0, __builtin_shufflevector(__builtin_bit_cast(v4i_t, b0[NT_]), z4, 0, 1, 2, 3, 4, 5, 6, 7), \
-                                                                                       acc[mt][NT_], 4, 4, 0, sa, NT_, sbw);
+                                                                                       acc[mt][NT_], 4, 4, 0, sa, 2 * ((NT_) & 1), (NT_) < 2 ? sbq.x : sbq.y);
                         FS2_MX4_PAIR(0) FS2_MX4_PAIR(1) FS2_MX4_PAIR(2) FS2_MX4_PAIR(3)
 #undef FS2_MX4_PAIR
 #define FS2_MX4_PAIR(NT_)                                                                                                                              \
                         acc[mt][NT_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av1, __builtin_shufflevector(__builtin_bit_cast(v4i_t, b1[NT_]), z4, 0, 1, 2, 3, 4, 5, 6, 7), \
-                                                                                       acc[mt][NT_], 4, 4, 0, sa, NT_, sbw);
+                                                                                       acc[mt][NT_], 4, 4, 0, sa, 2 * ((NT_) & 1) + 1, (NT_) < 2 ? sbq.x : sbq.y);
                         FS2_MX4_PAIR(0) FS2_MX4_PAIR(1) FS2_MX4_PAIR(2) FS2_MX4_PAIR(3)
 #undef FS2_MX4_PAIR
                     } else if constexpr (KIND == 2) {

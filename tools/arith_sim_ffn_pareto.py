@@ -99,6 +99,7 @@ E4, E5 = ("e4m3", "static"), ("e5m2", "static")
 F6, F6S, F4, F6W = ("e2m3", "block"), ("e2m3", "static"), ("e2m1", "block"), ("e3m2", "block")
 F4S = ("e2m1", "shared")
 F4SO, F4S12, F4SEP, F4SEPO = ("e2m1", "shared-ocp"), ("e2m1", "shared-4096"), ("e2m1", "sep-fit"), ("e2m1", "sep-ocp")
+F4WB = ("e2m1", "shared-ocp-wblock16")
 F4C8, F4C16, F4CW = ("e2m1", "shared-ocp-clip8"), ("e2m1", "shared-ocp-clip16"), ("e2m1", "shared-ocp-clipw8")      # the scheme built as precision mode mix_mx4: per frame / per output channel, fp16 part and residual x 2^11 under ONE scale
 F4R, F6R, F4H = ("e2m1", "row"), ("e2m3", "row"), ("e2m1", "hybrid")      # row: one scale per frame / per output channel; hybrid: activations per 32-block, weights per output channel
 SCHEMES = [
@@ -112,8 +113,9 @@ SCHEMES = [
     (1.50, "both cross terms fp4 e2m1, MX blocks of 32", F4, F4, "all"),
     (1.50, "both cross terms fp4 e2m1, one scale per frame / per output channel", F4R, F4R, "all"),
     (1.50, "first candidate: ONE scale per frame / output channel that FITS the maximum (no saturation)", F4S, F4S, "all"),
-    (1.50, "mix_mx4 AS BUILT: one shared scale per frame / output channel, OCP rule (top quarter-binade saturates)", F4SO, F4SO, "all"),
+    (1.50, "second candidate (first build): one shared scale per frame / output channel, OCP rule (top quarter-binade saturates)", F4SO, F4SO, "all"),
     (1.50, "variant: one shared scale, residual x 2^12", F4S12, F4S12, "all"),
+    (1.50, "mix_mx4 AS BUILT: activations one scale per frame, weights one per 16-channel block of a tap (the B operand's native block), OCP rule", F4WB, F4WB, "all"),
     (1.50, "robust: as built, maxima clipped at 8 x the slice's mean |x| (weights and activations)", F4C8, F4C8, "all"),
     (1.50, "robust: as built, maxima clipped at 16 x mean", F4C16, F4C16, "all"),
     (1.50, "robust: as built, WEIGHT maxima clipped at 8 x mean only", F4CW, F4CW, "all"),
@@ -164,7 +166,14 @@ def make_ffn(scheme, stats):
             clip_w = 8.0 if c_ra[1].endswith(("clip8", "clipw8")) else (16.0 if c_ra[1].endswith("clip16") else 0.0)
             clip_a = 0.0 if c_ra[1].endswith("clipw8") else clip_w
             ah4, ra4 = q_shared(ah, ra, c_ra[0], (1,), rule, pre, clip_a)
-            wh4, rw4 = q_shared(wh, rw, c_ra[0], (1, 2), rule, pre, clip_w)
+            if c_ra[1].endswith("wblock16"):      # weights [N, C, k] -> blocks of 16 channels of one (n, tap)
+                N_, C_, k_ = wh.shape
+                wb = lambda t: t.permute(0, 2, 1).reshape(N_, k_, C_ // 16, 16)
+                h4, r4 = q_shared(wb(wh), wb(rw), c_ra[0], (3,), rule, pre)
+                un = lambda t: t.reshape(N_, k_, C_).permute(0, 2, 1)
+                wh4, rw4 = un(h4), un(r4)
+            else:
+                wh4, rw4 = q_shared(wh, rw, c_ra[0], (1, 2), rule, pre, clip_w)
             y = y + conv(ra4, wh4 * mask) + conv(ah4, rw4 * mask)
         elif c_ra is not None and c_ra[1].startswith("sep"):
             rule = c_ra[1][4:]
