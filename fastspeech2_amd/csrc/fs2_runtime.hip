@@ -639,9 +639,11 @@ hipError_t launch_mx(hipStream_t s, const GemmArgs& a) {
 // tile-height rule above picks 256 there for every N >= 1024), + 512 bytes of LDS for the A tile's row-scale bytes
 hipError_t launch_mx4(hipStream_t s, const GemmArgs& a) {
     static LdsAttr attr;
-    constexpr size_t lds = pl_lds_bytes<256, false>() + 512 + 2048;      // + the A tile's row-scale bytes + two stages of weight block scales
-    static_assert(pl_arows<256, false>() <= 512, "one scale byte per A-tile row");
-    allow_lds(reinterpret_cast<const void*>(&gemm_pl_bf16<1, 256, false, 3>), lds, attr);
+    // + the A tile's scale bytes (8 per row and cross unit) + two stages of weight block scales; two workgroups per CU must still fit (a first build reserved 32 bytes per
+    // row = 78.3 KB per workgroup and ran 25 % slower: one workgroup per CU)
+    const size_t lds = pl_lds_bytes<256, false>() + kMx4RowScaleLds + 2048;
+    if (a.Cpad != 384) return hipErrorInvalidValue;      // (the LDS stride of the row scales is a compile-time constant: 8 bytes x 3 cross units; run_stack offers mx4 at D = 384 only)
+    allow_lds(reinterpret_cast<const void*>(&gemm_pl_bf16<1, 256, false, 3>), pl_lds_bytes<256, false>() + kMx4RowScaleLds + 2048, attr);
     dim3 grid((a.N + kB16BN - 1) / kB16BN, (a.R + 255) / 256, 1);
     hipLaunchKernelGGL((gemm_pl_bf16<1, 256, false, 3>), grid, dim3(256), lds, s, a);
     return hipGetLastError();
@@ -1065,7 +1067,7 @@ int run_stack(fs2_handle* h, hipStream_t s, const char* tag, const Stack& st, in
         a.ln_g = ly.ln1g; a.ln_b = ly.ln1b; a.ln_eps = 1e-5f;
         if (po) { a.residp = b.x0p; a.residp_chunks = D / 32; }      // (x0p: split-bf16 planes, from the input layer or the previous block's FFN2 + LN2)
         else { a.resid = b.x0; a.ldr = D; }
-        const bool mx4l = po && ffn_terms == kFfnMx4 && ly.w1.wm4 && b.xs4;                       // this layer's FFN conv in the mx4 arithmetic (fp4 cross terms; planes-only regime)?
+        const bool mx4l = po && ffn_terms == kFfnMx4 && ly.w1.wm4 && b.xs4 && D == 384;                       // this layer's FFN conv in the mx4 arithmetic (fp4 cross terms; planes-only regime)?
         const bool mxl = pl && (ffn_terms == kFfnMx || ffn_terms == kFfnMx4) && ly.w1.wm;         // ... in the mx arithmetic (also the fallback of mix_mx4 wherever mx4 does not apply)?
         const int f16t = (pl && ffn_terms && ffn_terms != kFfnMx && ffn_terms != kFfnMx4 && ly.w1.ktaps > 1 && ly.w1.wf) ? ffn_terms : 0;      // ... or on fp16 operands?
         if (pl) { a.Xp = ctxp; a.Yp = b.x1p; a.yp_chunks = D / 32; a.yp_f16 = mx4l ? 3 : (mxl ? 2 : (f16t ? 1 : 0)); a.yp_scale = mxl ? exp2f((float)ly.ka) : 1.f; }       // x1p feeds only that conv
@@ -1642,7 +1644,7 @@ size_t carve_frames(const fs2_config& c, const HostLayout& L, void* ws, size_t c
     f.sb.x0p = bp.take<float>(R * (size_t)round_up(std::max(c.ddim, c.postnet_chans), 32));
     f.sb.x1p = bp.take<float>(R * (size_t)round_up(std::max(std::max(c.adim, c.ddim), c.postnet_chans), 32));    // also holds the length-regulator output's planes
     f.sb.xps = bp.take<float>(R * (size_t)round_up(std::max(std::max(c.adim, c.ddim), std::max(std::max(c.var_chans, c.postnet_chans), c.odim)), 32));
-    f.sb.xs4 = bp.take<unsigned char>(R + 16);
+    f.sb.xs4 = bp.take<unsigned char>(R * 32 + 64);      // mx4: one scale byte per (row, 16-channel slot of a cross unit), 32 per row
     const size_t rf = (size_t)std::max(c.reduction_factor, 1);
     f.before = bp.take<float>(R * rf * c.odim);
     f.after = bp.take<float>(R * rf * c.odim);

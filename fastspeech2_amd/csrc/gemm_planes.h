@@ -29,6 +29,9 @@ constexpr size_t pl_lds_bytes() {
     const size_t out = (K1 && BM <= 128) ? (size_t)BM * kQkvLd * 4 : 0;       // fused QKV epilogue stages the fp32 tile here
     return ops > out ? ops : out;
 }
+typedef __attribute__((address_space(3))) const unsigned short lds_u16_t;
+constexpr int kMx4ScLd = 24;               // mx4 (ARITH = 3): scale bytes per row of the A tile in LDS (8 per cross unit; C = 384)
+constexpr int kMx4RowScaleLds = 272 * kMx4ScLd;      // ... for the 272 rows of a 256-row tile, behind the operand buffers
 template <int BM, bool K1> constexpr int pl_occ() { return pl_lds_bytes<BM, K1>() > 53 * 1024 ? 2 : 3; }
 
 // fp32 [R, ldx] -> planes (for activations whose producer is not plane-aware); channels >= C are zero
@@ -100,7 +103,8 @@ __device__ long long g_gemm_phase[8];
 // ah4 = e2m1(ah / s_row); the weight image has [wh4 wh4 | wh4 wh4 | rw4 rw4 | rw4 rw4] with rw4 = e2m1((w - wh) 2^11 / s_n), wh4 = e2m1(wh / s_n) at the
 // same byte positions, so that position by position the products are ra.wh 2^11 / (s_row s_n) and ah.rw 2^11 / (s_row s_n): ONE pair of E8M0 scale bytes per
 // (row, 16-channel block of the weight row), s_row = 2^e from the row's own maximum (written by the producing LayerNorm epilogue, one byte per row, 2^-11 folded
-// in), the weight side's from the block's own maximum (a lane's 16 bytes ARE the hardware's scale block: per-block scales are its native form).  e2m1 has two exponent bits: static per-tensor scales (what the e4m3 form uses) flush the residuals of small activations -- 4.4e-4
+// in), the weight side's from the block's own maximum (a lane's 16 bytes ARE the hardware's scale block: per-block scales are its native form) -- and since the
+// second build the activation side's too: one scale per (row, 16-channel slot), 32 bytes per row.  e2m1 has two exponent bits: static per-tensor scales (what the e4m3 form uses) flush the residuals of small activations -- 4.4e-4
 // on the mel with fp6, worse with fp4; the per-row scale costs the producer one more reduction pass and this loop one ds_read_u8 per m-tile and step.
 // A cross unit issues TWO v_mfma_scale_f32_16x16x128_f8f6f4 with cbsz = blgp = 4 per fragment pair (16 cycles each; the operands are the two 16-byte
 // pieces slot lg / slot 4 + lg of the row: 64 channels each, both terms); the scale of a lane's 32-value block comes from the lane's own register
@@ -181,21 +185,29 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
     const int c_begin = (a.ksplit > 1) ? ks * (nchunks / a.ksplit) : 0;
     const int c_end = (a.ksplit > 1) ? c_begin + nchunks / a.ksplit : nchunks;
     const int it_end = c_end * ktaps;
-    // mx4: the E8M0 scale bytes of the A tile's rows (one per row, the same for every unit) into LDS behind the operand buffers; the first
-    // dma_barrier of the loop makes them visible.  The weight side has a scale per 16-byte slot of every weight row (gemm_mx.h: mx4_scale_image_bytes): 1 KB per
+    // mx4: the E8M0 scale bytes of the A tile's rows (32 per row: one per 16-channel slot of every cross unit, gemm_row4.h EPI 4) into LDS behind the operand
+    // buffers; the first dma_barrier of the loop makes them visible.  The weight side has a scale per 16-byte slot of every weight row (gemm_mx.h: mx4_scale_image_bytes): 1 KB per
     // (N tile, cross unit, tap), fetched with the weight stage by ONE more LDS-DMA piece (wave 0) into a double buffer behind the row scales.
     unsigned char* Sc = reinterpret_cast<unsigned char*>(smem_p) + pl_lds_bytes<BM, K1>();
-    const unsigned char* Sb = Sc + 512;
+    constexpr int sc_ld = kMx4ScLd;                     // bytes per row of the A tile in LDS: 8 per cross unit, C = 384 (the launcher checks; the global records are 32 apart).
+                                                        // A compile-time stride: the eight reads of a step are then one base address + immediates (as a run-time stride they cost
+                                                        // registers the kernel does not have: 256 VGPRs + 28 bytes of scratch per lane, 25 % slower)
+    const unsigned char* Sb = Sc + AROWS * sc_ld;
     const int it_cross0 = (xunits >> 1) * ktaps;      // first cross-unit step
     const unsigned char* wsb_tile = MX4 ? a.w_rowscale + (size_t)blockIdx.x * (xunits / 4) * ktaps * 1024 + lane * 16 : nullptr;
-    const unsigned ldsSb = lds0 + (unsigned)pl_lds_bytes<BM, K1>() + 512;
+    const unsigned ldsSc = lds0 + (unsigned)pl_lds_bytes<BM, K1>();
+    const unsigned sc_lane = ldsSc + (unsigned)((wm * (BM / 2) + lp) * sc_ld + lg * 2);       // this lane's row of m-tile 0, tap 0, cross unit 0
+    const unsigned ldsSb = lds0 + (unsigned)pl_lds_bytes<BM, K1>() + (unsigned)(AROWS * sc_ld);
     auto dma_S = [&](int it_next) {      // the scale block of step it_next (a cross-unit step) into buffer it_next & 1
         if (MX4 && wave == 0 && it_next >= it_cross0) dma16(wsb_tile + (size_t)(it_next - it_cross0) * 1024, ldsSb + (it_next & 1) * 1024);
     };
     if constexpr (MX4) {
-        for (int t = tid; t < AROWS; t += 256) {
-            const int row = m0 - P + t;
-            Sc[t] = (row >= 0 && row < a.R) ? a.x_rowscale[row] : (unsigned char)127;
+        static_assert(!MX4 || AROWS * kMx4ScLd <= kMx4RowScaleLds, "row-scale records of the A tile");
+        constexpr int ncu = kMx4ScLd / 8;              // cross units per row: 8 scale bytes each
+        for (int t = tid; t < AROWS * ncu; t += 256) {      // 8 bytes (one cross unit of one row) per thread and turn
+            const int rt = t / ncu, u = t - rt * ncu, row = m0 - P + rt;
+            *reinterpret_cast<uint2*>(Sc + rt * sc_ld + u * 8) =
+                (row >= 0 && row < a.R) ? *reinterpret_cast<const uint2*>(a.x_rowscale + (size_t)row * 32 + u * 8) : uint2{0x7f7f7f7fu, 0x7f7f7f7fu};
         }
         dma_S(c_begin * ktaps);
     }
@@ -255,6 +267,9 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
                     b0[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, lg));
                     if (kNeedB1) b1[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + swz(n, 4 + lg));
                 }
+                // (KIND 3: this lane's row-scale words of the step, m-tile 0 -- as a 32-bit LDS address: through the generic pointer the compiler carries it in
+                //  64 bits, three register pairs the cross loop does not have, and the reload of the spilled one waits on vmcnt(0), i.e. on the stage's LDS-DMA)
+                const unsigned scp = sc_lane + (unsigned)__builtin_amdgcn_readfirstlane(tap * sc_ld + (chunk - (xunits >> 1)) * 8);
                 int2 sbq = int2{0, 0};
                 if constexpr (KIND == 3) sbq = *reinterpret_cast<const int2*>(Sb + (it & 1) * 1024 + (lg * 128 + wn * 64 + 4 * lr) * 2);
                 if (FS2_SETPRIO) __builtin_amdgcn_s_setprio(1);
@@ -269,7 +284,7 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
                     const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(ap0 + mt * 2048);
                     if constexpr (KIND == 3) {
                         const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(ap1 + mt * 2048);
-                        const int sa = Sc[rb + mt * 16];             // this lane's row of m-tile mt at this tap
+                        const int sa = *reinterpret_cast<lds_u16_t*>(scp + (unsigned)(mt * 16 * sc_ld));      // this lane's row of m-tile mt at this tap: byte 0 = slot lg, byte 1 = slot 4 + lg of this cross unit
                         // (sbq: this lane's eight weight-scale bytes of the step -- [n-tile 0: slot lg | slot 4 + lg][n-tile 1: ..] | [n-tile 2 ..][n-tile 3 ..] -- read once per step below)
                         const v4i_t z4 = v4i_t{0, 0, 0, 0};
                         const v8i_t av0 = __builtin_shufflevector(__builtin_bit_cast(v4i_t, a0), z4, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(256, (pl_occ<BM, K1>())) void gemm_pl_bf16(GemmArgs
 #undef FS2_MX4_PAIR
 #define FS2_MX4_PAIR(NT_)                                                                                                                              \
                         acc[mt][NT_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av1, __builtin_shufflevector(__builtin_bit_cast(v4i_t, b1[NT_]), z4, 0, 1, 2, 3, 4, 5, 6, 7), \
-                                                                                       acc[mt][NT_], 4, 4, 0, sa, 2 * ((NT_) & 1) + 1, (NT_) < 2 ? sbq.x : sbq.y);
+                                                                                       acc[mt][NT_], 4, 4, 1, sa, 2 * ((NT_) & 1) + 1, (NT_) < 2 ? sbq.x : sbq.y);
                         FS2_MX4_PAIR(0) FS2_MX4_PAIR(1) FS2_MX4_PAIR(2) FS2_MX4_PAIR(3)
 #undef FS2_MX4_PAIR
                     } else if constexpr (KIND == 2) {

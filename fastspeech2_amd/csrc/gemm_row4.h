@@ -531,49 +531,12 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
     f32x4 gam[NB], bet[NB];
 #pragma unroll
     for (int g = 0; g < NB; ++g) { gam[g] = *reinterpret_cast<const f32x4*>(a.ln_g + col0 + 64 * g); bet[g] = *reinterpret_cast<const f32x4*>(a.ln_b + col0 + 64 * g); }
-    // EPI 4 (mx4 planes): e2m1 has two exponent bits, so the cross-term copies carry ONE scale per ROW, taken from the row's own largest |LayerNorm output|:
-    // a fourth pass over the accumulators (the normalised values are recomputed in the store pass below: keeping 24 MT of them costs more than redoing 3 VALU
-    // each), reduced like the variances -- 16 lanes, then the two N-waves through LDS.  inv_row[mt][r] = 1 / s_row; the byte (2^-11 of the residuals'
-    // pre-scale folded in) goes to a.yp_rowscale[row], what gemm_pl_bf16<.., ARITH = 3> hands the scaled MFMA for this row.
-    float inv_row[MT][4];
-    if constexpr (EPI == 4) {
-        float rmax[MT][4];
-        for_seq_i<0, MT>([&](auto mt_tag) __attribute__((always_inline)) {
-            constexpr int mt = decltype(mt_tag)::value;
-            f32x4 m4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            for_seq_i<0, NB>([&](auto g_tag) __attribute__((always_inline)) {
-                constexpr int g = decltype(g_tag)::value;
-                for_seq_i<0, 4>([&](auto j_tag) __attribute__((always_inline)) {
-                    constexpr int j = decltype(j_tag)::value;
-                    const f32x4 x = acc_get<mt * NT + 4 * g + j>();
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) m4[r] = fmaxf(m4[r], fabsf((x[r] - mean[mt][r]) * rstd[mt][r] * gam[g][j] + bet[g][j]));
-                });
-            });
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = m4[r];
-                v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
-                rmax[mt][r] = v;
-            }
-        });
-        __syncthreads();                                // (every wave has read the variance partials)
-        if (lr == 0)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[wave * RW + mt * 16 + lg * 4 + r] = rmax[mt][r];
-        __syncthreads();
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int eb = mx4_scale_byte(fmaxf(rmax[mt][r], red[(wave ^ 1) * RW + mt * 16 + lg * 4 + r]));
-                inv_row[mt][r] = mx4_inv_scale(eb);
-                const int row = rowb + mt * 16 + rp[r];
-                if (lr == 0 && wn == 0 && row < a.R) a.yp_rowscale[row] = (unsigned char)(eb - 11);
-            }
-    }
+    // EPI 4 (mx4 planes): e2m1 has two exponent bits, so the cross-term copies carry a scale per (row, 16-channel slot) -- the block a lane of the consuming scaled
+    // MFMA holds -- taken from the slot's own largest |LayerNorm output|: the slot's 16 channels are this lane's four and those of its three neighbours (lr ^ 1, lr ^ 2),
+    // two shuffles inside the store pass below (the first build took ONE scale per row: a fourth pass over the accumulators and a cross-wave reduction, and channels
+    // whose gamma differ 80-fold shared it: 5.6e-4 on the mel under such weights, simulated 1.8e-4 per slot).  The byte (2^-11 of the residuals' pre-scale folded
+    // in) goes to a.yp_rowscale[row][32]: byte 8 u + 2 (s & 3) + (s >> 2) for slot s of cross unit u, so that a lane of gemm_pl_bf16<.., ARITH = 3> reads the scales of
+    // its two MFMAs of a step (slots lg and 4 + lg) as one 16-bit word.
     for_seq_i<0, MT>([&](auto mt_tag) __attribute__((always_inline)) {
         constexpr int mt = decltype(mt_tag)::value;
         int pos[4];
@@ -609,9 +572,19 @@ __global__ __launch_bounds__(256, 1) void gemm_row4_bf16(GemmArgs a) {
                     if constexpr (PE) { t = fmaxf(t, 0.f); t = t * a.x_scale + alpha * pe4[g][r][j]; }
                     v[j] = live ? t : 0.f;
                 }
+                int eb4 = 0;
+                if constexpr (EPI == 4) {      // (unconditional: every lane of the quad takes part in the shuffles; a quad shares its row)
+                    float m4 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    m4 = fmaxf(m4, __shfl_xor(m4, 1));
+                    m4 = fmaxf(m4, __shfl_xor(m4, 2));
+                    eb4 = mx4_scale_byte(m4);
+                }
                 if (row < a.R) {
                     if constexpr (RES == 0) *reinterpret_cast<f32x4*>(Y + (size_t)row * a.ldy + col) = v;
-                    if constexpr (EPI == 4) store_planes4_mx4(Yp, row, a.yp_chunks, col, v, a.yp_scale, inv_row[mt][r]);
+                    if constexpr (EPI == 4) {
+                        store_planes4_mx4(Yp, row, a.yp_chunks, col, v, a.yp_scale, mx4_inv_scale(eb4));
+                        if ((lr & 3) == 0) a.yp_rowscale[(size_t)row * 32 + (col >> 7) * 8 + ((col >> 4) & 3) * 2 + ((col >> 6) & 1)] = (unsigned char)(eb4 - 11);
+                    }
                     else if constexpr (EPI == 1) store_planes4_mx(Yp, row, a.yp_chunks, col, v, a.yp_scale);
                     else store_planes4(Yp, row, a.yp_chunks, col, v);
                 }

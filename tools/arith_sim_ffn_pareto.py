@@ -100,6 +100,7 @@ F6, F6S, F4, F6W = ("e2m3", "block"), ("e2m3", "static"), ("e2m1", "block"), ("e
 F4S = ("e2m1", "shared")
 F4SO, F4S12, F4SEP, F4SEPO = ("e2m1", "shared-ocp"), ("e2m1", "shared-4096"), ("e2m1", "sep-fit"), ("e2m1", "sep-ocp")
 F4WB = ("e2m1", "shared-ocp-wblock16")
+F4AB = ("e2m1", "shared-ocp-wblock16-ablock16")
 F4C8, F4C16, F4CW = ("e2m1", "shared-ocp-clip8"), ("e2m1", "shared-ocp-clip16"), ("e2m1", "shared-ocp-clipw8")      # the scheme built as precision mode mix_mx4: per frame / per output channel, fp16 part and residual x 2^11 under ONE scale
 F4R, F6R, F4H = ("e2m1", "row"), ("e2m3", "row"), ("e2m1", "hybrid")      # row: one scale per frame / per output channel; hybrid: activations per 32-block, weights per output channel
 SCHEMES = [
@@ -115,7 +116,8 @@ SCHEMES = [
     (1.50, "first candidate: ONE scale per frame / output channel that FITS the maximum (no saturation)", F4S, F4S, "all"),
     (1.50, "second candidate (first build): one shared scale per frame / output channel, OCP rule (top quarter-binade saturates)", F4SO, F4SO, "all"),
     (1.50, "variant: one shared scale, residual x 2^12", F4S12, F4S12, "all"),
-    (1.50, "mix_mx4 AS BUILT: activations one scale per frame, weights one per 16-channel block of a tap (the B operand's native block), OCP rule", F4WB, F4WB, "all"),
+    (1.50, "second build: activations one scale per frame, weights one per 16-channel block of a tap (the B operand's native block), OCP rule", F4WB, F4WB, "all"),
+    (1.50, "mix_mx4 AS BUILT: one scale per 16-channel block on BOTH sides (frame x 16 channels; weight row x tap x 16 channels), OCP rule", F4AB, F4AB, "all"),
     (1.50, "robust: as built, maxima clipped at 8 x the slice's mean |x| (weights and activations)", F4C8, F4C8, "all"),
     (1.50, "robust: as built, maxima clipped at 16 x mean", F4C16, F4C16, "all"),
     (1.50, "robust: as built, WEIGHT maxima clipped at 8 x mean only", F4CW, F4CW, "all"),
@@ -165,8 +167,15 @@ def make_ffn(scheme, stats):
             pre = 4096.0 if c_ra[1] == "shared-4096" else 2048.0
             clip_w = 8.0 if c_ra[1].endswith(("clip8", "clipw8")) else (16.0 if c_ra[1].endswith("clip16") else 0.0)
             clip_a = 0.0 if c_ra[1].endswith("clipw8") else clip_w
-            ah4, ra4 = q_shared(ah, ra, c_ra[0], (1,), rule, pre, clip_a)
-            if c_ra[1].endswith("wblock16"):      # weights [N, C, k] -> blocks of 16 channels of one (n, tap)
+            if c_ra[1].endswith("ablock16"):      # activations [B, C, T] -> blocks of 16 channels of one frame
+                B_, C2_, T_ = ah.shape
+                ab = lambda t: t.permute(0, 2, 1).reshape(B_, T_, C2_ // 16, 16)
+                a4, r4a = q_shared(ab(ah), ab(ra), c_ra[0], (3,), rule, pre)
+                ua = lambda t: t.reshape(B_, T_, C2_).permute(0, 2, 1)
+                ah4, ra4 = ua(a4), ua(r4a)
+            else:
+                ah4, ra4 = q_shared(ah, ra, c_ra[0], (1,), rule, pre, clip_a)
+            if "wblock16" in c_ra[1]:      # weights [N, C, k] -> blocks of 16 channels of one (n, tap)
                 N_, C_, k_ = wh.shape
                 wb = lambda t: t.permute(0, 2, 1).reshape(N_, k_, C_ // 16, 16)
                 h4, r4 = q_shared(wb(wh), wb(rw), c_ra[0], (3,), rule, pre)
