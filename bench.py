@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "mix_f16x2": 2500.0, "mix_f16x1": 2500.0, "mix_mx": 2500.0, "mix_mx4": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
 DTYPE_NAME = {"fp32": "f32", "bf16x3": "bf16x3", "bf16": "bf16", "mix_f16x2": "bf16x3 (FFN conv: f16x2)", "mix_f16x1": "bf16x3 (FFN conv: f16)",
               "mix_mx": "bf16x3 (FFN conv: f16 x f16 + block-scaled e4m3 cross terms)",
-              "mix_mx4": "bf16x3 (FFN conv: f16 x f16 + block-scaled e4m3 cross terms; the decoder's: block-scaled e2m1 cross terms, one scale per frame / output channel)"}
+              "mix_mx4": "bf16x3 (FFN conv: f16 x f16 + block-scaled e4m3 cross terms; the decoder's: block-scaled e2m1 cross terms, one E8M0 scale per 16-channel block on both operands)"}
 MFMA_PER_PRODUCT = {"bf16x3": 3, "mix_f16x2": 2, "mix_f16x1": 1, "mix_mx": 2.0, "mix_mx4": 1.5}       # MFMAs issued per algorithmic product in the dominant kernel (the FFN conv)
 HBM_PEAK_GBPS = 8000.0
 WORKLOAD_TEXT = {

@@ -51,7 +51,7 @@ extern "C" {
 /* as FS2_PREC_BF16X3, except that the 9-tap FFN convolution computes a.w = ah.wh (fp16 MFMA) + ra.wh + ah.rw (block-scaled
  * fp8 MFMA, v_mfma_scale_f32_16x16x128_f8f6f4): ~2.2 MFMA-equivalents per product at split-bf16-class accuracy */
 #define FS2_PREC_MIX_MX 5
-/* as FS2_PREC_MIX_MX with both cross terms of the decoder's FFN convolution in block-scaled fp4 (e2m1; one scale per frame and per output channel):
+/* as FS2_PREC_MIX_MX with both cross terms of the decoder's FFN convolution in block-scaled fp4 (e2m1; one E8M0 scale per 16-channel block of a frame / of a weight row and tap):
  * 1.5 MFMA-equivalents per product.  Applies where the decoder's activations travel as planes only (big frame-level regimes: gemm_row4_bf16
  * produces the operand with its row scales); everywhere else the mode IS FS2_PREC_MIX_MX.  Measured error / speed: BASELINE.md section 4. */
 #define FS2_PREC_MIX_MX4 6
