@@ -23,6 +23,7 @@ build-probes)
   /opt/rocm/bin/hipcc $HF $P/fp4_probe.hip -o $P/fp4_probe.bin &
   /opt/rocm/bin/hipcc $HF -DFS2_W32_ABL=0 $P/attn_w32_probe.hip -o $P/attn_w32_probe_abl0.bin &
   /opt/rocm/bin/hipcc $HF -DFS2_W32_ABL=256 $P/attn_w32_probe.hip -o $P/attn_w32_probe_abl256.bin &
+  /opt/rocm/bin/hipcc $HF -DFS2_CONV4_TIMING $P/conv4_probe.hip -o $P/conv4_probe.bin &      # the rejected one-wave-per-SIMD conv (profiles/r06_conv4_probe.txt)
   wait; ls -la $P/*.bin
   ;;
 tests)
@@ -70,6 +71,7 @@ probes)
   for r in 1 2; do for bm in 256 4256 2256; do $P/mx_conv_probe.bin 36611 384 1024 9 $bm 2 0 | tail -1; done; $P/mx_conv_probe.bin 36611 384 1024 9 256 0 0 | tail -1; done > $D/${TAG}_fp4_conv_probe.txt 2>&1
   for r in 1 2; do for bm in 256 4256; do $P/mx_conv_probe.bin 456700 384 1024 9 $bm 2 0 | tail -1; done; done >> $D/${TAG}_fp4_conv_probe.txt 2>&1
   tail -3 $D/${TAG}_fp4_conv_probe.txt
+  for rows in 35636 307000 76600; do $P/conv4_probe.bin $rows; done > $D/${TAG}_conv4_probe_raw.txt 2>&1      # c3 / c4 / c5-shard row counts
   ;;
 esac
 done
